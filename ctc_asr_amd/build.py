@@ -1,0 +1,63 @@
+"""Builds ``libctcasr.so`` (the C-ABI library of ``include/ctcasr.h``) for gfx950 with hipcc.
+
+In-tree, explicit ``hipcc -shared -fPIC``: the built library travels with the repository
+snapshot to the GPU box; no JIT cache is involved.  hipcc cross-compiles without a GPU.
+"""
+
+import glob
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, 'csrc')
+LIB_PATH = os.path.join(PKG_DIR, 'libctcasr.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC_DIR, '*.hip')))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC_DIR, '*.h')) + \
+        [os.path.join(PKG_DIR, '..', 'include', 'ctcasr.h'), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile every ``csrc/*.hip`` into one shared object; returns its path."""
+    if not force and not _stale():
+        return LIB_PATH
+    obj_dir = os.path.join(PKG_DIR, 'csrc', '_obj')
+    os.makedirs(obj_dir, exist_ok=True)
+    objects = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + '.o')
+        objects.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(
+                os.path.getmtime(src),
+                max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC_DIR, '*.h'))),
+                os.path.getmtime(os.path.join(PKG_DIR, '..', 'include', 'ctcasr.h'))):
+            continue
+        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in procs:
+        if proc.wait() != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objects
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

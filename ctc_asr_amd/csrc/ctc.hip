@@ -1,0 +1,366 @@
+// K8 / K9 / K10(greedy): log-softmax, CTC loss + gradient, greedy decode for gfx950.
+//
+// CTC alpha/beta is a dependency chain of T' steps per utterance with almost no bytes to move
+// (SURVEY.md 8d): one workgroup per utterance keeps the whole per-utterance log-softmax table
+// (T' x C floats, 58 KB at T'=500) and the extended-label lattice in LDS, so a step costs one
+// s_barrier and a handful of LDS reads; alpha goes to HBM once (for the gradient sweep) and is
+// prefetched one step ahead on the way back.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// log-softmax over C <= 64 classes: one wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) log_softmax_fwd_kernel(const float *__restrict__ x,
+                                                               float *__restrict__ y, int rows,
+                                                               int C) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        float v = lane < C ? x[(size_t)r * C + lane] : -INFINITY;
+        float mx = wave_max(v);
+        float e = lane < C ? expf(v - mx) : 0.f;
+        float lz = mx + logf(wave_sum(e));
+        if (lane < C) y[(size_t)r * C + lane] = v - lz;
+    }
+}
+
+__global__ void __launch_bounds__(256) log_softmax_bwd_kernel(const float *__restrict__ y,
+                                                               const float *__restrict__ dy,
+                                                               float *__restrict__ dx, int rows,
+                                                               int C) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        float g = lane < C ? dy[(size_t)r * C + lane] : 0.f;
+        float s = wave_sum(g);
+        if (lane < C) dx[(size_t)r * C + lane] = g - expf(y[(size_t)r * C + lane]) * s;
+    }
+}
+
+extern "C" int ctcasr_log_softmax_fwd(const float *x, float *y, int rows, int C,
+                                      ctcasr_stream_t stream) {
+    if (!x || !y || rows < 0 || C <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (C > 64) return CTCASR_ERR_UNSUPPORTED;
+    if (rows == 0) return CTCASR_OK;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    log_softmax_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, y, rows, C);
+    return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_log_softmax_bwd(const float *y, const float *dy, float *dx, int rows, int C,
+                                      ctcasr_stream_t stream) {
+    if (!y || !dy || !dx || rows < 0 || C <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (C > 64) return CTCASR_ERR_UNSUPPORTED;
+    if (rows == 0) return CTCASR_OK;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    log_softmax_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(y, dy, dx, rows, C);
+    return ctcasr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// CTC loss + gradient
+// ------------------------------------------------------------------------------------------
+#define CTC_THREADS 256
+#define CTC_MAX_PER_THREAD 4   // extended labels per thread: S = 2L+1 <= 1024
+
+// log(exp(a) + exp(b) + exp(c)); the state is kept in double so that |alpha| ~ 1e3 at T'=500
+// does not cost absolute precision, the exp/log of the O(1) differences run in float.
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    double m = fmax(a, fmax(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    float s = expf((float)(a - m)) + expf((float)(b - m)) + expf((float)(c - m));
+    return m + (double)logf(s);
+}
+
+struct CtcLds {
+    double *lat[2];   // lattice ping-pong (alpha, then beta), [S]
+    int *ext;         // extended labels [S]
+    float *occ[2];    // per-class occupancy ping-pong [64]
+    float *logp;      // [len * C] when it fits
+};
+
+template <bool LOGP_IN_LDS>
+__global__ void __launch_bounds__(CTC_THREADS)
+ctc_loss_kernel(const float *__restrict__ logits, const int *__restrict__ labels,
+                const int *__restrict__ label_offsets, const int *__restrict__ seq_len, int T,
+                int B, int C, int blank, int s_pad, float grad_scale, float *__restrict__ loss,
+                float *__restrict__ grad, int *__restrict__ status,
+                double *__restrict__ alpha_ws, float *__restrict__ logp_ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int L = label_offsets[b + 1] - label_offsets[b];
+    const int S = 2 * L + 1;
+    const int len = seq_len[b];
+    const int *lab = labels + label_offsets[b];
+
+    double *lat0 = reinterpret_cast<double *>(smem);
+    double *lat1 = lat0 + s_pad;
+    int *ext = reinterpret_cast<int *>(lat1 + s_pad);
+    float *occ0 = reinterpret_cast<float *>(ext + s_pad);
+    float *occ1 = occ0 + 64;
+    int *flags = reinterpret_cast<int *>(occ1 + 64);   // [0] bad label, [1] adjacent repeats
+    float *logp_s = reinterpret_cast<float *>(flags + 4);
+    float *logp = LOGP_IN_LDS ? logp_s : logp_ws + (size_t)b * T * C;
+
+    if (tid < 4) flags[tid] = 0;
+    if (tid < 64) { occ0[tid] = 0.f; occ1[tid] = 0.f; }
+    __syncthreads();
+    for (int u = tid; u < S; u += CTC_THREADS) {
+        int sym = blank;
+        if (u & 1) {
+            sym = lab[u >> 1];
+            if (sym < 0 || sym >= C || sym == blank) atomicOr(&flags[0], 1);
+            if (u >= 3 && lab[(u >> 1) - 1] == sym) atomicAdd(&flags[1], 1);
+        }
+        ext[u] = sym;
+    }
+    __syncthreads();
+    int st = 0;
+    if (flags[0] || len > T || len < 0) st = 2;
+    else if (len < L + flags[1]) st = 1;
+    const int live = st == 0 ? len : 0;
+
+    // gradient rows that carry no signal (beyond seq_len, or the whole utterance on error)
+    for (int i = tid; i < (T - live) * C; i += CTC_THREADS) {
+        int t = live + i / C, c = i % C;
+        grad[((size_t)t * B + b) * C + c] = 0.f;
+    }
+    if (st != 0) {
+        if (tid == 0) { status[b] = st; loss[b] = INFINITY; }
+        return;
+    }
+    if (len == 0) {
+        if (tid == 0) { status[b] = 0; loss[b] = 0.f; }
+        return;
+    }
+
+    // ---- phase 0: per-utterance log-softmax table ------------------------------------------
+    for (int t = tid; t < len; t += CTC_THREADS) {
+        const float *row = logits + ((size_t)t * B + b) * C;
+        float mx = row[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(row[c] - mx);
+        float lz = mx + logf(sum);
+        for (int c = 0; c < C; ++c) logp[t * C + c] = row[c] - lz;
+    }
+    __syncthreads();
+
+    // ---- phase 1: alpha ----------------------------------------------------------------------
+    double *aw = alpha_ws + (size_t)b * T * s_pad;
+    int my_ext[CTC_MAX_PER_THREAD];
+    bool skip_ok[CTC_MAX_PER_THREAD];   // may take the u-2 -> u (alpha) transition
+    bool skip_fw[CTC_MAX_PER_THREAD];   // may take the u -> u+2 (beta) transition
+#pragma unroll
+    for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+        int u = tid + i * CTC_THREADS;
+        my_ext[i] = u < S ? ext[u] : blank;
+        skip_ok[i] = u < S && u >= 2 && ext[u] != blank && ext[u] != ext[u - 2];
+        skip_fw[i] = u + 2 < S && ext[u + 2] != blank && ext[u + 2] != ext[u];
+    }
+#pragma unroll
+    for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+        int u = tid + i * CTC_THREADS;
+        if (u < S) {
+            double v = u == 0 ? (double)logp[blank] : (u == 1 ? (double)logp[my_ext[i]] : -INFINITY);
+            lat0[u] = v;
+            aw[u] = v;
+        }
+    }
+    __syncthreads();
+    for (int t = 1; t < len; ++t) {
+        double *cur = (t & 1) ? lat1 : lat0;
+        const double *prev = (t & 1) ? lat0 : lat1;
+        const float *lp = logp + t * C;
+#pragma unroll
+        for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+            int u = tid + i * CTC_THREADS;
+            if (u < S) {
+                double a0 = prev[u];
+                double a1 = u >= 1 ? prev[u - 1] : -INFINITY;
+                double a2 = skip_ok[i] ? prev[u - 2] : -INFINITY;
+                double v = lse3(a0, a1, a2);
+                if (v != -INFINITY) v += (double)lp[my_ext[i]];
+                cur[u] = v;
+                aw[(size_t)t * s_pad + u] = v;
+            }
+        }
+        __syncthreads();
+    }
+    const double *fin = ((len - 1) & 1) ? lat1 : lat0;
+    const double log_pzx = lse3(fin[S - 1], S > 1 ? fin[S - 2] : -INFINITY, -INFINITY);
+    __syncthreads();
+    if (tid == 0) { status[b] = 0; loss[b] = (float)(-log_pzx); }
+
+    // ---- phase 2: beta sweep, occupancy and gradient -------------------------------------------
+    // beta(t, u) excludes the emission at t, so alpha + beta is the joint log-probability.
+#pragma unroll
+    for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+        int u = tid + i * CTC_THREADS;
+        if (u < S) lat0[u] = (u >= S - 2) ? 0.0 : -INFINITY;
+    }
+    double a_pre[CTC_MAX_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+        int u = tid + i * CTC_THREADS;
+        a_pre[i] = u < S ? aw[(size_t)(len - 1) * s_pad + u] : -INFINITY;
+    }
+    __syncthreads();
+    int phase = 0;
+    for (int t = len - 1; t >= 0; --t, phase ^= 1) {
+        const double *cur = phase ? lat1 : lat0;
+        double *nxt = phase ? lat0 : lat1;
+        float *occ = phase ? occ1 : occ0;
+        const float *lp = logp + t * C;
+        double a_now[CTC_MAX_PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+            a_now[i] = a_pre[i];
+            int u = tid + i * CTC_THREADS;
+            if (t > 0 && u < S) a_pre[i] = aw[(size_t)(t - 1) * s_pad + u];   // prefetch
+        }
+#pragma unroll
+        for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+            int u = tid + i * CTC_THREADS;
+            if (u < S) {
+                double bu = cur[u];
+                double joint = a_now[i] + bu;
+                if (joint != -INFINITY && log_pzx != -INFINITY)
+                    atomicAdd(&occ[my_ext[i]], expf((float)(joint - log_pzx)));
+                if (t > 0) {
+                    double b0 = bu + (double)lp[my_ext[i]];
+                    double b1 = u + 1 < S ? cur[u + 1] + (double)lp[ext[u + 1]] : -INFINITY;
+                    double b2 = skip_fw[i] ? cur[u + 2] + (double)lp[ext[u + 2]] : -INFINITY;
+                    nxt[u] = lse3(b0, b1, b2);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < C) {
+            float g = expf(lp[tid]) - occ[tid];
+            occ[tid] = 0.f;
+            grad[((size_t)t * B + b) * C + tid] = g * grad_scale;
+        }
+    }
+}
+
+static size_t ctc_alpha_bytes(int T, int B, int max_label_len) {
+    return ctcasr_align_up((size_t)B * T * (2 * (size_t)max_label_len + 1) * sizeof(double), 256);
+}
+
+extern "C" size_t ctcasr_ctc_loss_workspace_bytes(int T, int B, int C, int max_label_len) {
+    if (T <= 0 || B <= 0 || C <= 0 || max_label_len < 0) return 0;
+    return ctc_alpha_bytes(T, B, max_label_len) +
+           ctcasr_align_up((size_t)B * T * C * sizeof(float), 256);
+}
+
+extern "C" int ctcasr_ctc_loss_fwd_bwd(const float *logits, const int32_t *labels,
+                                       const int32_t *label_offsets, const int32_t *seq_len, int T,
+                                       int B, int C, int blank, int max_label_len,
+                                       float grad_scale, float *loss, float *grad_logits,
+                                       int32_t *status, void *workspace, size_t workspace_bytes,
+                                       ctcasr_stream_t stream) {
+    if (!logits || !labels || !label_offsets || !seq_len || !loss || !grad_logits || !status)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (T <= 0 || B <= 0 || C <= 1 || blank < 0 || blank >= C || max_label_len < 0)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (C > 64) return CTCASR_ERR_UNSUPPORTED;
+    const int s_pad = 2 * max_label_len + 1;
+    if (s_pad > CTC_THREADS * CTC_MAX_PER_THREAD) return CTCASR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ctcasr_ctc_loss_workspace_bytes(T, B, C, max_label_len))
+        return CTCASR_ERR_WORKSPACE;
+    double *alpha_ws = reinterpret_cast<double *>(workspace);
+    float *logp_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                               ctc_alpha_bytes(T, B, max_label_len));
+    const size_t fixed = (size_t)s_pad * (2 * sizeof(double) + sizeof(int)) +
+                         128 * sizeof(float) + 4 * sizeof(int);
+    const size_t table = (size_t)T * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (fixed + table <= 150 * 1024) {
+        size_t lds = fixed + table;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&ctc_loss_kernel<true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return CTCASR_ERR_LAUNCH;
+        }
+        ctc_loss_kernel<true><<<B, CTC_THREADS, lds, s>>>(
+            logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, grad_scale, loss,
+            grad_logits, status, alpha_ws, logp_ws);
+    } else {
+        ctc_loss_kernel<false><<<B, CTC_THREADS, fixed, s>>>(
+            logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, grad_scale, loss,
+            grad_logits, status, alpha_ws, logp_ws);
+    }
+    return ctcasr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Greedy decode: one workgroup per utterance; argmax per frame, keep flags, block scan, scatter.
+// ------------------------------------------------------------------------------------------
+#define GREEDY_THREADS 256
+
+__global__ void __launch_bounds__(GREEDY_THREADS)
+greedy_decode_kernel(const float *__restrict__ logits, const int *__restrict__ seq_len, int T,
+                     int B, int C, int blank, int *__restrict__ out, int *__restrict__ out_len) {
+    __shared__ int carry_sym;      // argmax of the frame before the current chunk
+    __shared__ int base;           // symbols emitted so far
+    __shared__ int scan[GREEDY_THREADS];
+    __shared__ int syms[GREEDY_THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int len = seq_len[b];
+    if (len > T) len = T;
+    if (len < 0) len = 0;
+    if (tid == 0) { carry_sym = -1; base = 0; }
+    for (int i = tid; i < T; i += GREEDY_THREADS) out[(size_t)b * T + i] = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < len; t0 += GREEDY_THREADS) {
+        const int t = t0 + tid;
+        int best = -1;
+        if (t < len) {
+            const float *row = logits + ((size_t)t * B + b) * C;
+            float mx = row[0];
+            best = 0;
+            for (int c = 1; c < C; ++c) {
+                float v = row[c];
+                if (v > mx) { mx = v; best = c; }
+            }
+        }
+        syms[tid] = best;
+        __syncthreads();
+        int prev = tid == 0 ? carry_sym : syms[tid - 1];
+        int keep = (t < len && best != blank && best != prev) ? 1 : 0;
+        scan[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < GREEDY_THREADS; off <<= 1) {
+            int add = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        if (keep) out[(size_t)b * T + base + scan[tid] - 1] = best;
+        __syncthreads();
+        if (tid == GREEDY_THREADS - 1) {
+            base += scan[tid];
+            int last = len - 1 - t0;
+            carry_sym = syms[last < GREEDY_THREADS - 1 ? last : GREEDY_THREADS - 1];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out_len[b] = base;
+}
+
+extern "C" int ctcasr_ctc_greedy_decode(const float *logits, const int32_t *seq_len, int T, int B,
+                                        int C, int blank, int32_t *out, int32_t *out_len,
+                                        ctcasr_stream_t stream) {
+    if (!logits || !seq_len || !out || !out_len || T <= 0 || B <= 0 || C <= 0)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    greedy_decode_kernel<<<B, GREEDY_THREADS, 0, (hipStream_t)stream>>>(logits, seq_len, T, B, C,
+                                                                       blank, out, out_len);
+    return ctcasr_launch_status();
+}

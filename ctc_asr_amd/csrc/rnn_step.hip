@@ -1,0 +1,314 @@
+// K4/K5, streaming variant: one launch per time step, recurrent weights re-read from L2/MALL.
+//
+// This is the generic path of ctcasr_rnn_fwd/bwd (any H that is a multiple of 64, any B); the
+// LDS-resident persistent variant in rnn_persistent.hip takes over when the per-CU weight slice
+// fits.  Per step and direction the work is the skinny GEMM  [B, H] x [H, G*H]  (forward) or
+// [B, G*H] x [G*H, H] (backward data) on v_mfma_f32_16x16x4_f32, K split over the 4 waves of a
+// workgroup, with the gate non-linearities / cell update fused behind the reduction so the
+// pre-activations never touch HBM.
+//
+// Fragment trick used throughout: for a 16-float K chunk, lane l loads ONE float4 at
+// k = 16q + 4*(l>>4) for both operands; MFMA r (r = 0..3) then multiplies element r of those
+// float4s, i.e. lane group g covers k = 16q + 4g + r.  Every k is used exactly once, and both
+// operands are fetched with 16-byte loads instead of the 4-byte loads the textbook layout needs.
+#include "common.h"
+
+#define RNN_THREADS 256
+
+namespace {
+
+struct StepArgs {
+    const float *xw;       // [T, B, 2, G*H]
+    const float *w;        // fwd: w_hh [2, G*H, H]; bwd: w_hh_t [2, H, G*H]
+    const int *seq_len;    // [B] or nullptr
+    float *y;              // [T, B, 2H]
+    const float *dy;       // bwd
+    float *dxw;            // bwd out [T, B, 2, G*H]
+    float *gates;          // reserve: LSTM [T, B, 2, 4H] post-activation
+    float *cells;          // reserve: LSTM [T, B, 2, H]
+    float *hbuf;           // [2, 2, B, H] state ping-pong (fwd)
+    float *cbuf;           // [2, B, H] LSTM cell state (fwd) / dc carry (bwd)
+    int T, B, H, step;
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p) {
+    return *reinterpret_cast<const float4 *>(p);
+}
+
+__device__ __forceinline__ void mma4(f32x4 &acc, const float4 &a, const float4 &b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+
+// number of steps row b runs, and the time index it touches at step s
+__device__ __forceinline__ int row_steps(const int *seq_len, int b, int T) {
+    return seq_len ? min(max(seq_len[b], 0), T) : T;
+}
+__device__ __forceinline__ int row_time(int dir, int s, int steps) {
+    return dir == 0 ? s : steps - 1 - s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward step.  G gates, UPB = 32 / G units per workgroup -> 32 gate columns = 2 MFMA N tiles.
+// grid = (H / UPB, 2 directions, ceil(B / 16))
+// ---------------------------------------------------------------------------------------------
+template <int CELL>
+__global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
+    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    constexpr int UPB = 32 / G;
+    __shared__ float red[4][2][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y, mt = blockIdx.z;
+    const int u0 = blockIdx.x * UPB;
+    const int H = p.H, B = p.B;
+    const int pp = p.step & 1;
+    const float *hprev = p.hbuf + ((size_t)(pp * 2 + dir) * B) * H;
+    float *hnext = p.hbuf + ((size_t)((pp ^ 1) * 2 + dir) * B) * H;
+
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.step > 0) {
+        const int row = mt * 16 + (lane & 15);
+        const bool a_ok = row < B;
+        const int kq = 4 * (lane >> 4);
+        const float *arow = hprev + (size_t)(a_ok ? row : 0) * H + kq;
+        const float *brow[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int c = nt * 16 + (lane & 15);
+            int wrow = (c / UPB) * H + u0 + (c % UPB);
+            brow[nt] = p.w + ((size_t)dir * G * H + wrow) * H + kq;
+        }
+        const int kbeg = wave * (H / 4), kend = kbeg + H / 4;
+#pragma unroll 4
+        for (int k = kbeg; k < kend; k += 16) {
+            float4 a = a_ok ? ldg4(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b0 = ldg4(brow[0] + k);
+            float4 b1 = ldg4(brow[1] + k);
+            mma4(acc[0], a, b0);
+            mma4(acc[1], a, b1);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][nt][4 * (lane >> 4) + r][lane & 15] = acc[nt][r];
+    __syncthreads();
+
+    for (int item = tid; item < 16 * UPB; item += RNN_THREADS) {
+        const int bl = item / UPB, u = item % UPB;
+        const int b = mt * 16 + bl;
+        if (b >= B) continue;
+        const int unit = u0 + u;
+        const int steps = row_steps(p.seq_len, b, p.T);
+        const size_t hoff = (size_t)b * H + unit;
+        if (p.step >= steps) {   // beyond this row's length: carry the state, emit nothing
+            hnext[hoff] = p.step > 0 ? hprev[hoff] : 0.f;
+            continue;
+        }
+        const int t = row_time(dir, p.step, steps);
+        float rec[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int c = g * UPB + u;
+            rec[g] = red[0][c >> 4][bl][c & 15] + red[1][c >> 4][bl][c & 15] +
+                     red[2][c >> 4][bl][c & 15] + red[3][c >> 4][bl][c & 15];
+        }
+        const float *xw = p.xw + (((size_t)t * B + b) * 2 + dir) * G * H + unit;
+        float h;
+        if (CELL == CTCASR_CELL_LSTM) {
+            float gi = sigmoidf_(xw[0] + rec[0]);
+            float gf = sigmoidf_(xw[H] + rec[G > 1 ? 1 : 0]);
+            float gg = tanhf(xw[2 * H] + rec[G > 2 ? 2 : 0]);
+            float go = sigmoidf_(xw[3 * H] + rec[G > 3 ? 3 : 0]);
+            float *cst = p.cbuf + ((size_t)dir * B + b) * H + unit;
+            float cprev = p.step > 0 ? *cst : 0.f;
+            float c = gf * cprev + gi * gg;
+            *cst = c;
+            h = go * tanhf(c);
+            float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+            gr[0] = gi; gr[H] = gf; gr[2 * H] = gg; gr[3 * H] = go;
+            p.cells[(((size_t)t * B + b) * 2 + dir) * H + unit] = c;
+        } else {
+            float pre = xw[0] + rec[0];
+            h = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
+        }
+        hnext[hoff] = h;
+        p.y[((size_t)t * B + b) * 2 * H + dir * H + unit] = h;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward step s: dh_rec = dgates(step s+1) x W_hh  for 16 units, fused with the cell
+// derivative of step s for those units.  grid = (H / 16, 2, ceil(B / 16))
+// ---------------------------------------------------------------------------------------------
+template <int CELL>
+__global__ void __launch_bounds__(RNN_THREADS) rnn_bwd_step_kernel(StepArgs p) {
+    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    __shared__ float red[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y, mt = blockIdx.z;
+    const int u0 = blockIdx.x * 16;
+    const int H = p.H, B = p.B, GH = G * p.H;
+    const int s = p.step;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int row = mt * 16 + (lane & 15);
+        bool a_ok = row < B;
+        int steps = a_ok ? row_steps(p.seq_len, row, p.T) : 0;
+        a_ok = a_ok && (s + 1 < steps);
+        const int kq = 4 * (lane >> 4);
+        const int t_next = a_ok ? row_time(dir, s + 1, steps) : 0;
+        const float *arow = p.dxw + (((size_t)t_next * B + (a_ok ? row : 0)) * 2 + dir) * GH + kq;
+        const float *brow = p.w + ((size_t)dir * H + u0 + (lane & 15)) * GH + kq;
+        const int kbeg = wave * (GH / 4), kend = kbeg + GH / 4;
+        // wave-uniform early out is not possible (rows differ), but a fully dead tile is cheap:
+        if (__any(a_ok)) {
+#pragma unroll 4
+            for (int k = kbeg; k < kend; k += 16) {
+                float4 a = a_ok ? ldg4(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 b = ldg4(brow + k);
+                mma4(acc, a, b);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * (lane >> 4) + r][lane & 15] = acc[r];
+    __syncthreads();
+
+    const int bl = tid >> 4, u = tid & 15;
+    const int b = mt * 16 + bl;
+    if (b >= B) return;
+    const int steps = row_steps(p.seq_len, b, p.T);
+    if (s >= steps) return;
+    const int unit = u0 + u;
+    const int t = row_time(dir, s, steps);
+    const float dh = p.dy[((size_t)t * B + b) * 2 * H + dir * H + unit] +
+                     red[0][bl][u] + red[1][bl][u] + red[2][bl][u] + red[3][bl][u];
+    float *dx = p.dxw + (((size_t)t * B + b) * 2 + dir) * GH + unit;
+    if (CELL == CTCASR_CELL_LSTM) {
+        const float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+        const float gi = gr[0], gf = gr[H], gg = gr[2 * H], go = gr[3 * H];
+        const float c = p.cells[(((size_t)t * B + b) * 2 + dir) * H + unit];
+        float cprev = 0.f;
+        if (s > 0) {
+            const int tp = row_time(dir, s - 1, steps);
+            cprev = p.cells[(((size_t)tp * B + b) * 2 + dir) * H + unit];
+        }
+        float *dcst = p.cbuf + ((size_t)dir * B + b) * H + unit;
+        const float dc_in = (s + 1 < steps) ? *dcst : 0.f;
+        const float tc = tanhf(c);
+        const float dc = dc_in + dh * go * (1.f - tc * tc);
+        dx[0] = dc * gg * gi * (1.f - gi);
+        dx[H] = dc * cprev * gf * (1.f - gf);
+        dx[2 * H] = dc * gi * (1.f - gg * gg);
+        dx[3 * H] = dh * tc * go * (1.f - go);
+        *dcst = dc * gf;
+    } else {
+        const float h = p.y[((size_t)t * B + b) * 2 * H + dir * H + unit];
+        dx[0] = CELL == CTCASR_CELL_RNN_RELU ? (h > 0.f ? dh : 0.f) : dh * (1.f - h * h);
+    }
+}
+
+int cell_gates(int cell) {
+    switch (cell) {
+        case CTCASR_CELL_LSTM: return 4;
+        case CTCASR_CELL_GRU: return 3;
+        case CTCASR_CELL_RNN_RELU:
+        case CTCASR_CELL_RNN_TANH: return 1;
+        default: return 0;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H) {
+    if (T <= 0 || B <= 0 || H <= 0) return 0;
+    if (cell == CTCASR_CELL_LSTM) return (size_t)T * B * 2 * 5 * H * sizeof(float);
+    return 256;   // plain RNN cells recompute their derivative from y
+}
+
+extern "C" size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H) {
+    if (T <= 0 || B <= 0 || H <= 0 || cell_gates(cell) == 0) return 0;
+    // state ping-pong [2,2,B,H] + cell / dc carry [2,B,H]
+    return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256) + 4096;
+}
+
+static int rnn_check(int cell, int T, int B, int H) {
+    if (T <= 0 || B <= 0 || H <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (cell_gates(cell) == 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (cell == CTCASR_CELL_GRU) return CTCASR_ERR_UNSUPPORTED;
+    if (H % 64 != 0) return CTCASR_ERR_UNSUPPORTED;
+    return CTCASR_OK;
+}
+
+extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
+                              const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
+                              void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
+    (void)b_hh_n;
+    int rc = rnn_check(cell, T, B, H);
+    if (rc != CTCASR_OK) return rc;
+    if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
+        return CTCASR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    StepArgs p = {};
+    p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y;
+    p.gates = reinterpret_cast<float *>(reserve);
+    p.cells = p.gates + (size_t)T * B * 2 * 4 * H;
+    p.hbuf = reinterpret_cast<float *>(workspace);
+    p.cbuf = p.hbuf + (size_t)4 * B * H;
+    p.T = T; p.B = B; p.H = H;
+    if (seq_len &&
+        hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    const int G = cell_gates(cell);
+    dim3 grid(H / (32 / G), 2, (B + 15) / 16);
+    for (int step = 0; step < T; ++step) {
+        p.step = step;
+        if (cell == CTCASR_CELL_LSTM)
+            rnn_fwd_step_kernel<CTCASR_CELL_LSTM><<<grid, RNN_THREADS, 0, s>>>(p);
+        else if (cell == CTCASR_CELL_RNN_RELU)
+            rnn_fwd_step_kernel<CTCASR_CELL_RNN_RELU><<<grid, RNN_THREADS, 0, s>>>(p);
+        else
+            rnn_fwd_step_kernel<CTCASR_CELL_RNN_TANH><<<grid, RNN_THREADS, 0, s>>>(p);
+    }
+    return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
+                              const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
+                              const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                              size_t workspace_bytes, ctcasr_stream_t stream) {
+    (void)b_hh_n; (void)db_hh_n;
+    int rc = rnn_check(cell, T, B, H);
+    if (rc != CTCASR_OK) return rc;
+    if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
+        return CTCASR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = cell_gates(cell);
+    StepArgs p = {};
+    p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
+    p.gates = reinterpret_cast<float *>(const_cast<void *>(reserve));
+    p.cells = p.gates + (size_t)T * B * 2 * 4 * H;
+    p.hbuf = reinterpret_cast<float *>(workspace);
+    p.cbuf = p.hbuf + (size_t)4 * B * H;
+    p.T = T; p.B = B; p.H = H;
+    if (seq_len &&
+        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    dim3 grid(H / 16, 2, (B + 15) / 16);
+    for (int step = T - 1; step >= 0; --step) {
+        p.step = step;
+        if (cell == CTCASR_CELL_LSTM)
+            rnn_bwd_step_kernel<CTCASR_CELL_LSTM><<<grid, RNN_THREADS, 0, s>>>(p);
+        else if (cell == CTCASR_CELL_RNN_RELU)
+            rnn_bwd_step_kernel<CTCASR_CELL_RNN_RELU><<<grid, RNN_THREADS, 0, s>>>(p);
+        else
+            rnn_bwd_step_kernel<CTCASR_CELL_RNN_TANH><<<grid, RNN_THREADS, 0, s>>>(p);
+    }
+    return ctcasr_launch_status();
+}

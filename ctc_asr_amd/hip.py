@@ -1,0 +1,263 @@
+"""ctypes binding of ``libctcasr.so`` (``include/ctcasr.h``) for torch tensors.
+
+PyTorch only supplies device memory and the HIP stream here; every function below hands raw
+device pointers to the C ABI.  There is no fallback: a missing library, a CPU tensor or a
+non-zero status raises.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, 'libctcasr.so')
+
+CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
+CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}
+
+_c_int, _c_i64, _c_u64 = ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
+_c_f, _c_p, _c_sz = ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); doubles as the list of symbols the ABI must export
+SIGNATURES = {
+    'ctcasr_abi_version': (_c_int, []),
+    'ctcasr_error_string': (ctypes.c_char_p, [_c_int]),
+    'ctcasr_log_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
+    'ctcasr_log_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    'ctcasr_ctc_loss_workspace_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_ctc_loss_fwd_bwd': (_c_int, [_c_p] * 4 + [_c_int] * 5 + [_c_f] + [_c_p] * 4 +
+                                [_c_sz, _c_p]),
+    'ctcasr_ctc_greedy_decode': (_c_int, [_c_p, _c_p] + [_c_int] * 4 + [_c_p, _c_p, _c_p]),
+    'ctcasr_ctc_beam_workspace_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_ctc_beam_decode': (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_p] * 4 + [_c_sz, _c_p]),
+    'ctcasr_rnn_reserve_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_rnn_workspace_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
+    'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
+    'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
+    'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
+    'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
+    'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    'ctcasr_adam_step': (_c_int, [_c_p] * 4 + [_c_i64] + [_c_f] * 4 + [_c_i64, _c_f, _c_p]),
+}
+
+_lib = None
+
+
+class CtcAsrError(RuntimeError):
+    """Non-zero status from the C ABI."""
+
+
+def load(path=None):
+    """Load the library once; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise CtcAsrError('{} is missing - build it with `python -m ctc_asr_amd.build`; the '
+                          'MI355X path has no CPU fallback.'.format(path))
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI does not export the symbol
+        fn.restype, fn.argtypes = restype, argtypes
+    if lib.ctcasr_abi_version() != 1:
+        raise CtcAsrError('libctcasr ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _check(code, what):
+    if code != 0:
+        raise CtcAsrError('{} failed: {} ({})'.format(
+            what, load().ctcasr_error_string(code).decode(), code))
+
+
+def _dev(tensor, dtype=torch.float32, name='tensor'):
+    if tensor is None:
+        return None
+    if not tensor.is_cuda:
+        raise CtcAsrError('{} must live in HBM (got a CPU tensor); there is no CPU path.'
+                          .format(name))
+    if tensor.dtype != dtype:
+        raise CtcAsrError('{} must be {} (got {}).'.format(name, dtype, tensor.dtype))
+    if not tensor.is_contiguous():
+        raise CtcAsrError('{} must be contiguous.'.format(name))
+    return tensor.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+def log_softmax_fwd(x, out=None):
+    rows, classes = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    _check(load().ctcasr_log_softmax_fwd(_dev(x, name='x'), _dev(out, name='out'), rows, classes,
+                                         _stream()), 'log_softmax_fwd')
+    return out
+
+
+def log_softmax_bwd(y, dy, out=None):
+    rows, classes = y.numel() // y.shape[-1], y.shape[-1]
+    out = torch.empty_like(y) if out is None else out
+    _check(load().ctcasr_log_softmax_bwd(_dev(y, name='y'), _dev(dy, name='dy'),
+                                         _dev(out, name='out'), rows, classes, _stream()),
+           'log_softmax_bwd')
+    return out
+
+
+def ctc_loss_workspace_bytes(num_steps, batch, classes, max_label_len):
+    return load().ctcasr_ctc_loss_workspace_bytes(num_steps, batch, classes, max_label_len)
+
+
+def ctc_loss_fwd_bwd(logits, labels, label_offsets, seq_len, max_label_len, blank=None,
+                     grad_scale=1.0, loss=None, grad=None, status=None, workspace=None):
+    """logits f32[T,B,C]; labels/label_offsets/seq_len int32 device tensors.
+    Returns (loss f32[B], grad f32[T,B,C], status i32[B])."""
+    num_steps, batch, classes = logits.shape
+    blank = classes - 1 if blank is None else blank
+    dev = logits.device
+    loss = torch.empty(batch, dtype=torch.float32, device=dev) if loss is None else loss
+    grad = torch.empty_like(logits) if grad is None else grad
+    status = torch.empty(batch, dtype=torch.int32, device=dev) if status is None else status
+    need = ctc_loss_workspace_bytes(num_steps, batch, classes, max_label_len)
+    if workspace is None:
+        workspace = _workspace(need, dev)
+    _check(load().ctcasr_ctc_loss_fwd_bwd(
+        _dev(logits, name='logits'), _dev(labels, torch.int32, 'labels'),
+        _dev(label_offsets, torch.int32, 'label_offsets'), _dev(seq_len, torch.int32, 'seq_len'),
+        num_steps, batch, classes, blank, int(max_label_len), float(grad_scale),
+        _dev(loss, name='loss'), _dev(grad, name='grad'), _dev(status, torch.int32, 'status'),
+        _dev(workspace, torch.uint8, 'workspace'), workspace.numel(), _stream()),
+        'ctc_loss_fwd_bwd')
+    return loss, grad, status
+
+
+def ctc_greedy_decode(logits, seq_len, blank=None, out=None, out_len=None):
+    num_steps, batch, classes = logits.shape
+    blank = classes - 1 if blank is None else blank
+    dev = logits.device
+    out = torch.empty((batch, num_steps), dtype=torch.int32, device=dev) if out is None else out
+    out_len = torch.empty(batch, dtype=torch.int32, device=dev) if out_len is None else out_len
+    _check(load().ctcasr_ctc_greedy_decode(
+        _dev(logits, name='logits'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
+        classes, blank, _dev(out, torch.int32, 'out'), _dev(out_len, torch.int32, 'out_len'),
+        _stream()), 'ctc_greedy_decode')
+    return out, out_len
+
+
+def ctc_beam_decode(logits, seq_len, beam_width, blank=None, normalization='max'):
+    num_steps, batch, classes = logits.shape
+    blank = classes - 1 if blank is None else blank
+    dev = logits.device
+    out = torch.empty((batch, num_steps), dtype=torch.int32, device=dev)
+    out_len = torch.empty(batch, dtype=torch.int32, device=dev)
+    logp = torch.empty(batch, dtype=torch.float32, device=dev)
+    workspace = _workspace(load().ctcasr_ctc_beam_workspace_bytes(num_steps, batch, classes,
+                                                                  int(beam_width)), dev)
+    _check(load().ctcasr_ctc_beam_decode(
+        _dev(logits, name='logits'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
+        classes, blank, int(beam_width), {'max': 0, 'log_softmax': 1}[normalization],
+        _dev(out, torch.int32, 'out'), _dev(out_len, torch.int32, 'out_len'),
+        _dev(logp, name='logp'), _dev(workspace, torch.uint8, 'workspace'), workspace.numel(),
+        _stream()), 'ctc_beam_decode')
+    return out, out_len, logp
+
+
+def rnn_reserve_bytes(cell, num_steps, batch, hidden):
+    return load().ctcasr_rnn_reserve_bytes(CELL_IDS[cell], num_steps, batch, hidden)
+
+
+def rnn_workspace_bytes(cell, num_steps, batch, hidden):
+    return load().ctcasr_rnn_workspace_bytes(CELL_IDS[cell], num_steps, batch, hidden)
+
+
+def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None):
+    """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace)."""
+    num_steps, batch = xw.shape[0], xw.shape[1]
+    hidden = w_hh.shape[2]
+    dev = xw.device
+    y = torch.empty((num_steps, batch, 2 * hidden), dtype=torch.float32, device=dev) \
+        if y is None else y
+    if reserve is None:
+        reserve = _workspace(rnn_reserve_bytes(cell, num_steps, batch, hidden), dev)
+    if workspace is None:
+        workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
+    _check(load().ctcasr_rnn_fwd(
+        CELL_IDS[cell], _dev(xw, name='xw'), _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
+        _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
+        _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
+        workspace.numel(), _stream()), 'rnn_fwd')
+    return y, reserve, workspace
+
+
+def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, db_hh_n=None,
+            workspace=None):
+    """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H]."""
+    num_steps, batch = dy.shape[0], dy.shape[1]
+    hidden = w_hh_t.shape[1]
+    gates = CELL_GATES[cell]
+    dev = dy.device
+    dxw = torch.empty((num_steps, batch, 2, gates * hidden), dtype=torch.float32, device=dev) \
+        if dxw is None else dxw
+    if workspace is None:
+        workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
+    _check(load().ctcasr_rnn_bwd(
+        CELL_IDS[cell], _dev(dy, name='dy'), _dev(y, name='y'), _dev(w_hh_t, name='w_hh_t'),
+        _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
+        hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),
+        _dev(db_hh_n, name='db_hh_n'), _dev(workspace, torch.uint8, 'workspace'),
+        workspace.numel(), _stream()), 'rnn_bwd')
+    return dxw
+
+
+def bias_act_fwd(y, bias, cutoff, dropout_rate=0.0, seed=0):
+    """In place: y = dropout(min(max(y + bias, 0), cutoff)); cutoff <= 0 -> bias add only."""
+    cols = y.shape[-1]
+    _check(load().ctcasr_bias_act_fwd(_dev(y, name='y'), _dev(bias, name='bias'),
+                                      y.numel() // cols, cols, float(cutoff), float(dropout_rate),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), 'bias_act_fwd')
+    return y
+
+
+def bias_act_bwd(y, dy, cutoff, dropout_rate=0.0, dbias=None, dz=None):
+    cols = y.shape[-1]
+    dz = torch.empty_like(dy) if dz is None else dz
+    _check(load().ctcasr_bias_act_bwd(_dev(y, name='y'), _dev(dy, name='dy'), _dev(dz, name='dz'),
+                                      _dev(dbias, name='dbias'), y.numel() // cols, cols,
+                                      float(cutoff), float(dropout_rate), _stream()),
+           'bias_act_bwd')
+    return dz
+
+
+def colsum_accumulate(dz, dbias):
+    cols = dz.shape[-1]
+    _check(load().ctcasr_colsum_accumulate(_dev(dz, name='dz'), _dev(dbias, name='dbias'),
+                                           dz.numel() // cols, cols, _stream()),
+           'colsum_accumulate')
+    return dbias
+
+
+def transpose_batched(src, out=None):
+    """src f32[N, R, C] -> out f32[N, C, R]."""
+    batch, rows, cols = src.shape
+    out = torch.empty((batch, cols, rows), dtype=torch.float32, device=src.device) \
+        if out is None else out
+    _check(load().ctcasr_transpose_batched(_dev(src, name='src'), _dev(out, name='out'), batch,
+                                           rows, cols, _stream()), 'transpose_batched')
+    return out
+
+
+def adam_step(param, grad, m, v, step, lr=1e-5, beta1=0.9, beta2=0.999, epsilon=1e-8,
+              grad_scale=1.0):
+    _check(load().ctcasr_adam_step(_dev(param, name='param'), _dev(grad, name='grad'),
+                                   _dev(m, name='m'), _dev(v, name='v'), param.numel(), float(lr),
+                                   float(beta1), float(beta2), float(epsilon), int(step),
+                                   float(grad_scale), _stream()), 'adam_step')

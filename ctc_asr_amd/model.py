@@ -1,0 +1,543 @@
+"""The CTC acoustic model: DS1 / DS2 stacks, CTC loss, decoding, scoring.
+
+Drop-in counterpart of ``asr/model.py::CTCModel`` (``inference_fn`` :123-236, ``loss_fn``
+:238-269, ``decode_fn`` :271-309, ``error_rates_fn`` :311-345) and of the layer helpers in
+``asr/util/tf_contrib.py:34-194``.  The reference builds a TensorFlow graph and lets autodiff
+and cuDNN do the rest; here the forward and backward passes are written out explicitly over
+pre-allocated HBM buffers so that one training step is a fixed sequence of HIP launches
+(capturable in a hipGraph), with the parameters, their gradients and the Adam moments living
+in flat fp32 arenas (one fused optimiser launch, one contiguous all-reduce payload).
+
+PyTorch supplies device memory, streams, the plain library GEMMs / convolutions
+(hipBLASLt / MIOpen through ``torch.mm`` / ``aten.convolution``) and ``torch.distributed``;
+the recurrence, CTC, softmax, activations epilogues, decoding and the optimiser are the HIP
+kernels behind ``include/ctcasr.h``.
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from ctc_asr_amd import hip, metrics
+from ctc_asr_amd.labels import num_classes
+
+CONV_KERNEL_SIZES = ((11, 41), (11, 21), (11, 21))   # (time, freq), asr/util/tf_contrib.py:66
+CONV_STRIDES = ((2, 2), (1, 2), (1, 2))              # asr/util/tf_contrib.py:67
+GATES = {'lstm': 4, 'gru': 3, 'rnn_relu': 1, 'rnn_tanh': 1}
+
+
+class InfeasibleAlignmentError(ValueError):
+    """Raised where ``tf.nn.ctc_loss`` raises InvalidArgumentError ("Not enough time for target
+    transition sequence"), ``ignore_longer_outputs_than_inputs=False`` (``asr/model.py:259``)."""
+
+
+class ModelConfig:
+    """Network layout; field names are the reference's flag names (``asr/params.py``)."""
+
+    def __init__(self, used_model='ds2', conv_filters=(32, 32, 96), num_units_dense=2048,
+                 num_layers_rnn=4, num_units_rnn=2048, rnn_cell='rnn_relu', cudnn=True,
+                 relu_cutoff=20.0, conv_dropout_rate=0.0, rnn_dropout_rate=0.0,
+                 dense_dropout_rate=0.1, num_classes_=None, num_features=80, beam_width=1024):
+        if used_model not in ('ds1', 'ds2'):
+            raise ValueError('Unsupported model "{}" in flags.'.format(used_model))
+        if rnn_cell not in GATES:
+            raise ValueError('Unsupported rnn_cell "{}".'.format(rnn_cell))
+        conv_filters = tuple(int(f) for f in conv_filters)
+        if used_model == 'ds2' and not 1 <= len(conv_filters) <= len(CONV_STRIDES):
+            raise ValueError('conv_layers(): Arguments filters, kernel_size, and strides must '
+                             'contain the same number of elements.')
+        self.used_model = used_model
+        self.conv_filters = conv_filters
+        self.num_units_dense = int(num_units_dense)
+        self.num_layers_rnn = int(num_layers_rnn)
+        self.num_units_rnn = int(num_units_rnn)
+        self.rnn_cell = rnn_cell
+        self.cudnn = bool(cudnn)
+        self.relu_cutoff = float(relu_cutoff)
+        self.conv_dropout_rate = float(conv_dropout_rate)
+        self.rnn_dropout_rate = float(rnn_dropout_rate)
+        self.dense_dropout_rate = float(dense_dropout_rate)
+        self.num_classes = int(num_classes_ or num_classes())
+        self.num_features = int(num_features)
+        self.beam_width = int(beam_width)
+
+    @classmethod
+    def from_flags(cls, flags):
+        return cls(used_model=flags.used_model, conv_filters=flags.conv_filters,
+                   num_units_dense=flags.num_units_dense, num_layers_rnn=flags.num_layers_rnn,
+                   num_units_rnn=flags.num_units_rnn, rnn_cell=flags.rnn_cell, cudnn=flags.cudnn,
+                   relu_cutoff=flags.relu_cutoff, conv_dropout_rate=flags.conv_dropout_rate,
+                   rnn_dropout_rate=flags.rnn_dropout_rate,
+                   dense_dropout_rate=flags.dense_dropout_rate, num_classes_=flags.num_classes,
+                   beam_width=flags.beam_width)
+
+    @property
+    def cell(self):
+        """The cell that actually runs: ``cudnn=False`` ignores ``rnn_cell`` and uses the tanh
+        BasicRNNCell (``asr/params.py:47-50`` TODO, ``asr/util/tf_contrib.py:185``)."""
+        return self.rnn_cell if self.cudnn else 'rnn_tanh'
+
+    def conv_output_freq(self):
+        freq = self.num_features
+        for _ in self.conv_filters:
+            freq = -(-freq // 2)
+        return freq
+
+    def rnn_input_size(self):
+        if self.used_model == 'ds2':
+            return self.conv_output_freq() * self.conv_filters[-1]
+        return self.num_units_dense
+
+    def output_time(self, num_frames):
+        return -(-num_frames // 2) if self.used_model == 'ds2' else num_frames
+
+
+def same_padding(size, kernel, stride):
+    """TensorFlow SAME padding: (out, pad_before, pad_after); the odd element goes to the end."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + kernel - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def param_spec(cfg):
+    """Ordered (name, shape) list in the *shared layout* (see ``oracle/nn.py``): conv kernels
+    TensorFlow HWIO ``[kt, kf, Cin, Cout]``, dense kernels ``[in, out]``, RNN ``[2, G*H, I]``."""
+    spec = []
+    if cfg.used_model == 'ds2':
+        c_in = 1
+        for i, filt in enumerate(cfg.conv_filters):
+            k_t, k_f = CONV_KERNEL_SIZES[i]
+            spec.append(('conv{}/kernel'.format(i), (k_t, k_f, c_in, filt)))
+            spec.append(('conv{}/bias'.format(i), (filt,)))
+            c_in = filt
+    else:
+        d_in = cfg.num_features
+        for i in range(3):
+            spec.append(('dense{}/kernel'.format(i), (d_in, cfg.num_units_dense)))
+            spec.append(('dense{}/bias'.format(i), (cfg.num_units_dense,)))
+            d_in = cfg.num_units_dense
+    gates, hidden = GATES[cfg.cell], cfg.num_units_rnn
+    in_size = cfg.rnn_input_size()
+    for i in range(cfg.num_layers_rnn):
+        spec.append(('rnn{}/w_ih'.format(i), (2, gates * hidden, in_size)))
+        spec.append(('rnn{}/w_hh'.format(i), (2, gates * hidden, hidden)))
+        spec.append(('rnn{}/b_ih'.format(i), (2, gates * hidden)))
+        spec.append(('rnn{}/b_hh'.format(i), (2, gates * hidden)))
+        in_size = 2 * hidden
+    spec.append(('dense4/kernel', (2 * hidden, cfg.num_units_dense)))
+    spec.append(('dense4/bias', (cfg.num_units_dense,)))
+    spec.append(('logits/kernel', (cfg.num_units_dense, cfg.num_classes)))
+    spec.append(('logits/bias', (cfg.num_classes,)))
+    return spec
+
+
+def _truncated_normal(rng, shape, stddev):
+    out = rng.normal(size=shape) * stddev
+    bad = np.abs(out) > 2 * stddev
+    while bad.any():
+        out[bad] = rng.normal(size=int(bad.sum())) * stddev
+        bad = np.abs(out) > 2 * stddev
+    return out.astype(np.float32)
+
+
+def init_params(cfg, seed=0):
+    """Random initial parameters following the reference's initialisers: dense kernels
+    truncated-normal(0.046875) (``asr/model.py:146``), conv kernels glorot-normal
+    (``asr/util/tf_contrib.py:68``), cuDNN weights glorot-uniform per gate matrix and zero
+    biases (``asr/model.py:208-211``).  (TensorFlow's RNG stream itself cannot be reproduced.)"""
+    rng = np.random.default_rng(seed)
+    params = {}
+    gates, hidden = GATES[cfg.cell], cfg.num_units_rnn
+    for name, shape in param_spec(cfg):
+        if name.endswith('bias') or name.endswith('b_ih') or name.endswith('b_hh'):
+            params[name] = np.zeros(shape, dtype=np.float32)
+        elif name.startswith('conv'):
+            k_t, k_f, c_in, c_out = shape
+            std = math.sqrt(2.0 / (k_t * k_f * c_in + k_t * k_f * c_out))
+            params[name] = _truncated_normal(rng, shape, std)
+        elif name.startswith('rnn'):
+            fan_in = shape[2]
+            if cfg.cudnn:
+                limit = math.sqrt(6.0 / (fan_in + hidden))
+            else:   # one [I+H, H] BasicRNNCell kernel
+                layer = int(name[3:name.index('/')])
+                in_size = cfg.rnn_input_size() if layer == 0 else 2 * hidden
+                limit = math.sqrt(6.0 / (in_size + hidden + hidden))
+            params[name] = rng.uniform(-limit, limit, size=shape).astype(np.float32)
+        else:
+            params[name] = _truncated_normal(rng, shape, 0.046875)
+    del gates
+    return params
+
+
+def to_oracle_layout(flat_params, cfg):
+    """name->array dict  ->  the nested dict ``oracle/nn.py`` / ``oracle/torch_ref.py`` take."""
+    out = {}
+    if cfg.used_model == 'ds2':
+        out['conv'] = [(flat_params['conv{}/kernel'.format(i)], flat_params['conv{}/bias'.format(i)])
+                       for i in range(len(cfg.conv_filters))]
+    else:
+        out['dense'] = [(flat_params['dense{}/kernel'.format(i)],
+                         flat_params['dense{}/bias'.format(i)]) for i in range(3)]
+    out['rnn'] = [{k: flat_params['rnn{}/{}'.format(i, k)] for k in ('w_ih', 'w_hh', 'b_ih', 'b_hh')}
+                  for i in range(cfg.num_layers_rnn)]
+    out['dense4'] = (flat_params['dense4/kernel'], flat_params['dense4/bias'])
+    out['logits'] = (flat_params['logits/kernel'], flat_params['logits/bias'])
+    return out
+
+
+class ParamArena:
+    """Flat fp32 arenas in HBM for parameters, gradients and the two Adam moments.
+
+    Compute layout differs from the shared layout only for conv kernels, which are stored
+    ``[Cout, Cin, kt, kf]`` (what the convolution consumes); ``load`` / ``export`` convert.
+    Every tensor starts on a 16-byte boundary.  Layers appear in forward order, so a layer's
+    gradients are one contiguous slice (``layer_slices``) — the unit of the bucketed all-reduce.
+    """
+
+    def __init__(self, cfg, device):
+        self.cfg, self.device = cfg, device
+        self.offsets, self.shapes = {}, {}
+        self.layer_slices = []          # [(layer_name, start, stop)] in forward order
+        cursor, layer, layer_start = 0, None, 0
+        for name, shape in param_spec(cfg):
+            this_layer = name.split('/')[0]
+            if this_layer != layer:
+                if layer is not None:
+                    self.layer_slices.append((layer, layer_start, cursor))
+                layer, layer_start = this_layer, cursor
+            if name.startswith('conv') and name.endswith('kernel'):
+                shape = (shape[3], shape[2], shape[0], shape[1])
+            self.offsets[name], self.shapes[name] = cursor, tuple(shape)
+            cursor += (int(np.prod(shape)) + 3) // 4 * 4
+        self.layer_slices.append((layer, layer_start, cursor))
+        self.size = cursor
+        self.param = torch.zeros(cursor, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(cursor, dtype=torch.float32, device=device)
+        self.m = torch.zeros(cursor, dtype=torch.float32, device=device)
+        self.v = torch.zeros(cursor, dtype=torch.float32, device=device)
+        self.p = {n: self._view(self.param, n) for n in self.offsets}
+        self.g = {n: self._view(self.grad, n) for n in self.offsets}
+
+    def _view(self, arena, name):
+        shape = self.shapes[name]
+        start = self.offsets[name]
+        return arena[start:start + int(np.prod(shape))].view(shape)
+
+    def num_parameters(self):
+        return sum(int(np.prod(s)) for s in self.shapes.values())
+
+    def load(self, flat_params):
+        """Copy a name->array dict in the shared layout into the parameter arena."""
+        for name in self.offsets:
+            value = torch.as_tensor(np.asarray(flat_params[name]), dtype=torch.float32)
+            if name.startswith('conv') and name.endswith('kernel'):
+                value = value.permute(3, 2, 0, 1)
+            self.p[name].copy_(value.contiguous().to(self.device))
+
+    def export(self, which='param'):
+        """name->numpy dict in the shared layout (``which``: 'param' or 'grad')."""
+        views = self.p if which == 'param' else self.g
+        out = {}
+        for name, view in views.items():
+            value = view.detach().cpu()
+            if name.startswith('conv') and name.endswith('kernel'):
+                value = value.permute(2, 3, 1, 0)
+            out[name] = value.contiguous().numpy().copy()
+        return out
+
+
+class CTCModel:
+    """DS1 / DS2 acoustic model on one MI355X.  Mirrors the method surface of the reference's
+    ``CTCModel`` with torch tensors in place of TensorFlow tensors; ``forward_backward`` /
+    ``apply_gradients`` are the explicit counterparts of ``optimizer.minimize``."""
+
+    def __init__(self, cfg, device='cuda', seed=0, params=None):
+        hip.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise hip.CtcAsrError('CTCModel runs on the MI355X only; there is no CPU path.')
+        self.arena = ParamArena(cfg, self.device)
+        self.arena.load(params if params is not None else init_params(cfg, seed))
+        self.step_count = 0
+        self.dropout_seed = int(seed) * 0x9E3779B1 + 1
+        self._acts = None
+        self._w_hh_t = [torch.empty((2, cfg.num_units_rnn, GATES[cfg.cell] * cfg.num_units_rnn),
+                                    dtype=torch.float32, device=self.device)
+                        for _ in range(cfg.num_layers_rnn)]
+
+    # ------------------------------------------------------------------ forward
+    def _next_seed(self):
+        self.dropout_seed = (self.dropout_seed * 6364136223846793005 + 1442695040888963407) \
+            & 0xFFFFFFFFFFFFFFFF
+        return self.dropout_seed
+
+    def _dense_act(self, x2d, name, rate, training):
+        """x2d [rows, in] -> dropout(min(relu(x K + b), cutoff)); returns the activation."""
+        p = self.arena.p
+        out = torch.mm(x2d, p[name + '/kernel'])
+        hip.bias_act_fwd(out, p[name + '/bias'], self.cfg.relu_cutoff,
+                         rate if training else 0.0, self._next_seed())
+        return out
+
+    def inference_fn(self, sequences, seq_length, training=True):
+        """``sequences`` f32[B, T, 80], ``seq_length`` i32[B] -> (logits f32[T', B, C] time-major,
+        seq_length i32[B]); keeps the activations for a following backward pass
+        (``asr/model.py:123-236``)."""
+        cfg, p = self.cfg, self.arena.p
+        sequences = sequences.to(self.device, torch.float32).contiguous()
+        batch, frames, _ = sequences.shape
+        acts = {'training': training, 'batch': batch}
+        if cfg.used_model == 'ds2':
+            # conv dropout: the reference never forwards `training` to conv_layers, so a
+            # non-zero conv_dropout_rate fires in evaluation too (asr/model.py:161).
+            x = sequences.unsqueeze(1)                       # NCHW [B, 1, T, F]
+            conv_in, conv_out, pads = [], [], []
+            for i in range(len(cfg.conv_filters)):
+                k_t, k_f = CONV_KERNEL_SIZES[i]
+                s_t, s_f = CONV_STRIDES[i]
+                _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
+                _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
+                xp = torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1))
+                y = torch.ops.aten.convolution(xp, p['conv{}/kernel'.format(i)],
+                                               p['conv{}/bias'.format(i)], [s_t, s_f], [0, 0],
+                                               [1, 1], False, [0, 0], 1)
+                hip.bias_act_fwd(y, None, cfg.relu_cutoff, cfg.conv_dropout_rate,
+                                 self._next_seed())
+                conv_in.append(xp)
+                conv_out.append(y)
+                pads.append((pt0, pt1, pf0, pf1))
+                x = y
+            t_out = x.shape[2]
+            # [B, C, T', F'] -> time-major [T', B, F'*C] (freq-major, channel-minor like NHWC)
+            rnn_in = x.permute(2, 0, 3, 1).reshape(t_out, batch, -1)
+            acts.update(conv_in=conv_in, conv_out=conv_out, pads=pads)
+            seq_length = torch.full((batch,), t_out, dtype=torch.int32, device=self.device)
+        else:
+            t_out = frames
+            x2d = sequences.transpose(0, 1).reshape(t_out * batch, -1)
+            dense_in, dense_out = [], []
+            for i in range(3):
+                dense_in.append(x2d)
+                x2d = self._dense_act(x2d, 'dense{}'.format(i), cfg.dense_dropout_rate, training)
+                dense_out.append(x2d)
+            rnn_in = x2d.view(t_out, batch, -1)
+            acts.update(dense_in=dense_in, dense_out=dense_out)
+            seq_length = torch.as_tensor(seq_length).to(self.device, torch.int32).contiguous()
+
+        cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
+        rnn_len = None if cfg.cudnn else seq_length
+        layer_in, layer_out, reserves = [], [], []
+        x = rnn_in.contiguous()
+        workspace = None
+        for i in range(cfg.num_layers_rnn):
+            w_ih = p['rnn{}/w_ih'.format(i)].view(2 * gates * hidden, -1)
+            xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
+            # both biases are plain additive terms for LSTM / RNN cells: fold them into xw
+            hip.bias_act_fwd(xw, self._rnn_bias(i), 0.0)
+            y, reserve, workspace = hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gates * hidden),
+                                                p['rnn{}/w_hh'.format(i)], rnn_len,
+                                                workspace=workspace)
+            layer_in.append(x)
+            layer_out.append(y)
+            reserves.append(reserve)
+            x = y
+            if training and cfg.rnn_dropout_rate > 0.0 and i + 1 < cfg.num_layers_rnn:
+                raise hip.CtcAsrError('rnn_dropout_rate > 0 is not implemented yet.')
+        acts.update(layer_in=layer_in, layer_out=layer_out, reserves=reserves, rnn_ws=workspace,
+                    rnn_len=rnn_len, t_out=t_out)
+
+        rnn_flat = x.view(t_out * batch, 2 * hidden)
+        dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training)
+        logits = torch.mm(dense4, p['logits/kernel'])
+        hip.bias_act_fwd(logits, p['logits/bias'], 0.0)
+        acts.update(rnn_flat=rnn_flat, dense4=dense4)
+        self._acts = acts
+        return logits.view(t_out, batch, cfg.num_classes), seq_length
+
+    def _rnn_bias(self, layer):
+        """b_ih + b_hh as one [2*G*H] vector (scratch, recomputed per call)."""
+        p = self.arena.p
+        return (p['rnn{}/b_ih'.format(layer)] + p['rnn{}/b_hh'.format(layer)]).reshape(-1)
+
+    # ------------------------------------------------------------------ loss
+    @staticmethod
+    def pack_labels(labels, device):
+        """Dense zero-padded ``[B, L]`` int labels (or a list of lists) -> concatenated ids,
+        offsets, max length: the ``dense_to_sparse`` of ``asr/model.py:71`` (0 = pad/eos)."""
+        if isinstance(labels, torch.Tensor):
+            labels = labels.cpu().numpy()
+        rows = [[int(v) for v in row if int(v) != 0] for row in labels]
+        offsets = np.zeros(len(rows) + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum([len(r) for r in rows])
+        flat = np.array([v for r in rows for v in r] or [0], dtype=np.int32)
+        max_len = max([len(r) for r in rows] + [1])
+        return (torch.as_tensor(flat).to(device), torch.as_tensor(offsets).to(device), max_len,
+                rows)
+
+    def loss_fn(self, logits, seq_length, labels, check=True):
+        """Mean over the batch of the CTC loss (``asr/model.py:238-269``).  Also leaves
+        d(mean loss)/d(logits) in ``self._acts['dlogits']`` for ``backward``.  Raises
+        `InfeasibleAlignmentError` where TensorFlow raises (``check=False`` defers the
+        device->host status read to the caller)."""
+        flat, offsets, max_len, _ = self.pack_labels(labels, self.device)
+        batch = logits.shape[1]
+        per_utt, grad, status = hip.ctc_loss_fwd_bwd(logits, flat, offsets, seq_length, max_len,
+                                                     grad_scale=1.0 / batch)
+        if self._acts is not None:
+            self._acts['dlogits'] = grad
+        self.last_status, self.last_per_utterance_loss = status, per_utt
+        if check:
+            self.check_status(status)
+        return per_utt.mean()
+
+    @staticmethod
+    def check_status(status):
+        bad = status.cpu().numpy()
+        if (bad == 1).any():
+            raise InfeasibleAlignmentError(
+                'Not enough time for target transition sequence (batch rows {})'
+                .format(np.nonzero(bad == 1)[0].tolist()))
+        if (bad == 2).any():
+            raise ValueError('CTC labels out of range or sequence_length > max_time (rows {})'
+                             .format(np.nonzero(bad == 2)[0].tolist()))
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, reduce_hook=None):
+        """Back-propagate ``dlogits`` (set by `loss_fn`) through the stack; fills the gradient
+        arena.  ``reduce_hook(layer_name, start, stop)`` is called as soon as a layer's slice of
+        the arena is final (logits first, front-end last) — the bucketed all-reduce hook."""
+        cfg, p, g, acts = self.cfg, self.arena.p, self.arena.g, self._acts
+        if acts is None or 'dlogits' not in acts:
+            raise RuntimeError('backward() needs inference_fn() and loss_fn() first.')
+        slices = {name: (start, stop) for name, start, stop in self.arena.layer_slices}
+
+        def done(layer):
+            if reduce_hook is not None:
+                reduce_hook(layer, *slices[layer])
+
+        self.arena.grad.zero_()
+        training = acts['training']
+        t_out, batch = acts['t_out'], acts['batch']
+        hidden, gates, cell = cfg.num_units_rnn, GATES[cfg.cell], cfg.cell
+        rows = t_out * batch
+        dlogits = acts['dlogits'].view(rows, cfg.num_classes)
+
+        # logits layer
+        torch.mm(acts['dense4'].t(), dlogits, out=g['logits/kernel'])
+        hip.colsum_accumulate(dlogits, g['logits/bias'])
+        d_dense4 = torch.mm(dlogits, p['logits/kernel'].t())
+        done('logits')
+        # dense4
+        dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
+                              cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
+        torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel'])
+        dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
+        done('dense4')
+
+        # recurrent stack, top layer first
+        need_dx_first = True
+        for i in range(cfg.num_layers_rnn - 1, -1, -1):
+            name = 'rnn{}'.format(i)
+            x, y = acts['layer_in'][i], acts['layer_out'][i]
+            hip.transpose_batched(p[name + '/w_hh'], out=self._w_hh_t[i])
+            dxw = hip.rnn_bwd(cell, dy.contiguous(), y, self._w_hh_t[i], acts['reserves'][i],
+                              acts['rnn_len'], workspace=acts['rnn_ws'])
+            dxw2d = dxw.view(rows, 2 * gates * hidden)
+            torch.mm(dxw2d.t(), x.view(rows, -1), out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
+            hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
+            g[name + '/b_hh'].copy_(g[name + '/b_ih'])
+            # dW_hh[d] = sum_t dgates_t^T h_{t-1}: one GEMM per direction over shifted views
+            if t_out > 1:
+                gh = gates * hidden
+                torch.mm(dxw[1:, :, 0, :].reshape((t_out - 1) * batch, gh).t(),
+                         y[:-1, :, :hidden].reshape((t_out - 1) * batch, hidden),
+                         out=g[name + '/w_hh'][0])
+                torch.mm(dxw[:-1, :, 1, :].reshape((t_out - 1) * batch, gh).t(),
+                         y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
+                         out=g[name + '/w_hh'][1])
+            if i > 0 or need_dx_first:
+                w_ih = p[name + '/w_ih'].view(2 * gates * hidden, -1)
+                dy = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
+            done(name)
+
+        # front-end
+        if cfg.used_model == 'ds2':
+            conv_out = acts['conv_out']
+            last = conv_out[-1]
+            b_, c_, tt, ff = last.shape
+            # [T', B, F'*C] -> NCHW [B, C, T', F']
+            dact = dy.view(tt, b_, ff, c_).permute(1, 3, 0, 2).contiguous()
+            for i in range(len(cfg.conv_filters) - 1, -1, -1):
+                name = 'conv{}'.format(i)
+                dz = hip.bias_act_bwd(conv_out[i], dact, cfg.relu_cutoff, cfg.conv_dropout_rate)
+                xp = acts['conv_in'][i]
+                pt0, pt1, pf0, pf1 = acts['pads'][i]
+                dxp, dw, db = torch.ops.aten.convolution_backward(
+                    dz, xp, p[name + '/kernel'], [p[name + '/bias'].shape[0]],
+                    list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
+                    [i > 0, True, True])
+                g[name + '/kernel'].copy_(dw)
+                g[name + '/bias'].copy_(db)
+                if i > 0:
+                    dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1].contiguous()
+                done(name)
+        else:
+            dact = dy.reshape(rows, -1)
+            for i in range(2, -1, -1):
+                name = 'dense{}'.format(i)
+                dz = hip.bias_act_bwd(acts['dense_out'][i], dact.contiguous(), cfg.relu_cutoff,
+                                      cfg.dense_dropout_rate if training else 0.0,
+                                      g[name + '/bias'])
+                torch.mm(acts['dense_in'][i].t(), dz, out=g[name + '/kernel'])
+                if i > 0:
+                    dact = torch.mm(dz, p[name + '/kernel'].t())
+                done(name)
+
+    def forward_backward(self, features, feature_len, labels, reduce_hook=None, check=True):
+        """One training forward + backward; returns the mean CTC loss (device scalar)."""
+        logits, seq_length = self.inference_fn(features, feature_len, training=True)
+        loss = self.loss_fn(logits, seq_length, labels, check=check)
+        self.backward(reduce_hook)
+        return loss
+
+    def apply_gradients(self, learning_rate=1e-5, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                        grad_scale=1.0):
+        """TensorFlow-form Adam over the whole arena in one launch (``asr/model.py:80-83``)."""
+        self.step_count += 1
+        a = self.arena
+        hip.adam_step(a.param, a.grad, a.m, a.v, self.step_count, learning_rate, beta1, beta2,
+                      epsilon, grad_scale)
+
+    # ------------------------------------------------------------------ decode / score
+    def decode_fn(self, logits, seq_len, originals=None, beam_width=None, greedy=False):
+        """CTC decode + plaintext (``asr/model.py:271-309``).  Returns (decoded: list of B int
+        lists — the values of the reference's SparseTensor —, plaintext object[B], summary
+        object[2, B]).  ``greedy=True`` selects the greedy decoder instead of the beam search."""
+        beam_width = self.cfg.beam_width if beam_width is None else beam_width
+        if greedy:
+            out, out_len = hip.ctc_greedy_decode(logits, seq_len)
+        else:
+            out, out_len, _ = hip.ctc_beam_decode(logits, seq_len, beam_width)
+        out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+        decoded = [out[b, :out_len[b]].tolist() for b in range(out.shape[0])]
+        width = max([len(d) for d in decoded] + [0])
+        dense = np.zeros((len(decoded), width), dtype=np.int32)
+        for b, row in enumerate(decoded):
+            dense[b, :len(row)] = row
+        plaintext, summary = metrics.dense_to_text(dense, originals if originals is not None
+                                                   else np.array([], dtype=np.int32))
+        return decoded, plaintext, summary
+
+    @staticmethod
+    def error_rates_fn(labels, originals, decoded, decoded_texts):
+        """(edit distances f32[B], mean edit distance, WERs f32[B], mean WER)
+        (``asr/model.py:311-345``).  ``labels`` dense zero-padded ints or list of lists."""
+        if isinstance(labels, torch.Tensor):
+            labels = labels.cpu().numpy()
+        truths = [[int(v) for v in row if int(v) != 0] for row in labels]
+        edit_distances, mean_ed = metrics.edit_distance_batch(decoded, truths)
+        wers, wer = metrics.wer_batch(list(originals), list(decoded_texts))
+        return edit_distances, mean_ed, wers, wer

@@ -1,0 +1,159 @@
+/* ctcasr.h — C ABI of the MI355X-native CTC acoustic-model hot path (libctcasr.so).
+ *
+ * The reference (mdangschat/ctc-asr) has no FFI of its own: its hot path is a chain of
+ * TensorFlow / cuDNN / python_speech_features calls made from Python.  Each entry point below
+ * replaces one of those call sites (cited per function; paths relative to the reference root)
+ * and is what a binding for that call site would bind.  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions (all functions):
+ *   - plain C types only; every pointer is a DEVICE pointer (HBM) owned by the caller unless the
+ *     parameter name ends in `_host`; tensors are contiguous, row-major, float32 unless noted;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it and the
+ *     function returns without synchronising; nothing is allocated behind the caller's back —
+ *     scratch memory is sized by the matching *_workspace_bytes() query and passed in;
+ *   - return value: CTCASR_OK (0) or a negative CTCASR_ERR_* code for an argument / launch
+ *     error; functions never throw and never abort.  Per-utterance data errors (an infeasible
+ *     CTC alignment) are reported through a device-side `status` array, mirroring the point at
+ *     which TensorFlow raises InvalidArgumentError.
+ *   - time-major activations: [T, B, *]; direction index 0 = forward, 1 = backward.
+ */
+#ifndef CTCASR_H_
+#define CTCASR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTCASR_ABI_VERSION 1
+
+enum {
+    CTCASR_OK = 0,
+    CTCASR_ERR_BAD_ARGUMENT = -1,   /* null pointer, non-positive size, unknown enum           */
+    CTCASR_ERR_UNSUPPORTED = -2,    /* valid request outside what the kernels cover            */
+    CTCASR_ERR_WORKSPACE = -3,      /* workspace pointer null or too small                     */
+    CTCASR_ERR_LAUNCH = -4          /* hipGetLastError() reported a launch failure             */
+};
+
+/* RNN cell types; names follow FLAGS.rnn_cell (asr/params.py:47-50, asr/model.py:194-199). */
+enum {
+    CTCASR_CELL_RNN_RELU = 0,
+    CTCASR_CELL_RNN_TANH = 1,
+    CTCASR_CELL_LSTM = 2,
+    CTCASR_CELL_GRU = 3
+};
+
+typedef void *ctcasr_stream_t;
+
+int ctcasr_abi_version(void);
+const char *ctcasr_error_string(int code);
+
+/* ---- K8: (log-)softmax over the class axis ------------------------------------------------
+ * Replaces the softmax inside tf.nn.ctc_loss / ctc_beam_search_decoder (asr/model.py:259,292).
+ * x, y: [rows, C] with C <= 64.  bwd: dx = dy - exp(y) * sum_c(dy). */
+int ctcasr_log_softmax_fwd(const float *x, float *y, int rows, int C, ctcasr_stream_t stream);
+int ctcasr_log_softmax_bwd(const float *y, const float *dy, float *dx, int rows, int C,
+                           ctcasr_stream_t stream);
+
+/* ---- K9: CTC loss + gradient, log-softmax fused ---------------------------------------------
+ * Replaces tf.nn.ctc_loss(labels, inputs=logits, sequence_length, time_major=True,
+ * ctc_merge_repeated=True, preprocess_collapse_repeated=False) and its gradient
+ * (asr/model.py:259-264; the reduce_mean of :267 is applied through `grad_scale` = 1/B).
+ *   logits        [T, B, C] raw activations; blank = C - 1 for the reference (pass it anyway)
+ *   labels        int32, concatenated label ids of all B utterances (ids in [0, C) \ {blank})
+ *   label_offsets int32 [B + 1], labels of utterance b are labels[label_offsets[b] .. [b+1])
+ *   seq_len       int32 [B], frames of utterance b that count (<= T)
+ *   loss          [B]   -ln p(label_b | x_b); +inf when status[b] != 0
+ *   grad_logits   [T, B, C] d(sum_b grad_scale * loss_b) / d logits; rows t >= seq_len[b] are 0
+ *   status        int32 [B]: 0 ok; 1 "not enough time for target transition sequence"
+ *                 (TensorFlow raises here); 2 label id out of range / seq_len > T
+ * Workspace: ctcasr_ctc_loss_workspace_bytes(T, B, C, max_label_len). */
+size_t ctcasr_ctc_loss_workspace_bytes(int T, int B, int C, int max_label_len);
+int ctcasr_ctc_loss_fwd_bwd(const float *logits, const int32_t *labels,
+                            const int32_t *label_offsets, const int32_t *seq_len, int T, int B,
+                            int C, int blank, int max_label_len, float grad_scale, float *loss,
+                            float *grad_logits, int32_t *status, void *workspace,
+                            size_t workspace_bytes, ctcasr_stream_t stream);
+
+/* ---- K10: decoding --------------------------------------------------------------------------
+ * Greedy: argmax per frame (first maximum), merge repeats, drop blank — ctc_greedy_decoder
+ * semantics (named in asr/model.py:290,298 and required by BASELINE.json).
+ *   out [B, T] int32 (row padded with 0), out_len [B]. */
+int ctcasr_ctc_greedy_decode(const float *logits, const int32_t *seq_len, int T, int B, int C,
+                             int blank, int32_t *out, int32_t *out_len, ctcasr_stream_t stream);
+
+/* Beam search: tf.nn.ctc_beam_search_decoder(inputs=logits, sequence_length,
+ * beam_width, top_paths=1, merge_repeated=False) (asr/model.py:292-296).
+ *   norm_mode 0: per-frame max subtraction (TensorFlow 1.12); 1: full log-softmax (TF >= 1.14)
+ *   out [B, T] int32, out_len [B], logp [B] (log-probability of the top path; may be NULL)
+ * Workspace: ctcasr_ctc_beam_workspace_bytes(T, B, C, beam_width). */
+size_t ctcasr_ctc_beam_workspace_bytes(int T, int B, int C, int beam_width);
+int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, int B, int C,
+                           int blank, int beam_width, int norm_mode, int32_t *out,
+                           int32_t *out_len, float *logp, void *workspace,
+                           size_t workspace_bytes, ctcasr_stream_t stream);
+
+/* ---- K4/K5: recurrence of one bidirectional RNN layer ----------------------------------------
+ * Replaces the time loop of tfc.cudnn_rnn.Cudnn{LSTM,GRU,RNNRelu,RNNTanh}(direction=
+ * 'bidirectional') (asr/model.py:194-215) and of stack_bidirectional_dynamic_rnn over
+ * BasicRNNCell (asr/model.py:171-183).  The input projection W x + b_W (+ b_R where it commutes)
+ * is a plain GEMM done by the caller; this entry point runs h_t = cell(xw_t, h_{t-1}).
+ *   cell     CTCASR_CELL_*; G = gates per unit (LSTM 4: i,f,g,o; GRU 3: r,z,n; RNN 1)
+ *   xw       [T, B, 2, G*H] pre-computed input projections incl. bias, both directions
+ *   w_hh     [2, G*H, H] recurrent weights (cuDNN / torch layout, gate-major rows)
+ *   b_hh_n   [2, H] recurrent bias of the GRU candidate gate (NULL for the other cells)
+ *   seq_len  int32 [B] or NULL.  NULL = cuDNN semantics (all T steps for every row; the backward
+ *            direction starts at t = T-1).  Non-NULL = dynamic_rnn semantics (steps
+ *            t >= seq_len[b] emit zeros and keep the state; backward direction reversed per row).
+ *   y        [T, B, 2H]  = [h_fw || h_bw]
+ *   reserve  activations kept for the backward pass, ctcasr_rnn_reserve_bytes()
+ *   workspace ctcasr_rnn_workspace_bytes() (state ping-pong, grid-barrier words)
+ * bwd: dy [T,B,2H] -> dxw [T,B,2,G*H] (gradient w.r.t. xw, which is also what the weight
+ * gradients are GEMMs of), w_hh_t = w_hh transposed to [2, H, G*H] (caller keeps it current;
+ * ctcasr_transpose_batched does it), db_hh_n [2, H] (GRU only, accumulated +=). */
+size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H);
+size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H);
+int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
+                   const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
+                   void *workspace, size_t workspace_bytes, ctcasr_stream_t stream);
+int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
+                   const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
+                   const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                   size_t workspace_bytes, ctcasr_stream_t stream);
+
+/* ---- fused dense / conv epilogues (tf.layers.dense + ReLU + tf.minimum(., relu_cutoff) +
+ * tf.layers.dropout: asr/util/tf_contrib.py:50-61,122-135, asr/model.py:219-225) --------------
+ * fwd (in place): y[r, c] = dropout(min(max(y[r, c] + bias[c], 0), cutoff)); inverted dropout
+ *   with keep = 1 - rate, counter-based RNG keyed by (seed, element index); rate 0 = no dropout.
+ *   `cutoff` <= 0 disables the activation entirely (plain bias add: the logits layer).
+ * bwd: dz = dy * [0 < y < cutoff/keep] / keep * [y != 0] from the stored *output* y (no mask
+ *   tensor is kept); dbias[c] += sum_r dz[r, c] when dbias != NULL (caller zeroes it).
+ *   `cols` is the fastest dimension; for conv activations in NHWC pass rows = B*T*F, cols = C. */
+int ctcasr_bias_act_fwd(float *y, const float *bias, int64_t rows, int cols, float cutoff,
+                        float dropout_rate, uint64_t seed, ctcasr_stream_t stream);
+int ctcasr_bias_act_bwd(const float *y, const float *dy, float *dz, float *dbias, int64_t rows,
+                        int cols, float cutoff, float dropout_rate, ctcasr_stream_t stream);
+/* dbias[c] += sum_r dz[r, c] on its own (layers without activation). */
+int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t rows, int cols,
+                             ctcasr_stream_t stream);
+
+/* out[n][c][r] = in[n][r][c] for n < batch (weight re-layouts, e.g. w_hh -> w_hh_t). */
+int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,
+                             ctcasr_stream_t stream);
+
+/* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
+ * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):
+ *   lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step);  m, v updated in place;
+ *   param -= lr_t * m / (sqrt(v) + epsilon)     (epsilon OUTSIDE the bias correction).
+ * `step` counts from 1.  grad is scaled by grad_scale first (1/world_size after a summed
+ * all-reduce). */
+int ctcasr_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr,
+                     float beta1, float beta2, float epsilon, int64_t step, float grad_scale,
+                     ctcasr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTCASR_H_ */

@@ -1,0 +1,207 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc as octc
+from oracle import cref
+from oracle import nn as onn
+from tests.helpers import pack_labels
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _t(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV)
+
+
+def test_log_softmax_fwd_bwd(hip):
+    rng = np.random.default_rng(0)
+    x = (rng.normal(size=(37, 5, 29)) * 3).astype(np.float32)
+    y = hip.log_softmax_fwd(_t(x)).cpu().numpy()
+    ref = octc.log_softmax(x)
+    assert np.abs(y - ref).max() < 1e-5
+    dy = rng.normal(size=x.shape).astype(np.float32)
+    dx = hip.log_softmax_bwd(_t(ref), _t(dy)).cpu().numpy()
+    ref_dx = dy - np.exp(ref) * dy.sum(-1, keepdims=True)
+    assert np.abs(dx - ref_dx).max() < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(5, 2, 6), (50, 4, 29), (500, 16, 29), (850, 3, 29),
+                                   (1699, 2, 29)])
+def test_ctc_loss_matches_oracle(hip, shape):
+    num_steps, batch, classes = shape
+    rng = np.random.default_rng(num_steps)
+    logits = (rng.normal(size=shape) * 2).astype(np.float32)
+    max_len = max(1, min(num_steps // 3, 422))
+    labels = [list(rng.integers(0, classes - 1, size=rng.integers(0, max_len + 1)))
+              for _ in range(batch)]
+    labels[0] = list(rng.integers(0, classes - 1, size=max_len))
+    if batch > 1:
+        labels[1] = []          # empty label row
+    seq_len = np.array([num_steps] + [int(rng.integers(max(1, 2 * max_len), num_steps + 1))
+                                      for _ in range(batch - 1)], dtype=np.int32)
+    flat, offsets = pack_labels(labels)
+    loss, grad, status = hip.ctc_loss_fwd_bwd(_t(logits), _t(flat, torch.int32),
+                                              _t(offsets, torch.int32),
+                                              _t(seq_len, torch.int32), max_len, grad_scale=0.5)
+    ref_loss, ref_grad, ref_status = cref.ctc_loss(logits, labels, seq_len)
+    assert (status.cpu().numpy() == ref_status).all() and (ref_status == 0).all()
+    # bar: 1e-3 on the loss (fp32, north_star); the kernel keeps the lattice in double
+    assert np.abs(loss.cpu().numpy() - ref_loss).max() < 1e-3
+    assert np.abs(grad.cpu().numpy() - 0.5 * ref_grad).max() < 1e-4
+
+
+def test_ctc_loss_known_answer_tf(hip):
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'ctc_kat.json')))
+    for case in kat['loss_cases']:
+        probs = np.array(case['probs'], dtype=np.float64)
+        logits = np.log(probs).astype(np.float32)[:, None, :]
+        flat, offsets = pack_labels([case['targets']])
+        loss, grad, status = hip.ctc_loss_fwd_bwd(
+            _t(logits), _t(flat, torch.int32), _t(offsets, torch.int32),
+            _t(np.array([probs.shape[0]]), torch.int32), len(case['targets']))
+        assert int(status[0]) == 0
+        assert abs(float(loss[0]) - case['loss']) < 1e-4
+        assert np.abs(grad.cpu().numpy()[:, 0, :] - np.array(case['grad'])).max() < 1e-5
+
+
+def test_ctc_infeasible_and_bad_label(hip):
+    rng = np.random.default_rng(3)
+    logits = rng.normal(size=(4, 3, 6)).astype(np.float32)
+    labels = [[0, 0, 0], [1, 2], [5]]      # needs 5 frames; fine; blank as label
+    flat, offsets = pack_labels(labels)
+    loss, grad, status = hip.ctc_loss_fwd_bwd(_t(logits), _t(flat, torch.int32),
+                                              _t(offsets, torch.int32),
+                                              _t(np.array([4, 4, 4]), torch.int32), 3)
+    assert status.cpu().tolist() == [1, 0, 2]
+    assert torch.isinf(loss[0]) and torch.isinf(loss[2]) and torch.isfinite(loss[1])
+    assert float(grad[:, 0].abs().max()) == 0.0 and float(grad[:, 2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('shape', [(7, 3, 6), (300, 5, 29), (777, 2, 29)])
+def test_greedy_decode(hip, shape):
+    num_steps, batch, classes = shape
+    rng = np.random.default_rng(11)
+    logits = rng.normal(size=shape).astype(np.float32)
+    logits[:, :, -1] += 1.0      # more blanks
+    seq_len = rng.integers(1, num_steps + 1, size=batch).astype(np.int32)
+    seq_len[0] = num_steps
+    out, out_len = hip.ctc_greedy_decode(_t(logits), _t(seq_len, torch.int32))
+    ref = octc.greedy_decode(logits, seq_len)
+    out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+    for b in range(batch):
+        assert out[b, :out_len[b]].tolist() == ref[b]
+        assert (out[b, out_len[b]:] == 0).all()
+
+
+@pytest.mark.parametrize('cell', ['lstm', 'rnn_tanh', 'rnn_relu'])
+@pytest.mark.parametrize('use_len', [False, True])
+@pytest.mark.parametrize('dims', [(9, 3, 64), (23, 18, 128)])
+def test_rnn_fwd_bwd(hip, cell, use_len, dims):
+    num_steps, batch, hidden = dims
+    gates = onn.GATES[cell]
+    rng = np.random.default_rng(5)
+    xw = (rng.normal(size=(num_steps, batch, 2, gates * hidden)) * 0.5).astype(np.float32)
+    w_hh = (rng.normal(size=(2, gates * hidden, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    seq_len = None
+    if use_len:
+        seq_len = rng.integers(1, num_steps + 1, size=batch).astype(np.int32)
+        seq_len[0] = num_steps
+    dy = rng.normal(size=(num_steps, batch, 2 * hidden)).astype(np.float32)
+
+    # reference: torch CPU autograd over the same recurrence written with plain ops (float64)
+    xw_t = torch.tensor(xw, dtype=torch.float64, requires_grad=True)
+    w_t = torch.tensor(w_hh, dtype=torch.float64, requires_grad=True)
+    ys = torch.zeros(num_steps, batch, 2 * hidden, dtype=torch.float64)
+    out_rows = []
+    for d in (0, 1):
+        for b in range(batch):
+            steps = int(seq_len[b]) if use_len else num_steps
+            h = torch.zeros(hidden, dtype=torch.float64)
+            c = torch.zeros(hidden, dtype=torch.float64)
+            for s in range(steps):
+                t = s if d == 0 else steps - 1 - s
+                pre = xw_t[t, b, d] + w_t[d] @ h
+                if cell == 'lstm':
+                    i, f, g, o = pre.split(hidden)
+                    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                    h = torch.sigmoid(o) * torch.tanh(c)
+                elif cell == 'rnn_tanh':
+                    h = torch.tanh(pre)
+                else:
+                    h = torch.relu(pre)
+                out_rows.append((t, b, d, h))
+    ys = torch.zeros(num_steps, batch, 2, hidden, dtype=torch.float64)
+    idx_t = torch.tensor([r[0] for r in out_rows])
+    idx_b = torch.tensor([r[1] for r in out_rows])
+    idx_d = torch.tensor([r[2] for r in out_rows])
+    ys = ys.index_put((idx_t, idx_b, idx_d), torch.stack([r[3] for r in out_rows]))
+    ys = ys.reshape(num_steps, batch, 2 * hidden)
+    (ys * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+
+    sl = _t(seq_len, torch.int32) if use_len else None
+    y, reserve, ws = hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl)
+    assert np.abs(y.cpu().numpy() - ys.detach().numpy()).max() < 2e-5
+    w_hh_t = hip.transpose_batched(_t(w_hh))
+    assert torch.equal(w_hh_t.cpu(), torch.tensor(w_hh).transpose(1, 2).contiguous())
+    dxw = hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl)
+    assert np.abs(dxw.cpu().numpy() - xw_t.grad.numpy()).max() < 1e-4
+    # weight gradient = sum_t dgates_t (x) h_{t-1}; check through the same dxw with torch on CPU
+    # (the product path forms it as one GEMM outside the time loop)
+
+
+def test_bias_act_and_colsum(hip):
+    rng = np.random.default_rng(9)
+    for rows, cols in [(33, 29), (100, 64), (257, 96)]:
+        z = (rng.normal(size=(rows, cols)) * 15).astype(np.float32)
+        bias = rng.normal(size=cols).astype(np.float32)
+        y = hip.bias_act_fwd(_t(z), _t(bias), 20.0)
+        ref = np.minimum(np.maximum(z + bias, 0), 20.0)
+        assert np.abs(y.cpu().numpy() - ref).max() < 1e-6
+        dy = rng.normal(size=(rows, cols)).astype(np.float32)
+        dbias = torch.zeros(cols, device=DEV)
+        dz = hip.bias_act_bwd(y, _t(dy), 20.0, 0.0, dbias)
+        ref_dz = dy * ((ref > 0) & (ref < 20.0))
+        assert np.abs(dz.cpu().numpy() - ref_dz).max() < 1e-6
+        assert np.abs(dbias.cpu().numpy() - ref_dz.sum(0)).max() < 1e-3
+        # plain bias add (logits layer) + standalone column sum
+        y2 = hip.bias_act_fwd(_t(z), _t(bias), 0.0)
+        assert np.abs(y2.cpu().numpy() - (z + bias)).max() < 1e-6
+        db2 = torch.zeros(cols, device=DEV)
+        hip.colsum_accumulate(_t(dy), db2)
+        assert np.abs(db2.cpu().numpy() - dy.sum(0)).max() < 1e-3
+
+
+def test_bias_act_dropout_statistics(hip):
+    rows, cols, rate = 512, 256, 0.1
+    z = torch.full((rows, cols), 5.0, device=DEV)
+    y = hip.bias_act_fwd(z.clone(), torch.zeros(cols, device=DEV), 20.0, rate, seed=1234)
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - (1 - rate)) < 0.01
+    assert torch.allclose(y[y > 0], torch.tensor(5.0 / (1 - rate), device=DEV))
+    y2 = hip.bias_act_fwd(z.clone(), torch.zeros(cols, device=DEV), 20.0, rate, seed=1234)
+    assert torch.equal(y, y2)                       # same seed -> same mask
+    dz = hip.bias_act_bwd(y, torch.ones_like(y), 20.0, rate)
+    assert torch.allclose(dz, (y > 0).float() / (1 - rate))
+
+
+def test_adam_tf_form(hip):
+    rng = np.random.default_rng(2)
+    n = 1003
+    p = rng.normal(size=n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    dp, dm, dv = _t(p), _t(m), _t(v)
+    ref_p, ref_m, ref_v = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in range(1, 4):
+        g = rng.normal(size=n).astype(np.float32)
+        hip.adam_step(dp, _t(g), dm, dv, step, lr=1e-3, grad_scale=0.5)
+        ref_p, ref_m, ref_v = onn.adam_step(ref_p, 0.5 * g.astype(np.float64), ref_m, ref_v,
+                                            step, lr=1e-3)
+    assert np.abs(dp.cpu().numpy() - ref_p).max() < 1e-6
+    assert np.abs(dv.cpu().numpy() - ref_v).max() < 1e-6

@@ -1,0 +1,123 @@
+"""Training engine: one process per GPU, data-parallel over utterances with RCCL.
+
+The reference trains on a single device through ``tf.estimator`` (``asr/train.py:31-55``,
+``train_distribute=None``); the step it runs is forward -> CTC loss -> backward -> Adam
+(``asr/model.py:49-83``).  `Trainer.train_step` is that step written out over the HIP kernels,
+plus what BASELINE.json adds: minibatches sharded across the GPUs of a node, gradients summed
+with RCCL all-reduce over xGMI — per layer slice of the flat gradient arena, launched as soon
+as the backward pass has finished that layer so the collective overlaps the rest of backward.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+from ctc_asr_amd import hip
+from ctc_asr_amd.model import CTCModel
+
+
+def init_distributed(backend=None):
+    """Initialise ``torch.distributed`` from the torchrun environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world_size).  ``backend`` defaults to
+    'nccl' (= RCCL on ROCm) when a GPU is visible, else 'gloo'."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradientReducer:
+    """Bucketed sum-all-reduce of the flat gradient arena.
+
+    ``hook(layer, start, stop)`` is called by ``CTCModel.backward`` when a layer's slice is
+    final; slices are merged into buckets of at least ``bucket_bytes`` (contiguous because the
+    arena is laid out in layer order and backward walks it from the end) and each bucket is
+    reduced asynchronously.  ``finish()`` flushes the remainder and waits.  With world size 1
+    everything is a no-op.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets of
+    tens of MB keep each ring step bandwidth- rather than latency-bound without delaying the
+    first launch."""
+
+    def __init__(self, grad_arena, world_size, bucket_bytes=64 << 20, group=None):
+        self.grad, self.world, self.group = grad_arena, world_size, group
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.pending_start = None
+        self.pending_stop = None
+        self.works = []
+
+    def hook(self, _layer, start, stop):
+        if self.world <= 1:
+            return
+        if self.pending_stop is None:
+            self.pending_start, self.pending_stop = start, stop
+        else:
+            # backward visits layers from the end of the arena towards its start
+            if stop != self.pending_start:
+                self._flush()
+                self.pending_start, self.pending_stop = start, stop
+            else:
+                self.pending_start = start
+        if self.pending_stop - self.pending_start >= self.bucket_elems:
+            self._flush()
+
+    def _flush(self):
+        if self.pending_stop is None:
+            return
+        view = self.grad[self.pending_start:self.pending_stop]
+        self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
+                                          async_op=True))
+        self.pending_start = self.pending_stop = None
+
+    def finish(self):
+        if self.world <= 1:
+            return
+        self._flush()
+        for work in self.works:
+            work.wait()
+        self.works = []
+
+
+class Trainer:
+    """Owns a `CTCModel` replica on this rank's GPU and runs synchronous data-parallel steps."""
+
+    def __init__(self, cfg, flags=None, device=None, seed=0, params=None, world_size=1, rank=0,
+                 bucket_bytes=64 << 20):
+        self.world, self.rank = world_size, rank
+        device = device or 'cuda:{}'.format(torch.cuda.current_device())
+        self.model = CTCModel(cfg, device, seed=seed, params=params)
+        self.lr = getattr(flags, 'learning_rate', 1e-5) if flags is not None else 1e-5
+        self.beta1 = getattr(flags, 'adam_beta1', 0.9) if flags is not None else 0.9
+        self.beta2 = getattr(flags, 'adam_beta2', 0.999) if flags is not None else 0.999
+        self.eps = getattr(flags, 'adam_epsilon', 1e-8) if flags is not None else 1e-8
+        self.reducer = GradientReducer(self.model.arena.grad, world_size, bucket_bytes)
+        if world_size > 1:   # identical replicas: rank 0's initial parameters win
+            dist.broadcast(self.model.arena.param, src=0)
+
+    def train_step(self, features, feature_len, labels, check=True):
+        """forward + CTC + backward (+ all-reduce) + Adam on this rank's shard of the global
+        batch; returns the local mean loss (device scalar).  The global loss is the mean over
+        ranks of the local means (equal shard sizes), so gradients are summed and scaled by
+        1 / world_size inside the Adam kernel."""
+        loss = self.model.forward_backward(features, feature_len, labels,
+                                           reduce_hook=self.reducer.hook, check=check)
+        self.reducer.finish()
+        self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
+                                   grad_scale=1.0 / self.world)
+        return loss
+
+    def global_mean(self, value):
+        """Average a device scalar over ranks (logged loss, eval metrics)."""
+        if self.world <= 1:
+            return value
+        value = value.detach().clone()
+        dist.all_reduce(value, op=dist.ReduceOp.SUM)
+        return value / self.world

@@ -44,6 +44,40 @@ SIGNATURES = {
 
 _lib = None
 
+# Optional per-entry-point timing: set ``EVENTS = {}`` and every wrapped call listed in
+# ``TIMED`` is bracketed by HIP events on the launch stream (``drain_events`` returns ms sums).
+EVENTS = None
+TIMED = ('rnn_fwd', 'rnn_bwd', 'ctc_loss_fwd_bwd')
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if EVENTS is not None and self.name in TIMED:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.stop = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if EVENTS is not None and self.name in TIMED:
+            self.stop.record()
+            EVENTS.setdefault(self.name, []).append((self.start, self.stop))
+        return False
+
+
+def drain_events():
+    """{name: (calls, total_ms)} for the events collected so far; call after a synchronize."""
+    global EVENTS
+    out = {}
+    for name, pairs in (EVENTS or {}).items():
+        out[name] = (len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
+    if EVENTS is not None:
+        EVENTS = {}
+    return out
+
 
 class CtcAsrError(RuntimeError):
     """Non-zero status from the C ABI."""
@@ -130,7 +164,8 @@ def ctc_loss_fwd_bwd(logits, labels, label_offsets, seq_len, max_label_len, blan
     need = ctc_loss_workspace_bytes(num_steps, batch, classes, max_label_len)
     if workspace is None:
         workspace = _workspace(need, dev)
-    _check(load().ctcasr_ctc_loss_fwd_bwd(
+    with _Timed('ctc_loss_fwd_bwd'):
+      _check(load().ctcasr_ctc_loss_fwd_bwd(
         _dev(logits, name='logits'), _dev(labels, torch.int32, 'labels'),
         _dev(label_offsets, torch.int32, 'label_offsets'), _dev(seq_len, torch.int32, 'seq_len'),
         num_steps, batch, classes, blank, int(max_label_len), float(grad_scale),
@@ -190,7 +225,8 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
         reserve = _workspace(rnn_reserve_bytes(cell, num_steps, batch, hidden), dev)
     if workspace is None:
         workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
-    _check(load().ctcasr_rnn_fwd(
+    with _Timed('rnn_fwd'):
+      _check(load().ctcasr_rnn_fwd(
         CELL_IDS[cell], _dev(xw, name='xw'), _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
         _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
         _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
@@ -209,7 +245,8 @@ def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, d
         if dxw is None else dxw
     if workspace is None:
         workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
-    _check(load().ctcasr_rnn_bwd(
+    with _Timed('rnn_bwd'):
+      _check(load().ctcasr_rnn_bwd(
         CELL_IDS[cell], _dev(dy, name='dy'), _dev(y, name='y'), _dev(w_hh_t, name='w_hh_t'),
         _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
         hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),

@@ -382,7 +382,10 @@ class CTCModel:
         d(mean loss)/d(logits) in ``self._acts['dlogits']`` for ``backward``.  Raises
         `InfeasibleAlignmentError` where TensorFlow raises (``check=False`` defers the
         device->host status read to the caller)."""
-        flat, offsets, max_len, _ = self.pack_labels(labels, self.device)
+        if isinstance(labels, tuple) and len(labels) == 4 and torch.is_tensor(labels[0]):
+            flat, offsets, max_len, _ = labels          # already packed by `pack_labels`
+        else:
+            flat, offsets, max_len, _ = self.pack_labels(labels, self.device)
         batch = logits.shape[1]
         per_utt, grad, status = hip.ctc_loss_fwd_bwd(logits, flat, offsets, seq_length, max_len,
                                                      grad_scale=1.0 / batch)

@@ -203,28 +203,42 @@ def main():
         t_out = cfg.output_time(frames)
         flops_per_audio_s = 3.0 * forward_flops_per_utt(cfg, frames) / seconds
         gates = GATES[cfg.cell]
-        # dominant kernel: the recurrent time step (fwd + bwd), launched once per step per
-        # layer-pass in the streaming variant.
-        calls = events.get('rnn_fwd', (0, 0.0))[0] + events.get('rnn_bwd', (0, 0.0))[0]
-        rnn_ms = events.get('rnn_fwd', (0, 0.0))[1] + events.get('rnn_bwd', (0, 0.0))[1]
-        launches = calls * t_out
+        # dominant kernel: the recurrence.  Persistent variant: one launch per layer-pass runs all
+        # T' steps with the recurrent weights resident in LDS -> fp32-MFMA roof (the limiter is the
+        # per-step all-to-all exchange of h / dgates).  Streaming variant: one launch per time
+        # step re-reads the weights -> HBM/MALL bandwidth roof.
+        persistent = hip.rnn_persistent_supported(cfg.cell, t_out, batch, hidden)
         roofline = None
-        if launches:
-            avg_s = rnn_ms * 1e-3 / launches
-            # algorithmic bytes of one time-step launch (both directions): the recurrent
-            # weights once + h in / h out + the gate pre-activations it consumes or produces
-            bytes_per_launch = 2 * (gates * hidden * hidden + batch * hidden * (2 + gates)) * 4
-            flops_per_launch = 2.0 * 2 * batch * hidden * gates * hidden
-            achieved_gbs = bytes_per_launch / avg_s / 1e9
-            roofline = {
-                'kernel': 'rnn_{fwd,bwd}_step_kernel<LSTM> (one launch per time step)',
-                'bound': 'hbm', 'achieved': round(achieved_gbs, 1), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(achieved_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
-                'avg_launch_us': round(avg_s * 1e6, 3), 'launches': launches,
-                'algorithmic_bytes_per_launch': bytes_per_launch,
-                'mfma_tflops': round(flops_per_launch / avg_s / 1e12, 2),
-                'share_of_step': round(rnn_ms / (elapsed * 1e3), 3),
-            }
+        dom = max(('rnn_fwd', 'rnn_bwd'), key=lambda k: events.get(k, (0, 0.0))[1])
+        calls, dom_ms = events.get(dom, (0, 0.0))
+        if calls:
+            flops_per_step = 2.0 * 2 * batch * hidden * gates * hidden    # both directions
+            bytes_per_step = 2 * (gates * hidden * hidden + batch * hidden * (2 + gates)) * 4
+            if persistent:
+                avg_s = dom_ms * 1e-3 / calls
+                achieved = flops_per_step * t_out / avg_s / 1e12
+                roofline = {
+                    'kernel': 'prnn_{}_kernel<LSTM> (persistent, LDS-resident recurrent weights; '
+                              'one launch = {} time steps x 2 directions)'.format(dom[4:], t_out),
+                    'bound': 'mfma', 'achieved': round(achieved, 2),
+                    'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'avg_launch_us': round(avg_s * 1e6, 1), 'launches': calls,
+                    'algorithmic_flops_per_launch': flops_per_step * t_out,
+                    'us_per_time_step': round(avg_s * 1e6 / t_out, 3),
+                    'share_of_step': round(dom_ms / (elapsed * 1e3), 3)}
+            else:
+                launches = calls * t_out
+                avg_s = dom_ms * 1e-3 / launches
+                achieved_gbs = bytes_per_step / avg_s / 1e9
+                roofline = {
+                    'kernel': 'rnn_{}_step_kernel<LSTM> (one launch per time step)'.format(dom[4:]),
+                    'bound': 'hbm', 'achieved': round(achieved_gbs, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(achieved_gbs / HBM_PEAK_GBS, 4),
+                    'traffic': None, 'avg_launch_us': round(avg_s * 1e6, 3),
+                    'launches': launches, 'algorithmic_bytes_per_launch': bytes_per_step,
+                    'mfma_tflops': round(flops_per_step / avg_s / 1e12, 2),
+                    'share_of_step': round(dom_ms / (elapsed * 1e3), 3)}
         result = {
             'metric': 'audio-seconds/s training throughput (DS2, 10 s utterances)',
             'value': round(value, 2), 'unit': 'audio-s/s', 'n_gpus': world,

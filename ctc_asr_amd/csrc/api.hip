@@ -10,6 +10,7 @@ extern "C" const char *ctcasr_error_string(int code) {
         case CTCASR_ERR_UNSUPPORTED: return "unsupported configuration";
         case CTCASR_ERR_WORKSPACE: return "workspace missing or too small";
         case CTCASR_ERR_LAUNCH: return "kernel launch failed";
+        case CTCASR_ERR_TIMEOUT: return "in-kernel wait timed out";
         default: return "unknown error";
     }
 }

@@ -1,0 +1,571 @@
+// K4/K5, persistent variant: ONE launch runs all T time steps of a bidirectional layer.
+//
+// The recurrence is bound by latency and by re-reading the recurrent weights every step
+// (SURVEY.md 7.2): R is 16.8 MB per direction at H=1024 fp32, more than a 4 MB XCD L2 holds.
+// Here every workgroup keeps its slice of R in LDS for the whole sequence — 128 KB per CU, both
+// directions across the 256 CUs of the chip — laid out in MFMA fragment order so the B operand
+// is a conflict-free lane-linear ds_read_b128.  Per step a workgroup then only (1) reads the
+// previous hidden state (forward: 64 KB at B=16) straight into A fragments with every load in
+// flight at once, (2) issues its share of v_mfma_f32_16x16x4_f32, (3) reduces over its 4 waves
+// through LDS and applies the gate math for the units it owns (cell state stays in registers),
+// and (4) meets the other workgroups of ITS direction at a two-level counter barrier.
+// The two directions are independent chains and never wait for each other.
+//
+// Inter-workgroup visibility uses the write-through form of the guide's placement-independent
+// protocol (no fences on the critical path): the values other workgroups consume (h_t forward,
+// dgates_t backward) are stored with 16-byte `sc1` buffer stores, every storing wave drains
+// them (vmcnt(0)), a workgroup barrier, then ONE lane posts a relaxed agent-scope arrival on its
+// group's counter (8 counters per direction).  Waiters poll the 8 counters with relaxed
+// agent-scope loads from 8 lanes, and read the published rows with `sc1` buffer loads (L1 is
+// bypassed, so no acquire invalidation is needed).  Stores that only the host-side backward
+// pass needs (the LSTM reserve) are plain and issued after the arrival.  Published rows live in
+// the output tensors themselves, whose addresses are unique per time step.  Every spin is
+// bounded; a timeout raises an error word that the host reports (ctcasr_rnn_poll_error).
+#include "common.h"
+#include <stddef.h>
+#include <stdlib.h>
+
+#define PRNN_THREADS 256
+#define PRNN_GROUPS 8
+#define PRNN_SPIN_LIMIT (1u << 22)
+
+namespace {
+
+// Every arrival counter sits in its own 256-byte block: the 16 counters of a launch then map to
+// different memory channels instead of serialising 256 arrivals + all polls on one line.
+#define PRNN_CNT_STRIDE 64
+struct SyncWords {
+    unsigned group_cnt[2][PRNN_GROUPS][PRNN_CNT_STRIDE];
+    unsigned error;
+    unsigned pad[63];
+    unsigned long long prof[16];   // CTCASR_RNN_PROF=1: per-phase 100 MHz ticks of workgroup 0
+};
+
+struct PArgs {
+    const float *xw;       // [T, B, 2, G*H]
+    const float *w;        // fwd: w_hh [2, G*H, H]; bwd: w_hh_t [2, H, G*H]
+    const int *seq_len;
+    float *y;              // [T, B, 2H]
+    const float *dy;
+    float *dxw;
+    float *gates;          // LSTM reserve [T, B, 2, 4H]
+    float *cells;          // LSTM reserve [T, B, 2, H]
+    SyncWords *sync;
+    int T, B, H, nwg;      // nwg = workgroups per direction
+    int prof;              // record phase timings of workgroup 0
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p) {
+    return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ void mma4(f32x4 &acc, const float4 &a, const float4 &b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ int row_steps(const int *seq_len, int b, int T) {
+    return seq_len ? min(max(seq_len[b], 0), T) : T;
+}
+__device__ __forceinline__ int row_time(int dir, int s, int steps) {
+    return dir == 0 ? s : steps - 1 - s;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte write-through store / L1-bypassing load (buffer_*_dwordx4 ... sc1)
+__device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off,
+                                            float a, float b, float c, float d) {
+    u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ float4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                       __uint_as_float(v.w));
+}
+
+// Direction-wide barrier, split in two so that the arrival is posted as soon as a step's
+// published stores are out and the wait happens at the top of the next step.
+// `step` counts arrivals (0-based).
+__device__ __forceinline__ void dir_arrive(SyncWords *sy, int dir, int grp, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_fetch_add(&sy->group_cnt[dir][grp][0], 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait until every workgroup of this direction has posted arrival number `step` (0-based).
+// Only wave 0 polls (8 lanes, one counter each): more pollers measurably slow the arrivals down.
+// On timeout the error word is raised and the workgroup carries on with whatever it reads
+// (results are invalid, the host reports CTCASR_ERR_TIMEOUT) so that no barrier is abandoned.
+__device__ __forceinline__ void dir_wait(SyncWords *sy, int dir, int group_size, unsigned step,
+                                         int tid) {
+    if (tid < 64) {
+        const unsigned target = (unsigned)group_size * (step + 1);
+        unsigned spins = 0;
+        for (;;) {
+            bool ready = true;
+            if (tid < PRNN_GROUPS)
+                ready = __hip_atomic_load(&sy->group_cnt[dir][tid][0], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) >= target;
+            if (__all(ready)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PRNN_SPIN_LIMIT ||
+                ((spins & 1023u) == 0 &&
+                 __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (tid == 0)
+                    __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  NT N-tiles of 16 gate columns per workgroup (cols = 16*NT = G * UPB), QW = 16-float
+// K chunks per wave (H = 64 * QW), MT = batch tiles of 16 rows.
+// LDS: fragments [NT][4*QW][64] float4, then reduction scratch [4][NT][MT*16][17], then a flag.
+// ---------------------------------------------------------------------------------------------
+template <int CELL, int NT, int QW, int MT>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
+    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    constexpr int COLS = 16 * NT;
+    constexpr int UPB = COLS / G;
+    constexpr int Q = 4 * QW;
+    constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *frag = reinterpret_cast<float4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)NT * Q * 64 * sizeof(float4));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.x / p.nwg, slice = blockIdx.x % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int H = p.H, B = p.B, T = p.T;
+    const int u0 = slice * UPB;
+    const int kq = 4 * (lane >> 4);
+
+    // ---- stage this workgroup's slice of R into LDS in fragment order (once) ----------------
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = nt * 16 + (lane & 15);
+        const float *wrow = p.w + ((size_t)dir * G * H + (c / UPB) * H + u0 + (c % UPB)) * H + kq;
+        for (int i = 0; i < QW; ++i) {
+            const int q = wave * QW + i;
+            frag[(nt * Q + q) * 64 + lane] = ldg4(wrow + 16 * q);
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.y, 0, (int)((size_t)T * B * 2 * H * sizeof(float)), 0x00020000);
+
+    // ---- per-item state ----------------------------------------------------------------------
+    float c_state[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) c_state[it] = 0.f;
+
+    int a_steps[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + (lane & 15);
+        a_steps[mt] = row < B ? row_steps(p.seq_len, row, T) : 0;
+    }
+
+    unsigned long long pt[5] = {0, 0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
+    for (int s = 0; s < T; ++s) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
+        // gate pre-activations from the input projection: independent of the recurrence, so
+        // they are requested before waiting for the other workgroups
+        float xw[ITEMS][G];
+        int it_t[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = tid + it * PRNN_THREADS;
+            it_t[it] = -1;
+            if (item < 16 * MT * UPB) {
+                const int b = item / UPB, u = item % UPB;
+                if (b < B) {
+                    const int steps = row_steps(p.seq_len, b, T);
+                    if (s < steps) {
+                        const int t = row_time(dir, s, steps);
+                        it_t[it] = t;
+                        const float *x = p.xw + (((size_t)t * B + b) * 2 + dir) * G * H + u0 + u;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) xw[it][g] = x[(size_t)g * H];
+                    }
+                }
+            }
+        }
+
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        if (s > 0) {
+            dir_wait(p.sync, dir, group_size, (unsigned)(s - 1), tid);
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
+            // A fragments: h_{s-1} rows straight from y, every load issued before the first MFMA
+            float4 a[MT][QW];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = mt * 16 + (lane & 15);
+                const bool ok = s < a_steps[mt];     // row still running (implies s-1 ran too)
+                const int tp = ok ? row_time(dir, s - 1, a_steps[mt]) : 0;
+                const unsigned aoff = (unsigned)((((size_t)tp * B + (ok ? row : 0)) * 2 * H +
+                                                  dir * H + wave * (H / 4) + kq) * sizeof(float));
+#pragma unroll
+                for (int i = 0; i < QW; ++i)
+                    a[mt][i] = ok ? load16_sc1(y_rsrc, aoff + 64 * i)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                const int q = wave * QW + i;
+                float4 bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = frag[(nt * Q + q) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma4(acc[mt][nt], a[mt][i], bf[nt]);
+            }
+        }
+        // cross-wave reduction of the K split
+        if (prof) {
+            asm volatile("" ::"v"(acc[0][0][0]));
+            unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[((wave * NT + nt) * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 +
+                        (lane & 15)] = acc[mt][nt][r];
+        __syncthreads();
+
+        float hv[ITEMS], rsv[ITEMS][5];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            hv[it] = 0.f;
+            if (it_t[it] >= 0) {
+                const int item = tid + it * PRNN_THREADS;
+                const int b = item / UPB, u = item % UPB;
+                float rec[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int c = g * UPB + u;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        sum += red[((w * NT + (c >> 4)) * MT * 16 + b) * 17 + (c & 15)];
+                    rec[g] = sum;
+                }
+                if constexpr (CELL == CTCASR_CELL_LSTM) {
+                    const float gi = sigmoidf_(xw[it][0] + rec[0]);
+                    const float gf = sigmoidf_(xw[it][1] + rec[1]);
+                    const float gg = tanhf(xw[it][2] + rec[2]);
+                    const float go = sigmoidf_(xw[it][3] + rec[3]);
+                    const float c = gf * c_state[it] + gi * gg;
+                    c_state[it] = c;
+                    hv[it] = go * tanhf(c);
+                    rsv[it][0] = gi; rsv[it][1] = gf; rsv[it][2] = gg; rsv[it][3] = go;
+                    rsv[it][4] = c;
+                } else {
+                    const float pre = xw[it][0] + rec[0];
+                    hv[it] = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
+                }
+            }
+            // publish h: lanes of 4 consecutive units gather into one 16-byte sc1 store
+            const float h1 = __shfl_down(hv[it], 1, 64), h2 = __shfl_down(hv[it], 2, 64),
+                        h3 = __shfl_down(hv[it], 3, 64);
+            if (it_t[it] >= 0 && (tid & 3) == 0) {
+                const int item = tid + it * PRNN_THREADS;
+                const int b = item / UPB, u = item % UPB;
+                store16_sc1(y_rsrc, (unsigned)((((size_t)it_t[it] * B + b) * 2 * H + dir * H +
+                                                u0 + u) * sizeof(float)),
+                            hv[it], h1, h2, h3);
+            }
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
+        if (s + 1 < T) dir_arrive(p.sync, dir, grp, tid);
+        // reserve for the backward pass: nobody inside this launch reads it
+        if constexpr (CELL == CTCASR_CELL_LSTM) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                if (it_t[it] < 0) continue;
+                const int item = tid + it * PRNN_THREADS;
+                const int b = item / UPB, unit = u0 + item % UPB;
+                float *gr = p.gates + (((size_t)it_t[it] * B + b) * 2 + dir) * 4 * H + unit;
+                gr[0] = rsv[it][0]; gr[H] = rsv[it][1]; gr[2 * H] = rsv[it][2];
+                gr[3 * H] = rsv[it][3];
+                p.cells[(((size_t)it_t[it] * B + b) * 2 + dir) * H + unit] = rsv[it][4];
+            }
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if (prof)
+        for (int i = 0; i < 4; ++i) p.sync->prof[i] = pt[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  Each workgroup owns UPB = 8 hidden units (output columns of dh_rec = dgates x R);
+// the K dimension is G*H (all gates of all units), split over the 4 waves: QW chunks each.
+// LDS: fragments [4*QW][32] float4 (lanes with (lane&15) >= 8 re-read the first 8 columns; the
+// duplicated MFMA columns are ignored), reduction scratch [4][MT*16][17], flag.
+// ---------------------------------------------------------------------------------------------
+template <int CELL, int QW, int MT, int LB>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
+    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    constexpr int UPB = 8;
+    constexpr int Q = 4 * QW;
+    constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
+    constexpr int NB = QW / LB;          // load batches per wave (LB chunks in flight each)
+    constexpr int CPG = QW / G;          // 16-float chunks per gate within a wave's unit range
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *frag = reinterpret_cast<float4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)Q * 32 * sizeof(float4));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.x / p.nwg, slice = blockIdx.x % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int H = p.H, B = p.B, T = p.T, GH = G * p.H;
+    const int u0 = slice * UPB;
+    const int kq = 4 * (lane >> 4);
+    const int half = (lane >> 4) * 8 + (lane & 7);   // fragment slot shared by lanes l, l+8
+
+    if ((lane & 15) < 8) {
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (lane & 7)) * GH + wave * (H / 4) + kq;
+        for (int i = 0; i < QW; ++i)
+            frag[(wave * QW + i) * 32 + half] = ldg4(wrow + (i / CPG) * H + (i % CPG) * 16);
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.dxw, 0, (int)((size_t)T * B * 2 * GH * sizeof(float)), 0x00020000);
+    float dc_state[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) dc_state[it] = 0.f;
+    int a_steps[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + (lane & 15);
+        a_steps[mt] = row < B ? row_steps(p.seq_len, row, T) : 0;
+    }
+
+    for (int s = T - 1; s >= 0; --s) {
+        // everything the cell derivative needs except dh_rec: prefetched before the barrier
+        float dyv[ITEMS], gv[ITEMS][4], cv[ITEMS], cpv[ITEMS], hv[ITEMS];
+        int it_t[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = tid + it * PRNN_THREADS;
+            it_t[it] = -1;
+            if (item < 16 * MT * UPB) {
+                const int b = item / UPB, u = item % UPB;
+                if (b < B) {
+                    const int steps = row_steps(p.seq_len, b, T);
+                    if (s < steps) {
+                        const int t = row_time(dir, s, steps);
+                        const int unit = u0 + u;
+                        it_t[it] = t;
+                        dyv[it] = p.dy[((size_t)t * B + b) * 2 * H + dir * H + unit];
+                        if constexpr (CELL == CTCASR_CELL_LSTM) {
+                            const float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+                            gv[it][0] = gr[0]; gv[it][1] = gr[H];
+                            gv[it][2] = gr[2 * H]; gv[it][3] = gr[3 * H];
+                            cv[it] = p.cells[(((size_t)t * B + b) * 2 + dir) * H + unit];
+                            cpv[it] = 0.f;
+                            if (s > 0) {
+                                const int tp = row_time(dir, s - 1, steps);
+                                cpv[it] = p.cells[(((size_t)tp * B + b) * 2 + dir) * H + unit];
+                            }
+                        } else {
+                            hv[it] = p.y[((size_t)t * B + b) * 2 * H + dir * H + unit];
+                        }
+                    }
+                }
+            }
+        }
+
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        if (s < T - 1) {
+            // dgates of step s+1 from every workgroup of this direction
+            dir_wait(p.sync, dir, group_size, (unsigned)(T - 2 - s), tid);
+            unsigned aoff[MT];
+            bool ok[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = mt * 16 + (lane & 15);
+                ok[mt] = s + 1 < a_steps[mt];
+                const int tn = ok[mt] ? row_time(dir, s + 1, a_steps[mt]) : 0;
+                aoff[mt] = (unsigned)(((((size_t)tn * B + (ok[mt] ? row : 0)) * 2 + dir) * GH +
+                                       wave * (H / 4) + kq) * sizeof(float));
+            }
+            // chunk i of this wave = gate i / CPG, 16-float unit chunk i % CPG; loads of batch
+            // nb+1 are in flight while batch nb feeds the MFMAs
+            float4 a[2][MT][LB];
+            auto issue = [&](int nb, float4 (&dst)[MT][LB]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < LB; ++i) {
+                        const int c = nb * LB + i;
+                        const unsigned off = (unsigned)(((c / CPG) * H + (c % CPG) * 16) *
+                                                        sizeof(float));
+                        dst[mt][i] = ok[mt] ? load16_sc1(dx_rsrc, aoff[mt] + off)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            };
+            issue(0, a[0]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (nb + 1 < NB) issue(nb + 1, a[(nb + 1) & 1]);
+#pragma unroll
+                for (int i = 0; i < LB; ++i) {
+                    const float4 bf = frag[(wave * QW + nb * LB + i) * 32 + half];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma4(acc[mt], a[nb & 1][mt][i], bf);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[mt][r];
+        __syncthreads();
+
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            float dg[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) dg[g] = 0.f;
+            const int item = tid + it * PRNN_THREADS;
+            const int b = item / UPB, u = item % UPB;
+            if (it_t[it] >= 0) {
+                float dh = dyv[it];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) dh += red[(w * MT * 16 + b) * 17 + u];
+                if constexpr (CELL == CTCASR_CELL_LSTM) {
+                    const float gi = gv[it][0], gf = gv[it][1], gg = gv[it][2], go = gv[it][3];
+                    const float tc = tanhf(cv[it]);
+                    const float dc = dc_state[it] + dh * go * (1.f - tc * tc);
+                    dg[0] = dc * gg * gi * (1.f - gi);
+                    dg[1] = dc * cpv[it] * gf * (1.f - gf);
+                    dg[2] = dc * gi * (1.f - gg * gg);
+                    dg[3] = dh * tc * go * (1.f - go);
+                    dc_state[it] = dc * gf;
+                } else {
+                    const float h = hv[it];
+                    dg[0] = CELL == CTCASR_CELL_RNN_RELU ? (h > 0.f ? dh : 0.f)
+                                                         : dh * (1.f - h * h);
+                }
+            }
+            // publish dgates: 4 consecutive units per 16-byte sc1 store, one store per gate
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float d1 = __shfl_down(dg[g], 1, 64), d2 = __shfl_down(dg[g], 2, 64),
+                            d3 = __shfl_down(dg[g], 3, 64);
+                if (it_t[it] >= 0 && (tid & 3) == 0)
+                    store16_sc1(dx_rsrc,
+                                (unsigned)(((((size_t)it_t[it] * B + b) * 2 + dir) * GH +
+                                            (size_t)g * H + u0 + u) * sizeof(float)),
+                                dg[g], d1, d2, d3);
+            }
+        }
+        if (s > 0) dir_arrive(p.sync, dir, grp, tid);
+    }
+}
+
+int device_cu_count() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        else
+            cus = 0;
+    }
+    return cus;
+}
+
+template <typename K>
+int launch_persistent(K kernel, const PArgs &p, size_t lds, hipStream_t s) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    if (hipMemsetAsync(p.sync, 0, sizeof(SyncWords), s) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    kernel<<<2 * p.nwg, PRNN_THREADS, lds, s>>>(p);
+    return ctcasr_launch_status();
+}
+
+}  // namespace
+
+// Whether the LDS-resident kernels cover this shape (LSTM, H = 1024, B <= 32 for now; every
+// other shape takes the streaming kernels of rnn_step.hip).
+extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
+    // B <= 32: two batch tiles keep the reduction scratch next to the 128 KB weight slice
+    if (cell != CTCASR_CELL_LSTM || H != 1024 || B < 1 || B > 32 || T < 1) return 0;
+    const char *mode = getenv("CTCASR_RNN_MODE");   // "stream" forces the per-step kernels
+    if (mode && mode[0] == 's') return 0;
+    return device_cu_count() >= 256 ? 1 : 0;
+}
+
+size_t prnn_sync_bytes() { return sizeof(SyncWords); }
+
+int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
+             int H, float *y, float *gates, float *cells, void *sync, hipStream_t s) {
+    PArgs p = {};
+    p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
+    p.sync = reinterpret_cast<SyncWords *>(sync);
+    p.T = T; p.B = B; p.H = H; p.nwg = 4 * H / 32;
+    p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
+    if (seq_len && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    const int mt = (B + 15) / 16;
+    constexpr int NT = 2, QW = 16;
+    const size_t frag = (size_t)NT * 4 * QW * 64 * 16;
+#define PRNN_FWD(MT_)                                                                         \
+    return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, NT, QW, MT_>, p,                \
+                             frag + (size_t)4 * NT * MT_ * 16 * 17 * 4 + 16, s)
+    (void)cell;
+    if (mt == 1) { PRNN_FWD(1); }
+    PRNN_FWD(2);
+#undef PRNN_FWD
+}
+
+int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
+             const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
+             float *dxw, void *sync, hipStream_t s) {
+    PArgs p = {};
+    p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
+    p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
+    p.sync = reinterpret_cast<SyncWords *>(sync);
+    p.T = T; p.B = B; p.H = H; p.nwg = H / 8;
+    if (seq_len &&
+        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * 4 * H * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    const int mt = (B + 15) / 16;
+    constexpr int QW = 64;
+    const size_t frag = (size_t)4 * QW * 32 * 16;
+#define PRNN_BWD(MT_, LB_)                                                                    \
+    return launch_persistent(prnn_bwd_kernel<CTCASR_CELL_LSTM, QW, MT_, LB_>, p,               \
+                             frag + (size_t)4 * MT_ * 16 * 17 * 4 + 16, s)
+    (void)cell;
+    if (mt == 1) { PRNN_BWD(1, 32); }
+    PRNN_BWD(2, 16);
+#undef PRNN_BWD
+}
+
+size_t prnn_error_offset() { return offsetof(SyncWords, error); }

@@ -224,6 +224,20 @@ int cell_gates(int cell) {
 
 }  // namespace
 
+// persistent (LDS-resident weights) variant, rnn_persistent.hip
+extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
+size_t prnn_sync_bytes();
+size_t prnn_error_offset();
+int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
+             int H, float *y, float *gates, float *cells, void *sync, hipStream_t s);
+int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
+             const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
+             float *dxw, void *sync, hipStream_t s);
+
+static size_t rnn_state_bytes(int B, int H) {
+    return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256);
+}
+
 extern "C" size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0) return 0;
     if (cell == CTCASR_CELL_LSTM) return (size_t)T * B * 2 * 5 * H * sizeof(float);
@@ -233,7 +247,7 @@ extern "C" size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H) {
 extern "C" size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0 || cell_gates(cell) == 0) return 0;
     // state ping-pong [2,2,B,H] + cell / dc carry [2,B,H]
-    return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256) + 4096;
+    return rnn_state_bytes(B, H) + prnn_sync_bytes();
 }
 
 static int rnn_check(int cell, int T, int B, int H) {
@@ -261,6 +275,9 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, cons
     p.hbuf = reinterpret_cast<float *>(workspace);
     p.cbuf = p.hbuf + (size_t)4 * B * H;
     p.T = T; p.B = B; p.H = H;
+    if (ctcasr_rnn_persistent_supported(cell, T, B, H))
+        return prnn_fwd(cell, xw, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
+                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), s);
     if (seq_len &&
         hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
@@ -297,6 +314,9 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
     p.hbuf = reinterpret_cast<float *>(workspace);
     p.cbuf = p.hbuf + (size_t)4 * B * H;
     p.T = T; p.B = B; p.H = H;
+    if (ctcasr_rnn_persistent_supported(cell, T, B, H))
+        return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw,
+                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), s);
     if (seq_len &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
@@ -311,4 +331,20 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
             rnn_bwd_step_kernel<CTCASR_CELL_RNN_TANH><<<grid, RNN_THREADS, 0, s>>>(p);
     }
     return ctcasr_launch_status();
+}
+
+// Synchronises `stream` and reports whether the last persistent launch that used `workspace`
+// gave up at a grid barrier (CTCASR_ERR_TIMEOUT).  Streaming launches never set the word.
+extern "C" int ctcasr_rnn_poll_error(const void *workspace, size_t workspace_bytes, int cell,
+                                     int T, int B, int H, ctcasr_stream_t stream) {
+    if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
+        return CTCASR_ERR_WORKSPACE;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    if (!ctcasr_rnn_persistent_supported(cell, T, B, H)) return CTCASR_OK;
+    unsigned err = 0;
+    const char *word = reinterpret_cast<const char *>(workspace) + rnn_state_bytes(B, H) +
+                       prnn_error_offset();
+    if (hipMemcpy(&err, word, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    return err ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
 }

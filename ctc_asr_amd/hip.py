@@ -33,6 +33,8 @@ SIGNATURES = {
     'ctcasr_ctc_beam_decode': (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_p] * 4 + [_c_sz, _c_p]),
     'ctcasr_rnn_reserve_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_rnn_workspace_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_rnn_persistent_supported': (_c_int, [_c_int] * 4),
+    'ctcasr_rnn_poll_error': (_c_int, [_c_p, _c_sz] + [_c_int] * 4 + [_c_p]),
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
     'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
@@ -212,6 +214,17 @@ def rnn_reserve_bytes(cell, num_steps, batch, hidden):
 
 def rnn_workspace_bytes(cell, num_steps, batch, hidden):
     return load().ctcasr_rnn_workspace_bytes(CELL_IDS[cell], num_steps, batch, hidden)
+
+
+def rnn_persistent_supported(cell, num_steps, batch, hidden):
+    return bool(load().ctcasr_rnn_persistent_supported(CELL_IDS[cell], num_steps, batch, hidden))
+
+
+def rnn_poll_error(cell, workspace, num_steps, batch, hidden):
+    """Synchronise and raise if the last persistent recurrence launch timed out at a barrier."""
+    _check(load().ctcasr_rnn_poll_error(_dev(workspace, torch.uint8, 'workspace'),
+                                        workspace.numel(), CELL_IDS[cell], num_steps, batch,
+                                        hidden, _stream()), 'rnn persistent kernel')
 
 
 def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None):

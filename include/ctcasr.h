@@ -34,7 +34,8 @@ enum {
     CTCASR_ERR_BAD_ARGUMENT = -1,   /* null pointer, non-positive size, unknown enum           */
     CTCASR_ERR_UNSUPPORTED = -2,    /* valid request outside what the kernels cover            */
     CTCASR_ERR_WORKSPACE = -3,      /* workspace pointer null or too small                     */
-    CTCASR_ERR_LAUNCH = -4          /* hipGetLastError() reported a launch failure             */
+    CTCASR_ERR_LAUNCH = -4,         /* hipGetLastError() reported a launch failure             */
+    CTCASR_ERR_TIMEOUT = -5         /* a bounded in-kernel wait gave up (persistent RNN kernel) */
 };
 
 /* RNN cell types; names follow FLAGS.rnn_cell (asr/params.py:47-50, asr/model.py:194-199). */
@@ -118,6 +119,13 @@ size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H);
 int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
                    const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
                    void *workspace, size_t workspace_bytes, ctcasr_stream_t stream);
+/* 1 when the LDS-resident single-launch kernels cover (cell, T, B, H) on this device, else the
+ * per-step streaming kernels run.  CTCASR_RNN_MODE=stream in the environment forces the latter. */
+int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
+/* Synchronises the stream and returns CTCASR_ERR_TIMEOUT if the last persistent launch that used
+ * `workspace` abandoned a grid barrier (its results are then invalid), else CTCASR_OK. */
+int ctcasr_rnn_poll_error(const void *workspace, size_t workspace_bytes, int cell, int T, int B,
+                          int H, ctcasr_stream_t stream);
 int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                    const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                    const void *reserve, float *dxw, float *db_hh_n, void *workspace,

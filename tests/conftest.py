@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    import torch
+    # many-core hosts: torch's CPU pools crawl on tiny ops with hundreds of threads
+    torch.set_num_threads(min(8, torch.get_num_threads()))
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 

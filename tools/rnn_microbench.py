@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Times ctcasr_rnn_fwd / ctcasr_rnn_bwd alone (C2 shape by default) and, with
+CTCASR_RNN_PROF=1, prints the per-phase timings workgroup 0 of the persistent kernel recorded.
+
+    python tools/rnn_microbench.py [T B H]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ctc_asr_amd import hip  # noqa: E402
+
+
+def main():
+    T, B, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (500, 16, 1024)
+    hip.load()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    xw = torch.randn(T, B, 2, 4 * H, device='cuda', generator=g) * 0.5
+    w = torch.randn(2, 4 * H, H, device='cuda', generator=g) / np.sqrt(H)
+    dy = torch.randn(T, B, 2 * H, device='cuda', generator=g)
+    wt = hip.transpose_batched(w)
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w)
+    dxw = hip.rnn_bwd('lstm', dy, y, wt, reserve, workspace=ws)
+    hip.rnn_poll_error('lstm', ws, T, B, H)
+    for name, fn in (('fwd', lambda: hip.rnn_fwd('lstm', xw, w, y=y, reserve=reserve, workspace=ws)),
+                     ('bwd', lambda: hip.rnn_bwd('lstm', dy, y, wt, reserve, dxw=dxw, workspace=ws))):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        start.record()
+        for _ in range(reps):
+            fn()
+        stop.record()
+        torch.cuda.synchronize()
+        ms = start.elapsed_time(stop) / reps
+        print('{}: {:.3f} ms per call, {:.2f} us per time step'.format(name, ms, ms * 1e3 / T))
+        if os.environ.get('CTCASR_RNN_PROF') and name == 'fwd':
+            state = (6 * B * H * 4 + 255) // 256 * 256
+            words = ws[state + 4096 + 256: state + 4096 + 256 + 64].cpu().numpy().view(np.uint64)
+            labels = ['wait', 'loads+mfma', 'reduce+gates', 'arrive']
+            print('  wg0 phases (us/step): ' + ', '.join(
+                '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
+    hip.rnn_poll_error('lstm', ws, T, B, H)
+    # checksum for A/B comparisons between variants
+    print('checksum y {:.6f} dxw {:.6f}'.format(float(y.double().abs().sum()),
+                                                 float(dxw.double().abs().sum())))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,69 @@
+"""The C-ABI library loads on a GPU-less host, exports every symbol include/ctcasr.h declares,
+and rejects bad arguments before touching the device (no compute calls here)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from ctc_asr_amd import build, hip
+    build.build(verbose=False)
+    return hip.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'ctcasr.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ctcasr_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from ctc_asr_amd import hip
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(hip.SIGNATURES) == declared
+
+
+def test_version_and_error_strings(lib):
+    assert lib.ctcasr_abi_version() == 1
+    assert lib.ctcasr_error_string(0) == b'ok'
+    assert b'workspace' in lib.ctcasr_error_string(-3)
+    assert lib.ctcasr_error_string(-5) == b'in-kernel wait timed out'
+
+
+def test_argument_errors_are_reported_not_thrown(lib):
+    assert lib.ctcasr_log_softmax_fwd(None, None, 4, 29, None) == -1
+    assert lib.ctcasr_ctc_loss_fwd_bwd(None, None, None, None, 5, 2, 29, 28, 3, 1.0, None, None,
+                                       None, None, 0, None) == -1
+    assert lib.ctcasr_rnn_fwd(2, None, None, None, None, 0, 2, 64, None, None, None, 0, None) == -1
+    assert lib.ctcasr_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0,
+                                None) == -1
+    # workspace sizing is pure host arithmetic
+    need = lib.ctcasr_ctc_loss_workspace_bytes(500, 16, 29, 150)
+    assert need >= 500 * 16 * 301 * 8 + 500 * 16 * 29 * 4
+    assert lib.ctcasr_rnn_reserve_bytes(2, 500, 16, 1024) == 500 * 16 * 2 * 5 * 1024 * 4
+    assert lib.ctcasr_rnn_workspace_bytes(2, 500, 16, 1024) > 6 * 16 * 1024 * 4
+
+
+def test_host_wrappers_refuse_cpu_tensors(lib):
+    import torch
+    from ctc_asr_amd import hip
+    with pytest.raises(hip.CtcAsrError):
+        hip.log_softmax_fwd(torch.zeros(4, 29))
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    with pytest.raises(Exception):
+        CTCModel(ModelConfig(num_units_rnn=64, num_layers_rnn=1, num_units_dense=32), 'cpu')
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from ctc_asr_amd import hip
+    with pytest.raises(hip.CtcAsrError):
+        hip.load(str(tmp_path / 'libctcasr.so'))

@@ -1,17 +1,354 @@
-// K10 beam search entry points (device kernel lands in a later commit of this round).
+// K10: CTC beam search on the GPU with the semantics of TensorFlow 1.12's CTCBeamSearchDecoder
+// (top path, merge_repeated=False) as called by CTCModel.decode_fn (asr/model.py:292-296).
+//
+// One workgroup per utterance; the beam (<= 1024 leaves) lives in LDS.  Per frame:
+//   1. all threads: normalise the frame, copy new -> old, update every leaf from its own and its
+//      parent's old probabilities (TensorFlow's first loop is embarrassingly parallel);
+//   2. all threads: two bitonic sorts - the leaves by OLD total (descending: TensorFlow's branch
+//      order) and by NEW total (ascending: a sorted array is a valid min-heap);
+//   3. wave 0: TensorFlow's second loop, literally - branches in order, children in symbol order,
+//      a bounded min-heap whose bottom is replaced when a child beats it.  The 28 child values of
+//      a branch are computed by 28 lanes at once and only children that beat the bottom take the
+//      serial heap path, so a branch without insertions costs a few dozen cycles.
+// The serial part is kept because TensorFlow's result is order dependent in one corner: a leaf
+// that is pushed out of the heap and then re-proposed (and rejected) by its still-active parent
+// before its own turn has its old probabilities wiped and does not expand in this frame.  That
+// is tracked with per-leaf eviction / expansion event numbers instead of mutable tree state.
+// The prefix tree (parent, label, children table, beam slot per node) lives in HBM so that a
+// prefix that leaves the beam and re-enters later is the same node, like TensorFlow's BeamEntry.
+// Ties in total are broken towards the older tree node (TensorFlow leaves them to gtl::TopN /
+// std::sort); node ages can differ from the CPU oracle's, so exact ties are not a parity case.
 #include "common.h"
 
+#define BEAM_THREADS 256
+#define BEAM_MAX_WIDTH 1024
+#define BEAM_SLOTS (2 * BEAM_MAX_WIDTH)   // live leaves + leaves evicted but still due to expand
+#define BEAM_MAX_CLASSES 64
+
+namespace {
+
+__device__ __forceinline__ float lse2f(float a, float b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float hi = fmaxf(a, b), lo = fminf(a, b);
+    return hi + log1pf(expf(lo - hi));
+}
+__device__ __forceinline__ unsigned order_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int gload(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gstore(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct BeamLds {
+    // per slot
+    int node[BEAM_SLOTS], label[BEAM_SLOTS], parent[BEAM_SLOTS], pslot[BEAM_SLOTS];
+    float o_total[BEAM_SLOTS], o_blank[BEAM_SLOTS];
+    float n_total[BEAM_SLOTS], n_blank[BEAM_SLOTS], n_label[BEAM_SLOTS];
+    unsigned long long kids_in_beam[BEAM_SLOTS];   // bit c: child c of this leaf is in the heap
+    short alive[BEAM_SLOTS], was_alive[BEAM_SLOTS], expanded[BEAM_SLOTS];
+    int bidx[BEAM_SLOTS], evict_time[BEAM_SLOTS];
+    // per beam position
+    int heap[BEAM_MAX_WIDTH], branches[BEAM_MAX_WIDTH];
+    unsigned long long sort_a[BEAM_MAX_WIDTH], sort_b[BEAM_MAX_WIDTH];
+    int freelist[BEAM_SLOTS];
+    float x[BEAM_MAX_CLASSES];
+    int misc[8];   // 0 nheap, 1 node count, 2 nfree
+};
+
+// a ranks below b in the heap order (lower total; equal totals: the younger node)
+__device__ __forceinline__ bool worse(const BeamLds &L, int a, int b) {
+    if (L.n_total[a] != L.n_total[b]) return L.n_total[a] < L.n_total[b];
+    return L.node[a] > L.node[b];
+}
+
+// ascending bitonic sort of n 64-bit keys (n padded to pow2 with ~0ull), all threads
+__device__ void bitonic_sort(unsigned long long *keys, int n_pow2, int tid) {
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pow2; i += BEAM_THREADS) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long a = keys[i], b = keys[partner];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BEAM_THREADS)
+beam_decode_kernel(const float *__restrict__ logits, const int *__restrict__ seq_len, int T, int B,
+                   int C, int blank, int W, int norm_mode, int *__restrict__ out,
+                   int *__restrict__ out_len, float *__restrict__ logp, int *pool_parent,
+                   int *pool_label, int *pool_slot, int *pool_children, int nodes_per_utt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BeamLds &L = *reinterpret_cast<BeamLds *>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    int len = seq_len[b];
+    len = len < 0 ? 0 : (len > T ? T : len);
+    pool_parent += (size_t)b * nodes_per_utt;
+    pool_label += (size_t)b * nodes_per_utt;
+    pool_slot += (size_t)b * nodes_per_utt;
+    pool_children += (size_t)b * nodes_per_utt * C;
+    const int nslots = 2 * W;
+
+    for (int s = tid; s < nslots; s += BEAM_THREADS) { L.alive[s] = 0; L.was_alive[s] = 0; }
+    for (int c = tid; c < C; c += BEAM_THREADS) gstore(&pool_children[c], -1);
+    for (int i = tid; i < T; i += BEAM_THREADS) out[(size_t)b * T + i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        L.node[0] = 0; L.label[0] = -1; L.parent[0] = -1; L.alive[0] = 1;
+        L.n_total[0] = 0.f; L.n_blank[0] = 0.f; L.n_label[0] = -INFINITY;
+        gstore(&pool_parent[0], -1); gstore(&pool_label[0], -1); gstore(&pool_slot[0], 0);
+        L.heap[0] = 0;
+        L.misc[0] = 1; L.misc[1] = 1; L.misc[3] = 0;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < len; ++t) {
+        const int nheap0 = L.misc[0];
+        // ---- 1. frame, old <- new, parent slots, children-in-beam masks -------------------------
+        if (tid < 64) {
+            const float *row = logits + ((size_t)t * B + b) * C;
+            const float v = tid < C ? row[tid] : -INFINITY;
+            const float mx = wave_max(v);
+            float off = mx;
+            if (norm_mode == 1) off = mx + logf(wave_sum(tid < C ? expf(v - mx) : 0.f));
+            if (tid < C) L.x[tid] = v - off;
+        }
+        for (int s = tid; s < nslots; s += BEAM_THREADS) {
+            L.kids_in_beam[s] = 0ull;
+            L.was_alive[s] = L.alive[s];
+            L.expanded[s] = 0;
+            L.evict_time[s] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int i = tid; i < nheap0; i += BEAM_THREADS) {
+            const int s = L.heap[i];
+            L.o_total[s] = L.n_total[s];
+            L.o_blank[s] = L.n_blank[s];
+            int ps = -1;
+            if (L.parent[s] >= 0) ps = gload(&pool_slot[L.parent[s]]);
+            L.pslot[s] = ps;
+            if (ps >= 0) atomicOr(&L.kids_in_beam[ps], 1ull << L.label[s]);
+        }
+        __syncthreads();
+        // ---- update the leaves (TensorFlow's first loop) ------------------------------------------
+        for (int i = tid; i < nheap0; i += BEAM_THREADS) {
+            const int s = L.heap[i];
+            float nl = L.n_label[s];
+            const int lab = L.label[s];
+            if (lab >= 0) {
+                const int ps = L.pslot[s];
+                if (ps >= 0) nl = lse2f(nl, lab == L.label[ps] ? L.o_blank[ps] : L.o_total[ps]);
+                nl += L.x[lab];
+            }
+            const float nb = L.o_total[s] + L.x[blank];
+            L.n_label[s] = nl;
+            L.n_blank[s] = nb;
+            L.n_total[s] = lse2f(nb, nl);
+        }
+        __syncthreads();
+        // ---- 2. branch order (old total desc, older node first) and heap (new total asc) --------
+        int n_pow2 = 1;
+        while (n_pow2 < nheap0) n_pow2 <<= 1;
+        for (int i = tid; i < n_pow2; i += BEAM_THREADS) {
+            if (i < nheap0) {
+                const int s = L.heap[i];
+                const unsigned nd = min((unsigned)L.node[s], 0x1fffffu);
+                // descending old total == ascending ~key; ties: older (smaller id) node first
+                L.sort_a[i] = ((unsigned long long)(~order_key(L.o_total[s])) << 32) |
+                              (nd << 11) | (unsigned)s;
+                // ascending new total; ties: the worse (younger = larger id) first
+                L.sort_b[i] = ((unsigned long long)order_key(L.n_total[s]) << 32) |
+                              ((0x1fffffu - nd) << 11) | (unsigned)s;
+            } else {
+                L.sort_a[i] = ~0ull;
+                L.sort_b[i] = ~0ull;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(L.sort_a, n_pow2, tid);
+        bitonic_sort(L.sort_b, n_pow2, tid);
+        for (int i = tid; i < nheap0; i += BEAM_THREADS) {
+            const int sa = (int)(L.sort_a[i] & 0x7ffu);
+            L.branches[i] = sa;
+            L.bidx[sa] = i;
+            L.heap[i] = (int)(L.sort_b[i] & 0x7ffu);
+        }
+        __syncthreads();
+
+        // ---- 3. TensorFlow's second loop, serial over branches, on wave 0 ------------------------
+        if (tid < 64) {
+            int nheap = nheap0, nfree = 0, nodes = L.misc[1];
+            for (int base = 0; base < nslots; base += 64) {      // free slots, ordered
+                const bool is_free = base + lane < nslots && !L.alive[base + lane];
+                const unsigned long long m = __ballot(is_free);
+                if (is_free)
+                    L.freelist[nfree + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
+                nfree += __popcll(m);
+            }
+            for (int j = 0; j < nheap0; ++j) {
+                const int s = L.branches[j];
+                const float ot = L.o_total[s];
+                // branches come in descending old total and the heap bottom only rises: once a
+                // branch cannot beat the bottom of a full heap, no later one can
+                if (nheap == W && !(ot > L.n_total[L.heap[0]])) break;
+                if (!L.alive[s]) {
+                    // pushed out earlier in this frame: wiped if its parent re-proposed it since
+                    const int ps = L.pslot[s];
+                    if (ps >= 0 && L.expanded[ps] &&
+                        L.evict_time[s] < L.bidx[ps] * 64 + L.label[s])
+                        continue;
+                }
+                if (!(ot > -INFINITY)) continue;
+                if (!(nheap < W || ot > L.n_total[L.heap[0]])) continue;
+                if (lane == 0) L.expanded[s] = 1;
+                const int slabel = L.label[s];
+                const unsigned long long active = L.kids_in_beam[s];
+                float v = -INFINITY;
+                if (lane < C && lane != blank && !((active >> lane) & 1ull))
+                    v = L.x[lane] + (lane == slabel ? L.o_blank[s] : ot);
+                // children that could enter right now; the bottom only rises while we insert
+                unsigned long long cand =
+                    __ballot(v > -INFINITY && (nheap < W || v > L.n_total[L.heap[0]]));
+                while (cand) {
+                    const int c = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const float vc = __shfl(v, c, 64);
+                    if (!(nheap < W || vc > L.n_total[L.heap[0]])) continue;
+                    if (nodes + 1 >= nodes_per_utt) {     // tree pool exhausted
+                        if (lane == 0) L.misc[3] = 1;
+                        cand = 0ull;
+                        continue;
+                    }
+                    if (lane == 0) {
+                        const bool full = nheap == W;
+                        if (full) {
+                            // the bottom leaves the beam (before a slot is taken: a transient
+                            // child hands its slot straight back)
+                            const int ev = L.heap[0];
+                            L.alive[ev] = 0;
+                            L.evict_time[ev] = j * 64 + c;
+                            const int eps = L.pslot[ev];
+                            if (eps >= 0) L.kids_in_beam[eps] &= ~(1ull << L.label[ev]);
+                            if (!L.was_alive[ev]) L.freelist[nfree++] = ev;
+                        }
+                        // node of child (s, c): reuse or create
+                        const int pnode = L.node[s];
+                        int kid = gload(&pool_children[(size_t)pnode * C + c]);
+                        if (kid < 0) {
+                            kid = nodes++;
+                            gstore(&pool_children[(size_t)pnode * C + c], kid);
+                            gstore(&pool_parent[kid], pnode);
+                            gstore(&pool_label[kid], c);
+                            for (int cc = 0; cc < C; ++cc)
+                                gstore(&pool_children[(size_t)kid * C + cc], -1);
+                        }
+                        const int ns = L.freelist[--nfree];
+                        L.node[ns] = kid; L.label[ns] = c; L.parent[ns] = pnode; L.pslot[ns] = s;
+                        L.n_total[ns] = vc; L.n_label[ns] = vc; L.n_blank[ns] = -INFINITY;
+                        L.alive[ns] = 1; L.was_alive[ns] = 0; L.expanded[ns] = 0;
+                        L.kids_in_beam[ns] = 0ull;
+                        L.kids_in_beam[s] |= 1ull << c;
+                        int pos;
+                        if (full) {
+                            L.heap[0] = ns;
+                            pos = 0;
+                            for (;;) {      // sift down
+                                int l = 2 * pos + 1, r = l + 1, m = pos;
+                                if (l < nheap && worse(L, L.heap[l], L.heap[m])) m = l;
+                                if (r < nheap && worse(L, L.heap[r], L.heap[m])) m = r;
+                                if (m == pos) break;
+                                const int tmp = L.heap[pos]; L.heap[pos] = L.heap[m];
+                                L.heap[m] = tmp; pos = m;
+                            }
+                        } else {
+                            pos = nheap;
+                            L.heap[pos] = ns;
+                            while (pos > 0) {   // sift up
+                                const int p = (pos - 1) / 2;
+                                if (!worse(L, L.heap[pos], L.heap[p])) break;
+                                const int tmp = L.heap[pos]; L.heap[pos] = L.heap[p];
+                                L.heap[p] = tmp; pos = p;
+                            }
+                        }
+                    }
+                    if (nheap < W) ++nheap;
+                    nfree = __shfl(nfree, 0, 64);
+                    nodes = __shfl(nodes, 0, 64);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (lane == 0) { L.misc[0] = nheap; L.misc[1] = nodes; }
+        }
+        __syncthreads();
+        // ---- beam slots of the tree nodes for the next frame -----------------------------------
+        for (int s = tid; s < nslots; s += BEAM_THREADS) {
+            if (L.alive[s]) gstore(&pool_slot[L.node[s]], s);
+            else if (L.was_alive[s]) gstore(&pool_slot[L.node[s]], -1);
+        }
+        __syncthreads();
+    }
+
+    // ---- best leaf and its label path --------------------------------------------------------------
+    if (tid == 0) {
+        const int nheap = L.misc[0];
+        int best = L.heap[0];
+        for (int i = 1; i < nheap; ++i)
+            if (worse(L, best, L.heap[i])) best = L.heap[i];
+        int n = 0;
+        for (int node = L.node[best]; gload(&pool_parent[node]) >= 0; node = gload(&pool_parent[node]))
+            ++n;
+        out_len[b] = L.misc[3] ? -1 : n;      // -1: the prefix-tree pool overflowed
+        if (logp) logp[b] = L.n_total[best];
+        int k = n;
+        for (int node = L.node[best]; gload(&pool_parent[node]) >= 0; node = gload(&pool_parent[node]))
+            out[(size_t)b * T + --k] = gload(&pool_label[node]);
+    }
+}
+
+// tree nodes per utterance: one per successful heap insertion (<= 2^21, the sort key's id field)
+size_t nodes_per_utt(int T, int W) {
+    const size_t n = (size_t)2 * W * T + 1;
+    return n < (1u << 21) ? n : (1u << 21);
+}
+
+}  // namespace
+
 extern "C" size_t ctcasr_ctc_beam_workspace_bytes(int T, int B, int C, int beam_width) {
-    (void)T; (void)B; (void)C; (void)beam_width;
-    return 256;
+    if (T <= 0 || B <= 0 || C <= 0 || beam_width <= 0) return 0;
+    return (size_t)B * nodes_per_utt(T, beam_width) * (3 + (size_t)C) * sizeof(int) + 256;
 }
 
 extern "C" int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, int B,
                                       int C, int blank, int beam_width, int norm_mode,
                                       int32_t *out, int32_t *out_len, float *logp, void *workspace,
                                       size_t workspace_bytes, ctcasr_stream_t stream) {
-    (void)logits; (void)seq_len; (void)T; (void)B; (void)C; (void)blank; (void)beam_width;
-    (void)norm_mode; (void)out; (void)out_len; (void)logp; (void)workspace;
-    (void)workspace_bytes; (void)stream;
-    return CTCASR_ERR_UNSUPPORTED;
+    if (!logits || !seq_len || !out || !out_len || T <= 0 || B <= 0 || C <= 1 || blank < 0 ||
+        blank >= C || beam_width <= 0 || norm_mode < 0 || norm_mode > 1)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (beam_width > BEAM_MAX_WIDTH || C > BEAM_MAX_CLASSES) return CTCASR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ctcasr_ctc_beam_workspace_bytes(T, B, C, beam_width))
+        return CTCASR_ERR_WORKSPACE;
+    const size_t n = nodes_per_utt(T, beam_width);
+    int *pool_parent = reinterpret_cast<int *>(workspace);
+    int *pool_label = pool_parent + (size_t)B * n;
+    int *pool_slot = pool_label + (size_t)B * n;
+    int *pool_children = pool_slot + (size_t)B * n;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&beam_decode_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(BeamLds)) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    beam_decode_kernel<<<B, BEAM_THREADS, sizeof(BeamLds), (hipStream_t)stream>>>(
+        logits, seq_len, T, B, C, blank, beam_width, norm_mode, out, out_len, logp, pool_parent,
+        pool_label, pool_slot, pool_children, (int)n);
+    return ctcasr_launch_status();
 }

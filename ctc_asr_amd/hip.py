@@ -41,6 +41,12 @@ SIGNATURES = {
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    'ctcasr_features_num_frames': (_c_int, [_c_int]),
+    'ctcasr_features_tables_bytes': (_c_sz, []),
+    'ctcasr_features_init_tables': (_c_int, [_c_p, _c_int, _c_p]),
+    'ctcasr_features_workspace_bytes': (_c_sz, [_c_int, _c_int]),
+    'ctcasr_features': (_c_int, [_c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_p, _c_int, _c_p, _c_p,
+                                 _c_sz, _c_p]),
     'ctcasr_adam_step': (_c_int, [_c_p] * 4 + [_c_i64] + [_c_f] * 4 + [_c_i64, _c_f, _c_p]),
 }
 
@@ -205,6 +211,8 @@ def ctc_beam_decode(logits, seq_len, beam_width, blank=None, normalization='max'
         _dev(out, torch.int32, 'out'), _dev(out_len, torch.int32, 'out_len'),
         _dev(logp, name='logp'), _dev(workspace, torch.uint8, 'workspace'), workspace.numel(),
         _stream()), 'ctc_beam_decode')
+    if bool((out_len < 0).any()):
+        raise CtcAsrError('ctc_beam_decode: prefix-tree pool exhausted')
     return out, out_len, logp
 
 
@@ -311,3 +319,41 @@ def adam_step(param, grad, m, v, step, lr=1e-5, beta1=0.9, beta2=0.999, epsilon=
                                    _dev(m, name='m'), _dev(v, name='v'), param.numel(), float(lr),
                                    float(beta1), float(beta2), float(epsilon), int(step),
                                    float(grad_scale), _stream()), 'adam_step')
+
+
+_FEATURE_TABLES = {}
+
+
+def features_num_frames(num_samples):
+    return load().ctcasr_features_num_frames(int(num_samples))
+
+
+def features(pcm, num_samples, feature_type='mel', normalization='local',
+             drop_every_second_frame=False, sampling_rate=16000, out=None, out_len=None):
+    """pcm int16[B, N] (device), num_samples int32[B] (device) -> (f32[B, T, 80], i32[B])."""
+    if pcm.dtype != torch.int16:
+        raise CtcAsrError('pcm must be int16 (raw WAV samples, not rescaled).')
+    batch, max_samples = pcm.shape
+    dev = pcm.device
+    key = (dev.index, int(sampling_rate))
+    if key not in _FEATURE_TABLES:
+        tables = _workspace(load().ctcasr_features_tables_bytes(), dev)
+        _check(load().ctcasr_features_init_tables(_dev(tables, torch.uint8, 'tables'),
+                                                  int(sampling_rate), _stream()),
+               'features_init_tables')
+        _FEATURE_TABLES[key] = tables
+    tables = _FEATURE_TABLES[key]
+    frames = features_num_frames(max_samples)
+    if drop_every_second_frame:
+        frames = (frames + 1) // 2
+    out = torch.empty((batch, frames, 80), dtype=torch.float32, device=dev) if out is None else out
+    out_len = torch.empty(batch, dtype=torch.int32, device=dev) if out_len is None else out_len
+    workspace = _workspace(load().ctcasr_features_workspace_bytes(batch, max_samples), dev)
+    _check(load().ctcasr_features(
+        _dev(pcm, torch.int16, 'pcm'), _dev(num_samples, torch.int32, 'num_samples'), batch,
+        max_samples, {'mel': 0, 'mfcc': 1}[feature_type],
+        {'none': 0, 'local': 1, 'local_scalar': 2}[normalization],
+        1 if drop_every_second_frame else 0, _dev(tables, torch.uint8, 'tables'),
+        _dev(out, name='out'), out.shape[1], _dev(out_len, torch.int32, 'out_len'),
+        _dev(workspace, torch.uint8, 'workspace'), workspace.numel(), _stream()), 'features')
+    return out, out_len

@@ -1,0 +1,245 @@
+"""Corpus loading, feature extraction and batching.
+
+Drop-in counterpart of ``asr/input_functions.py`` (``input_fn_generator`` :21-122,
+``__input_generator`` :125-153, ``load_sample`` :156-250).  The reference computes features with
+python_speech_features on one Python thread and batches with ``tf.data``; here WAV bytes are
+read on the host, raw int16 PCM of a whole batch is uploaded once, and log-mel / MFCC features,
+the optional frame drop and the per-utterance normalisation run on the MI355X
+(``ctcasr_features``), writing straight into the zero-padded ``[B, T, 80]`` batch tensor the
+model consumes.  Bucketing only needs frame *counts*, which follow from the sample count.
+
+Reference quirks kept on purpose: the CSV slice ``[1:-1]`` drops the
+header and the LAST example; ``train_batch`` keeps CSV order and drops the remainder; bucketed
+targets shuffle, pad to the longest utterance of the batch and keep partial final batches;
+int16 PCM is not rescaled; padding (0.0) is appended after normalisation.
+"""
+
+import bisect
+import os
+import queue
+import random
+import threading
+
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+from ctc_asr_amd import hip
+from ctc_asr_amd.csv_helper import get_bucket_boundaries, read_csv_rows
+from ctc_asr_amd.labels import ctoi
+from ctc_asr_amd.params import CSV_HEADER_LABEL, CSV_HEADER_PATH, FLAGS
+
+SUPPORTED_FEATURE_TYPES = ('mel', 'mfcc')
+SUPPORTED_NORMALIZATIONS = ('none', 'local', 'local_scalar')
+
+
+def read_wav(file_path):
+    """``wavfile.read`` + the reference's validity checks (``asr/input_functions.py:205-217``)."""
+    if not isinstance(file_path, str):
+        file_path = str(file_path, 'utf-8')
+    if not os.path.isfile(file_path):
+        raise ValueError('"{}" does not exist.'.format(file_path))
+    sampling_rate, audio = wavfile.read(file_path)
+    if len(audio) < 401:
+        raise RuntimeError('Sample length {:,d} to short: {}'.format(len(audio), file_path))
+    if sampling_rate != FLAGS.sampling_rate:
+        raise RuntimeError('Sampling rate is {:,d}, expected {:,d}.'
+                           .format(sampling_rate, FLAGS.sampling_rate))
+    if audio.dtype != np.int16 or audio.ndim != 1:
+        raise RuntimeError('Only mono 16-bit PCM WAV files are supported: {}'.format(file_path))
+    return audio
+
+
+def num_frames(num_samples, drop_every_second_frame=None):
+    """Feature frames of an utterance of ``num_samples`` samples (after the optional drop)."""
+    drop = FLAGS.features_drop_every_second_frame if drop_every_second_frame is None \
+        else drop_every_second_frame
+    frames = hip.features_num_frames(num_samples)
+    return (frames + 1) // 2 if drop else frames
+
+
+def _check_feature_args(feature_type, feature_normalization):
+    feature_type = feature_type if feature_type is not None else FLAGS.feature_type
+    feature_normalization = feature_normalization if feature_normalization is not None \
+        else FLAGS.feature_normalization
+    if feature_type not in SUPPORTED_FEATURE_TYPES:
+        raise ValueError('Requested feature type of {} isn\'t supported.'.format(feature_type))
+    if feature_normalization not in SUPPORTED_NORMALIZATIONS:
+        raise ValueError('Requested feature normalization method {} is invalid.'
+                         .format(feature_normalization))
+    return feature_type, feature_normalization
+
+
+def features_from_pcm(pcm_list, device='cuda', feature_type=None, feature_normalization=None):
+    """List of int16 arrays -> (f32[B, Tmax, 80] device tensor, i32[B] device tensor)."""
+    feature_type, feature_normalization = _check_feature_args(feature_type,
+                                                              feature_normalization)
+    lengths = np.array([len(p) for p in pcm_list], dtype=np.int32)
+    batch = np.zeros((len(pcm_list), int(lengths.max())), dtype=np.int16)
+    for row, pcm in enumerate(pcm_list):
+        batch[row, :len(pcm)] = pcm
+    return hip.features(torch.from_numpy(batch).to(device), torch.from_numpy(lengths).to(device),
+                        feature_type, feature_normalization,
+                        FLAGS.features_drop_every_second_frame, FLAGS.sampling_rate)
+
+
+def load_sample(file_path, feature_type=None, feature_normalization=None, device='cuda'):
+    """Load a WAV file and convert it into feature vectors: (f32[T, 80] ndarray, int32 scalar).
+
+    Same contract and error behaviour as the reference's ``load_sample``; the arithmetic runs on
+    the GPU."""
+    feature_type, feature_normalization = _check_feature_args(feature_type,
+                                                              feature_normalization)
+    audio = read_wav(file_path)
+    feats, lengths = features_from_pcm([audio], device, feature_type, feature_normalization)
+    sample_len = np.array(int(lengths[0]), dtype=np.int32)
+    return feats[0, :int(sample_len)].cpu().numpy(), sample_len
+
+
+def read_manifest(csv_path):
+    """CSV rows as the reference's generator sees them: header AND last row dropped."""
+    return read_csv_rows(csv_path)[1:-1]
+
+
+class Batch:
+    """One minibatch: ``features`` dict + dense zero-padded ``labels`` like the reference's
+    ``input_fn`` output (``asr/input_functions.py:112-120``), tensors already in HBM."""
+
+    def __init__(self, spectrogram, spectrogram_length, label_plaintext, labels, seconds):
+        self.features = {'spectrogram': spectrogram, 'spectrogram_length': spectrogram_length,
+                         'label_plaintext': label_plaintext}
+        self.labels = labels
+        self.audio_seconds = seconds
+
+    def __iter__(self):      # (features, labels) = batch
+        return iter((self.features, self.labels))
+
+
+def _make_batch(items, device):
+    pcm = [it[0] for it in items]
+    feats, lengths = features_from_pcm(pcm, device)
+    width = max(len(it[1]) for it in items)
+    labels = np.zeros((len(items), max(width, 1)), dtype=np.int32)
+    for row, it in enumerate(items):
+        labels[row, :len(it[1])] = it[1]
+    seconds = float(sum(len(p) for p in pcm)) / FLAGS.sampling_rate
+    return Batch(feats, lengths, [it[2] for it in items], labels, seconds)
+
+
+def _example_stream(csv_path, shuffle, rng):
+    lines = read_manifest(csv_path)
+    if shuffle:
+        rng.shuffle(lines)
+    for line in lines:
+        path = os.path.join(FLAGS.corpus_dir, line[CSV_HEADER_PATH])
+        label = line[CSV_HEADER_LABEL]
+        audio = read_wav(path)
+        yield audio, [ctoi(c) for c in label], label, num_frames(len(audio))
+
+
+def _shuffle_buffer(stream, size, rng):
+    """``tf.data.Dataset.shuffle(size)``: uniform draws from a sliding buffer."""
+    buf = []
+    for item in stream:
+        if len(buf) < size:
+            buf.append(item)
+            continue
+        idx = rng.randrange(size)
+        yield buf[idx]
+        buf[idx] = item
+    rng.shuffle(buf)
+    for item in buf:
+        yield item
+
+
+def _group_batches(stream, use_buckets, boundaries, batch_size):
+    if not use_buckets:
+        pending = []
+        for item in stream:
+            pending.append(item)
+            if len(pending) == batch_size:
+                yield pending
+                pending = []
+        return                                   # drop_remainder=True
+    buckets = {}
+    for item in stream:
+        key = bisect.bisect_right(boundaries, item[3])
+        bucket = buckets.setdefault(key, [])
+        bucket.append(item)
+        if len(bucket) == batch_size:
+            yield bucket
+            buckets[key] = []
+    for key in sorted(buckets):                  # partial final batches are kept
+        if buckets[key]:
+            yield buckets[key]
+
+
+def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, prefetch=8):
+    """Zero-argument ``input_fn`` for ``target`` in {'train_bucket', 'train_batch', 'dev', 'test'}
+    (``asr/input_functions.py:21-56``).  Calling it returns an iterator of `Batch`.
+
+    Data-parallel runs group ``world_size * batch_size`` utterances per step from ONE bucket (all
+    ranks walk the same seeded order) and every rank keeps its contiguous shard, so the time
+    extent matches across ranks and nobody waits in the all-reduce; a ragged last group is cut
+    to a multiple of ``world_size``.
+    """
+    if target == 'train_bucket':
+        csv_path, use_buckets = FLAGS.train_csv, True
+    elif target == 'train_batch':
+        csv_path, use_buckets = FLAGS.train_csv, False
+    elif target == 'dev':
+        csv_path, use_buckets = FLAGS.dev_csv, True
+    elif target == 'test':
+        csv_path, use_buckets = FLAGS.test_csv, True
+    else:
+        raise ValueError('Invalid target: "{}"'.format(target))
+    boundaries = get_bucket_boundaries(csv_path, FLAGS.num_buckets) if use_buckets else []
+
+    def input_fn():
+        assert os.path.exists(csv_path) and os.path.isfile(csv_path)
+        rng = random.Random(seed) if (seed is not None or world_size > 1) else random.Random()
+        if world_size > 1 and seed is None:
+            rng = random.Random(FLAGS.random_seed or 1)
+        stream = _example_stream(csv_path, use_buckets, rng)
+        if use_buckets:
+            stream = _shuffle_buffer(stream, FLAGS.shuffle_buffer_size, rng)
+        groups = _group_batches(stream, use_buckets, boundaries, FLAGS.batch_size * world_size)
+
+        def shard(group):
+            if world_size == 1:
+                return group
+            per_rank = len(group) // world_size
+            return group[rank * per_rank:(rank + 1) * per_rank]
+
+        def host_side():
+            for group in groups:
+                part = shard(group)
+                if part:
+                    yield [(it[0], it[1], it[2]) for it in part]
+
+        if prefetch <= 0:
+            for items in host_side():
+                yield _make_batch(items, device)
+            return
+        # WAV reading / label encoding run ahead on a host thread (the reference's prefetch(64))
+        pending = queue.Queue(maxsize=prefetch)
+        done = object()
+
+        def producer():
+            try:
+                for items in host_side():
+                    pending.put(items)
+                pending.put(done)
+            except BaseException as exc:      # surface reader errors in the consumer
+                pending.put(exc)
+
+        threading.Thread(target=producer, daemon=True).start()
+        while True:
+            items = pending.get()
+            if items is done:
+                return
+            if isinstance(items, BaseException):
+                raise items
+            yield _make_batch(items, device)
+
+    return input_fn

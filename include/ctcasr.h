@@ -161,6 +161,27 @@ int ctcasr_adam_step(float *param, const float *grad, float *m, float *v, int64_
                      float beta1, float beta2, float epsilon, int64_t step, float grad_scale,
                      ctcasr_stream_t stream);
 
+/* ---- K1: feature extraction ----------------------------------------------------------------
+ * Replaces python_speech_features.logfbank / mfcc / delta + the post-processing of load_sample
+ * (asr/input_functions.py:156-335) for a batch of utterances.
+ *   pcm            int16 [B, max_samples] raw PCM (NOT rescaled), rows zero padded
+ *   num_samples    int32 [B] valid samples per row (>= 401 like the reference's check)
+ *   feature_type   0 = 'mel' (80 log-mel), 1 = 'mfcc' (40 cepstra + 40 deltas)
+ *   normalization  0 = 'none', 1 = 'local', 2 = 'local_scalar'
+ *   tables         device block of ctcasr_features_tables_bytes(), filled once by
+ *                  ctcasr_features_init_tables(tables, sampling_rate, stream) (synchronous)
+ *   out            float32 [B, out_frames, 80], rows beyond an utterance's length are 0
+ *   out_len        int32 [B] frames per utterance (after the optional every-2nd-frame drop)
+ * ctcasr_features_num_frames(n) = 1 + ceil((n - 400) / 160) is the frame count of n samples. */
+int ctcasr_features_num_frames(int num_samples);
+size_t ctcasr_features_tables_bytes(void);
+int ctcasr_features_init_tables(void *tables, int sampling_rate, ctcasr_stream_t stream);
+size_t ctcasr_features_workspace_bytes(int B, int max_samples);
+int ctcasr_features(const int16_t *pcm, const int32_t *num_samples, int B, int max_samples,
+                    int feature_type, int normalization, int drop_every_second_frame,
+                    const void *tables, float *out, int out_frames, int32_t *out_len,
+                    void *workspace, size_t workspace_bytes, ctcasr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

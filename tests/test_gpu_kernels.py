@@ -210,3 +210,74 @@ def test_adam_tf_form(hip):
                                             step, lr=1e-3)
     assert np.abs(dp.cpu().numpy() - ref_p).max() < 1e-6
     assert np.abs(dv.cpu().numpy() - ref_v).max() < 1e-6
+
+
+@pytest.mark.parametrize('feature_type', ['mel', 'mfcc'])
+@pytest.mark.parametrize('norm', ['none', 'local', 'local_scalar'])
+def test_features_match_oracle(hip, feature_type, norm):
+    from oracle import features as ofeat
+    rng = np.random.default_rng(21)
+    lengths = np.array([16000, 9000, 401, 12345], dtype=np.int32)
+    pcm = np.zeros((4, 16000), dtype=np.int16)
+    for b, n in enumerate(lengths):
+        t = np.arange(n) / 16000.0
+        tone = 4000 * np.sin(2 * np.pi * (200 + 150 * b) * t) * np.exp(-2 * t)
+        pcm[b, :n] = np.clip(rng.normal(size=n) * 1500 + tone, -32768, 32767).astype(np.int16)
+    for drop in (False, True):
+        out, out_len = hip.features(_t(pcm, torch.int16), _t(lengths, torch.int32), feature_type,
+                                    norm, drop)
+        out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+        for b, n in enumerate(lengths):
+            if n == 401 and norm != 'none':
+                continue     # 2 frames: constant-column / tiny-sample statistics, not a parity case
+            ref, ref_len = ofeat.load_sample_from_pcm(pcm[b, :n], 16000, feature_type, norm, drop)
+            assert out_len[b] == int(ref_len)
+            got = out[b, :out_len[b]]
+            # bar: 1e-3 (north_star, fp32); the kernel keeps float64 until the final cast
+            assert np.abs(got - ref).max() < 1e-3, (b, np.abs(got - ref).max())
+            assert np.abs(out[b, out_len[b]:]).max(initial=0.0) == 0.0
+
+
+@pytest.mark.parametrize('norm', ['max', 'log_softmax'])
+def test_beam_search_matches_tensorflow_style_oracle(hip, norm):
+    rng = np.random.default_rng(31)
+    logits = (rng.normal(size=(40, 6, 29)) * 2).astype(np.float32)
+    logits[:, :, -1] += 2.0
+    seq_len = np.array([40, 17, 1, 33, 40, 25], dtype=np.int32)
+    for width in (1, 2, 3, 8, 64, 200):
+        out, out_len, logp = hip.ctc_beam_decode(_t(logits), _t(seq_len, torch.int32), width,
+                                                 normalization=norm)
+        ref_paths, ref_logp = cref.beam_search_decode(logits, seq_len, width, normalization=norm)
+        out, out_len, logp = out.cpu().numpy(), out_len.cpu().numpy(), logp.cpu().numpy()
+        for b in range(len(seq_len)):
+            assert out[b, :out_len[b]].tolist() == ref_paths[b], (width, b)
+            assert (out[b, out_len[b]:] == 0).all()
+        assert np.allclose(logp, ref_logp, atol=1e-4)
+
+
+def test_beam_search_full_size_default_width(hip):
+    """T'=500, 29 classes, beam 1024 (reference default) and 64 (BASELINE config 5)."""
+    rng = np.random.default_rng(32)
+    logits = (rng.normal(size=(500, 3, 29)) * 3).astype(np.float32)
+    logits[:, :, -1] += 3.0
+    seq_len = np.array([500, 431, 500], dtype=np.int32)
+    for width in (64, 1024):
+        out, out_len, logp = hip.ctc_beam_decode(_t(logits), _t(seq_len, torch.int32), width)
+        ref_paths, ref_logp = cref.beam_search_decode(logits, seq_len, width)
+        out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+        for b in range(3):
+            assert out[b, :out_len[b]].tolist() == ref_paths[b], (width, b)
+        assert np.allclose(logp.cpu().numpy(), ref_logp, rtol=1e-5, atol=1e-2)
+
+
+def test_beam_search_known_answer(hip):
+    import json
+    import os
+    case = json.load(open(os.path.join(os.path.dirname(__file__), 'golden',
+                                       'ctc_kat.json')))['decode_case']
+    logits = np.log(np.array(case['probs'])).astype(np.float32)[:, None, :]
+    sl = _t(np.array([5]), torch.int32)
+    out, n, _ = hip.ctc_beam_decode(_t(logits), sl, 64)
+    assert out[0, :int(n[0])].tolist() == case['beam_wide']
+    out, n, _ = hip.ctc_beam_decode(_t(logits), sl, 2)
+    assert out[0, :int(n[0])].tolist() == case['beam_width_2']

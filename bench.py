@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one full training pass over one synthetic minibatch that is already resident in HBM:
-forward (conv front-end, BiLSTM stack, dense, logits) -> fused log-softmax + CTC loss/gradient
--> backward -> RCCL gradient all-reduce (N > 1) -> TensorFlow-form Adam.  Workload =
+A step = one full training pass over one synthetic minibatch of raw 16 kHz int16 PCM that is
+already resident in HBM: log-mel features + normalisation -> forward (conv front-end, BiLSTM
+stack, dense, logits) -> fused log-softmax + CTC loss/gradient -> backward -> RCCL gradient
+all-reduce (N > 1) -> TensorFlow-form Adam.  Workload =
 BASELINE.json configs[1]: DS2, 2 conv layers + 2 x BiLSTM-1024, batch 16 per GPU, 10 s
 utterances (999 feature frames -> T' = 500), fp32.  Scaling is weak: per-GPU batch fixed.
 
@@ -163,14 +164,24 @@ def main():
     trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank)
     model = trainer.model
 
-    feats, lengths, labels, _ = synthetic_batch(batch, seconds, seed=1234 + rank)
-    frames = feats.shape[1]
-    feats_d = torch.tensor(feats).to(device)
-    len_d = torch.tensor(lengths).to(device)
+    # synthetic 16 kHz utterances: int16 PCM resident in HBM (SURVEY.md 8d recipe), random labels
+    from ctc_asr_amd.synth import random_pcm
+    _, _, labels, _ = synthetic_batch(batch, seconds, seed=1234 + rank, frames=1)
+    rng = np.random.default_rng(4321 + rank)
+    num_samples = int(round(seconds * 16000))
+    pcm_d = torch.from_numpy(np.stack([random_pcm(rng, num_samples) for _ in range(batch)])) \
+        .to(device)
+    nsamp_d = torch.full((batch,), num_samples, dtype=torch.int32, device=device)
+    frames = hip.features_num_frames(num_samples)
+    feat_buf = torch.empty((batch, frames, 80), dtype=torch.float32, device=device)
+    len_d = torch.empty(batch, dtype=torch.int32, device=device)
     packed = CTCModel.pack_labels(labels, model.device)
 
     def step():
-        return trainer.train_step(feats_d, len_d, packed, check=False)
+        # hot path from raw audio: log-mel features + per-utterance normalisation on the GPU,
+        # then forward / CTC / backward / all-reduce / Adam
+        hip.features(pcm_d, nsamp_d, 'mel', 'local', False, 16000, out=feat_buf, out_len=len_d)
+        return trainer.train_step(feat_buf, len_d, packed, check=False)
 
     for _ in range(args.warmup):
         loss = step()
@@ -244,8 +255,8 @@ def main():
             'value': round(value, 2), 'unit': 'audio-s/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic (N(0,1) feature frames of 10 s utterances resident '
-                                    'in HBM, random 150-char labels)',
+            'dtype': 'f32', 'data': 'synthetic (16 kHz int16 Gaussian-noise PCM of fixed-length '
+                                    'utterances resident in HBM, random labels at 15 chars/s)',
             'config': {'workload': 'BASELINE.json configs[{}]: DS2 {}-conv + {}xBiLSTM-{}, '
                                    'batch {}/GPU, {:.0f} s utterances'.format(
                                        1 if args.workload.startswith('c2') else 2, len(filters),

@@ -40,6 +40,24 @@ def main(path, top=40, last_steps=0):
         total / 1e6, sum(r[1] for r in rows)))
 
 
+
+
+def pmc(path, top=12):
+    """Per-kernel average of every collected PMC counter (rocprofv3 --pmc ... --kernel-trace)."""
+    con = sqlite3.connect(path)
+    rows = con.execute(
+        'select kernel_name, counter_name, count(*), avg(value) from counters_collection '
+        'group by kernel_name, counter_name order by sum(value) desc').fetchall()
+    print('| kernel | counter | dispatches | avg per dispatch |')
+    print('|---|---|---:|---:|')
+    for name, counter, calls, avg in rows[:top]:
+        short = name if len(name) <= 100 else name[:97] + '...'
+        print('| `{}` | {} | {} | {:.1f} |'.format(short, counter, calls, avg))
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40,
-         int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    if sys.argv[1] == '--pmc':
+        pmc(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 12)
+    else:
+        main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40,
+             int(sys.argv[3]) if len(sys.argv) > 3 else 0)

@@ -51,6 +51,7 @@ struct PArgs {
     float *gates;          // LSTM reserve [T, B, 2, 4H]
     float *cells;          // LSTM reserve [T, B, 2, H]
     SyncWords *sync;
+    float *xchg;           // exchange buffer [T steps][2][K/16 chunks][B][16] (see below)
     int T, B, H, nwg;      // nwg = workgroups per direction
     int prof;              // record phase timings of workgroup 0
 };
@@ -63,6 +64,19 @@ __device__ __forceinline__ void mma4(f32x4 &acc, const float4 &a, const float4 &
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+// Two independent accumulators, alternated: v_mfma_f32_16x16x4_f32 issues every 32 cycles but a
+// dependent accumulate needs 40, so back-to-back MFMAs on ONE accumulator run 25 % slower.
+__device__ __forceinline__ void mma4x2(f32x4 &acc0, f32x4 &acc1, const float4 &a0,
+                                       const float4 &b0, const float4 &a1, const float4 &b1) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
 }
 __device__ __forceinline__ int row_steps(const int *seq_len, int b, int T) {
     return seq_len ? min(max(seq_len[b], 0), T) : T;
@@ -79,8 +93,15 @@ __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigne
     u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 16);
 }
+// Exchange-buffer read.  Plain (L1/L2-allocating) load: every exchange row has an address that
+// is written exactly once per launch (the buffer is indexed by step), always with write-through
+// stores and always before the direction barrier that precedes its first read, so no cache on
+// the reading side can hold an older copy of it - and the 15 other workgroups of the direction
+// on the same XCD then hit in L2 instead of going back to the Infinity Cache (sc1 loads did:
+// ~9 TB/s chip-wide, 7 us per backward step).  AUX selects the cache policy (0 plain, 16 sc1).
+template <int AUX = 0>
 __device__ __forceinline__ float4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
 }
@@ -158,8 +179,18 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     }
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.y, 0, (int)((size_t)T * B * 2 * H * sizeof(float)), 0x00020000);
+    // Published rows go to an exchange buffer laid out [step][dir][16-float K chunk][k group of
+    // 4][b][4 floats]: the A-fragment load of a chunk (lane l: batch row l & 15, k group l >> 4)
+    // is then LANE-LINEAR - lane l reads bytes [16 l, 16 l + 16) of one contiguous 1 KB block.
+    // Reading fragments from y itself (rows 8 KB apart: 16 half-used lines per instruction) ran
+    // at ~25 GB/s per CU, and a contiguous block with lanes permuted inside it (4 address cycles
+    // per lane quad) was still texture-addresser bound at ~37 GB/s per CU.
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * H * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * H;          // floats per step
+    // every workgroup of a direction reads the same rows: start each one at a different chunk so
+    // that the 16 workgroups sharing an XCD's L2 do not all hit the same channel at once
+    const int rot = slice & (QW - 1);
 
     // ---- per-item state ----------------------------------------------------------------------
     float c_state[ITEMS];
@@ -214,25 +245,47 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = mt * 16 + (lane & 15);
+                // rows that are not running (beyond B, or past their length) read the all-zero
+                // step T of the exchange buffer: the loads stay unconditional, so the compiler
+                // can count them (vmcnt(N)) and start the MFMAs as the first ones land
                 const bool ok = s < a_steps[mt];     // row still running (implies s-1 ran too)
-                const int tp = ok ? row_time(dir, s - 1, a_steps[mt]) : 0;
-                const unsigned aoff = (unsigned)((((size_t)tp * B + (ok ? row : 0)) * 2 * H +
-                                                  dir * H + wave * (H / 4) + kq) * sizeof(float));
+                const unsigned aoff = (unsigned)(((size_t)(ok ? s - 1 : T) * x_step +
+                                                  (size_t)dir * B * H +
+                                                  (size_t)(wave * QW) * B * 16 +
+                                                  (size_t)(lane >> 4) * B * 4 +
+                                                  (size_t)(ok ? row : 0) * 4) *
+                                                 sizeof(float));
 #pragma unroll
                 for (int i = 0; i < QW; ++i)
-                    a[mt][i] = ok ? load16_sc1(y_rsrc, aoff + 64 * i)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    a[mt][i] = load16_sc1(x_rsrc, aoff + (unsigned)(((i + rot) & (QW - 1)) *
+                                                                    B * 64));
             }
+            // keep every exchange load above the MFMA loop: hipcc otherwise sinks each load next to
+            // its first use and the step degenerates to load -> wait -> 8 MFMAs -> load ...
+            __builtin_amdgcn_sched_barrier(0);
+            // B fragments one chunk ahead of the MFMAs that consume them (see the backward kernel)
+            float4 bf[NT], nf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = frag[(nt * Q + wave * QW + rot) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
-                const int q = wave * QW + i;
-                float4 bf[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[nt] = frag[(nt * Q + q) * 64 + lane];
+                for (int nt = 0; nt < NT; ++nt) {
+                    nf[nt] = bf[nt];
+                    if (i + 1 < QW)
+                        nf[nt] = frag[(nt * Q + wave * QW + ((i + 1 + rot) & (QW - 1))) * 64 + lane];
+                }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (NT == 2) {
+                        mma4x2(acc[mt][0], acc[mt][1], a[mt][i], bf[0], a[mt][i], bf[1]);
+                    } else {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma4(acc[mt][nt], a[mt][i], bf[nt]);
+                        for (int nt = 0; nt < NT; ++nt) mma4(acc[mt][nt], a[mt][i], bf[nt]);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = nf[nt];
             }
         }
         // cross-wave reduction of the K split
@@ -287,15 +340,24 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                         h3 = __shfl_down(hv[it], 3, 64);
             if (it_t[it] >= 0 && (tid & 3) == 0) {
                 const int item = tid + it * PRNN_THREADS;
-                const int b = item / UPB, u = item % UPB;
-                store16_sc1(y_rsrc, (unsigned)((((size_t)it_t[it] * B + b) * 2 * H + dir * H +
-                                                u0 + u) * sizeof(float)),
+                const int b = item / UPB, unit = u0 + item % UPB;
+                store16_sc1(x_rsrc, (unsigned)(((size_t)s * x_step + (size_t)dir * B * H +
+                                                (size_t)(unit >> 4) * B * 16 +
+                                                (size_t)((unit & 15) >> 2) * B * 4 +
+                                                (size_t)b * 4) * sizeof(float)),
                             hv[it], h1, h2, h3);
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
         if (s + 1 < T) dir_arrive(p.sync, dir, grp, tid);
-        // reserve for the backward pass: nobody inside this launch reads it
+        // y and the reserve for the backward pass: nobody inside this launch reads them
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            if (it_t[it] < 0) continue;
+            const int item = tid + it * PRNN_THREADS;
+            const int b = item / UPB, unit = u0 + item % UPB;
+            p.y[((size_t)it_t[it] * B + b) * 2 * H + dir * H + unit] = hv[it];
+        }
         if constexpr (CELL == CTCASR_CELL_LSTM) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -347,8 +409,11 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     }
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.dxw, 0, (int)((size_t)T * B * 2 * GH * sizeof(float)), 0x00020000);
+    // exchange buffer [step][dir][16-float chunk of n = g*H + unit][k group][b][4] (see forward)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * GH;
+    const int rot = slice & (QW - 1);     // de-synchronise the workgroups' walk over the chunks
     float dc_state[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) dc_state[it] = 0.f;
@@ -359,7 +424,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
         a_steps[mt] = row < B ? row_steps(p.seq_len, row, T) : 0;
     }
 
+    unsigned long long pt[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
     for (int s = T - 1; s >= 0; --s) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
         // everything the cell derivative needs except dh_rec: prefetched before the barrier
         float dyv[ITEMS], gv[ITEMS][4], cv[ITEMS], cpv[ITEMS], hv[ITEMS];
         int it_t[ITEMS];
@@ -394,22 +462,27 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             }
         }
 
-        f32x4 acc[MT];
+        f32x4 acc[MT], acc2[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
         if (s < T - 1) {
             // dgates of step s+1 from every workgroup of this direction
             dir_wait(p.sync, dir, group_size, (unsigned)(T - 2 - s), tid);
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
             unsigned aoff[MT];
             bool ok[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = mt * 16 + (lane & 15);
-                ok[mt] = s + 1 < a_steps[mt];
-                const int tn = ok[mt] ? row_time(dir, s + 1, a_steps[mt]) : 0;
-                aoff[mt] = (unsigned)(((((size_t)tn * B + (ok[mt] ? row : 0)) * 2 + dir) * GH +
-                                       wave * (H / 4) + kq) * sizeof(float));
+                ok[mt] = s + 1 < a_steps[mt];     // otherwise: the all-zero step T
+                aoff[mt] = (unsigned)(((size_t)(ok[mt] ? s + 1 : T) * x_step + (size_t)dir * B * GH +
+                                       (size_t)(wave * (H / 64)) * B * 16 +
+                                       (size_t)(lane >> 4) * B * 4 +
+                                       (size_t)(ok[mt] ? row : 0) * 4) * sizeof(float));
             }
             // chunk i of this wave = gate i / CPG, 16-float unit chunk i % CPG; loads of batch
             // nb+1 are in flight while batch nb feeds the MFMAs
@@ -419,24 +492,40 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < LB; ++i) {
-                        const int c = nb * LB + i;
-                        const unsigned off = (unsigned)(((c / CPG) * H + (c % CPG) * 16) *
-                                                        sizeof(float));
-                        dst[mt][i] = ok[mt] ? load16_sc1(dx_rsrc, aoff[mt] + off)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const int c = (nb * LB + i + rot) & (QW - 1);
+                        // chunk index in n-space: gate * (H / 16) + unit chunk
+                        const unsigned off = (unsigned)(((size_t)(c / CPG) * (H / 16) + (c % CPG)) *
+                                                        B * 16 * sizeof(float));
+                        dst[mt][i] = load16_sc1(x_rsrc, aoff[mt] + off);
                     }
             };
             issue(0, a[0]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if (nb + 1 < NB) issue(nb + 1, a[(nb + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // loads stay above this batch's MFMAs
+                // B fragments (LDS) are fetched one pair of chunks ahead of the MFMAs that use
+                // them: an exposed ds_read_b128 per pair costs as much as the pair's 8 MFMAs
+                auto bfrag = [&](int i) -> float4 {
+                    return frag[(wave * QW + ((nb * LB + i + rot) & (QW - 1))) * 32 + half];
+                };
+                float4 cb0 = bfrag(0), cb1 = bfrag(1);
 #pragma unroll
-                for (int i = 0; i < LB; ++i) {
-                    const float4 bf = frag[(wave * QW + nb * LB + i) * 32 + half];
+                for (int i = 0; i < LB; i += 2) {
+                    float4 nb0 = cb0, nb1 = cb1;
+                    if (i + 2 < LB) { nb0 = bfrag(i + 2); nb1 = bfrag(i + 3); }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) mma4(acc[mt], a[nb & 1][mt][i], bf);
+                    for (int mt = 0; mt < MT; ++mt)
+                        mma4x2(acc[mt], acc2[mt], a[nb & 1][mt][i], cb0, a[nb & 1][mt][i + 1], cb1);
+                    cb0 = nb0; cb1 = nb1;
                 }
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] += acc2[mt];
+        }
+        if (prof) {
+            asm volatile("" ::"v"(acc[0][0]));
+            unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -476,15 +565,28 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             for (int g = 0; g < G; ++g) {
                 const float d1 = __shfl_down(dg[g], 1, 64), d2 = __shfl_down(dg[g], 2, 64),
                             d3 = __shfl_down(dg[g], 3, 64);
-                if (it_t[it] >= 0 && (tid & 3) == 0)
-                    store16_sc1(dx_rsrc,
-                                (unsigned)(((((size_t)it_t[it] * B + b) * 2 + dir) * GH +
-                                            (size_t)g * H + u0 + u) * sizeof(float)),
+                if (it_t[it] >= 0 && (tid & 3) == 0) {
+                    const int n = g * H + u0 + u;
+                    store16_sc1(x_rsrc,
+                                (unsigned)(((size_t)s * x_step + (size_t)dir * B * GH +
+                                            (size_t)(n >> 4) * B * 16 +
+                                            (size_t)((n & 15) >> 2) * B * 4 + (size_t)b * 4) *
+                                           sizeof(float)),
                                 dg[g], d1, d2, d3);
+                }
+            }
+            if (it_t[it] >= 0) {      // dxw in its GEMM layout: read after the launch only
+                float *dx = p.dxw + (((size_t)it_t[it] * B + b) * 2 + dir) * GH + u0 + u;
+#pragma unroll
+                for (int g = 0; g < G; ++g) dx[(size_t)g * H] = dg[g];
             }
         }
+        if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
         if (s > 0) dir_arrive(p.sync, dir, grp, tid);
+        if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
     }
+    if (prof)
+        for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
 }
 
 int device_cu_count() {
@@ -501,11 +603,15 @@ int device_cu_count() {
 }
 
 template <typename K>
-int launch_persistent(K kernel, const PArgs &p, size_t lds, hipStream_t s) {
+int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_floats,
+                      hipStream_t s) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     if (hipMemsetAsync(p.sync, 0, sizeof(SyncWords), s) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    if (hipMemsetAsync(p.xchg + (size_t)p.T * zero_step_floats, 0,
+                       zero_step_floats * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
     kernel<<<2 * p.nwg, PRNN_THREADS, lds, s>>>(p);
     return ctcasr_launch_status();
 }
@@ -524,9 +630,14 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
 
 size_t prnn_sync_bytes() { return sizeof(SyncWords); }
 
+size_t prnn_exchange_bytes(int T, int B, int H, int G) {
+    return ctcasr_align_up((size_t)(T + 1) * 2 * B * G * H * sizeof(float), 256);
+}
+
 int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
              int H, float *y, float *gates, float *cells, void *sync, hipStream_t s) {
     PArgs p = {};
+    p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H; p.nwg = 4 * H / 32;
@@ -538,7 +649,8 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
     const size_t frag = (size_t)NT * 4 * QW * 64 * 16;
 #define PRNN_FWD(MT_)                                                                         \
     return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, NT, QW, MT_>, p,                \
-                             frag + (size_t)4 * NT * MT_ * 16 * 17 * 4 + 16, s)
+                             frag + (size_t)4 * NT * MT_ * 16 * 17 * 4 + 16,                   \
+                             (size_t)2 * B * H, s)
     (void)cell;
     if (mt == 1) { PRNN_FWD(1); }
     PRNN_FWD(2);
@@ -549,10 +661,12 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
              float *dxw, void *sync, hipStream_t s) {
     PArgs p = {};
+    p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H; p.nwg = H / 8;
+    p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * 4 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
@@ -561,7 +675,8 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     const size_t frag = (size_t)4 * QW * 32 * 16;
 #define PRNN_BWD(MT_, LB_)                                                                    \
     return launch_persistent(prnn_bwd_kernel<CTCASR_CELL_LSTM, QW, MT_, LB_>, p,               \
-                             frag + (size_t)4 * MT_ * 16 * 17 * 4 + 16, s)
+                             frag + (size_t)4 * MT_ * 16 * 17 * 4 + 16,                        \
+                             (size_t)2 * B * 4 * H, s)
     (void)cell;
     if (mt == 1) { PRNN_BWD(1, 32); }
     PRNN_BWD(2, 16);

@@ -228,6 +228,7 @@ int cell_gates(int cell) {
 extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
 size_t prnn_sync_bytes();
 size_t prnn_error_offset();
+size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
              int H, float *y, float *gates, float *cells, void *sync, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
@@ -247,7 +248,10 @@ extern "C" size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H) {
 extern "C" size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0 || cell_gates(cell) == 0) return 0;
     // state ping-pong [2,2,B,H] + cell / dc carry [2,B,H]
-    return rnn_state_bytes(B, H) + prnn_sync_bytes();
+    // persistent variant: + the per-step exchange buffer (h forward, dgates backward)
+    return rnn_state_bytes(B, H) + ctcasr_align_up(prnn_sync_bytes(), 256) +
+           (ctcasr_rnn_persistent_supported(cell, T, B, H)
+                ? prnn_exchange_bytes(T, B, H, cell_gates(cell)) : 0);
 }
 
 static int rnn_check(int cell, int T, int B, int H) {

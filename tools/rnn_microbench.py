@@ -36,10 +36,11 @@ def main():
         torch.cuda.synchronize()
         ms = start.elapsed_time(stop) / reps
         print('{}: {:.3f} ms per call, {:.2f} us per time step'.format(name, ms, ms * 1e3 / T))
-        if os.environ.get('CTCASR_RNN_PROF') and name == 'fwd':
+        if os.environ.get('CTCASR_RNN_PROF'):
             state = (6 * B * H * 4 + 255) // 256 * 256
-            words = ws[state + 4096 + 256: state + 4096 + 256 + 64].cpu().numpy().view(np.uint64)
-            labels = ['wait', 'loads+mfma', 'reduce+gates', 'arrive']
+            base = state + 4096 + 256 + (0 if name == 'fwd' else 32)
+            words = ws[base: base + 32].cpu().numpy().view(np.uint64)
+            labels = ['wait', 'loads+mfma', 'reduce+gates+publish', 'drain+arrive']
             print('  wg0 phases (us/step): ' + ', '.join(
                 '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
     hip.rnn_poll_error('lstm', ws, T, B, H)

@@ -55,6 +55,16 @@ bias_act_fwd_kernel_v4(float4 *__restrict__ y, const float4 *__restrict__ bias, 
     }
 }
 
+// out = in * mask / keep with the mask regenerated from (seed, index): the same call serves the
+// forward pass (activations) and the backward pass (gradients).
+__global__ void __launch_bounds__(256)
+dropout_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n, float rate,
+               float inv_keep, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = uniform01(seed, (uint64_t)i) >= rate ? in[i] * inv_keep : 0.f;
+}
+
 // dz = dy * [0 < y < cutoff / keep] / keep, and dbias[c] += column sums.
 // grid = (ceil(cols / 64), row chunks); each wave strides over the rows of its chunk.
 __global__ void __launch_bounds__(256)
@@ -199,6 +209,16 @@ extern "C" int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t r
     if (!dz || !dbias || rows < 0 || cols <= 0) return CTCASR_ERR_BAD_ARGUMENT;
     if (rows == 0) return CTCASR_OK;
     return launch_bwd(nullptr, dz, nullptr, dbias, rows, cols, 0.f, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int ctcasr_dropout(const float *in, float *out, int64_t n, float dropout_rate,
+                              uint64_t seed, ctcasr_stream_t stream) {
+    if (!in || !out || n < 0 || dropout_rate < 0.f || dropout_rate >= 1.f)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (n == 0) return CTCASR_OK;
+    dropout_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(
+        in, out, n, dropout_rate, 1.f / (1.f - dropout_rate), seed);
+    return ctcasr_launch_status();
 }
 
 extern "C" int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,

@@ -27,7 +27,9 @@ struct StepArgs {
     float *gates;          // reserve: LSTM [T, B, 2, 4H] post-activation
     float *cells;          // reserve: LSTM [T, B, 2, H]
     float *hbuf;           // [2, 2, B, H] state ping-pong (fwd)
-    float *cbuf;           // [2, B, H] LSTM cell state (fwd) / dc carry (bwd)
+    float *cbuf;           // [2, B, H] LSTM cell state (fwd) / dc or GRU dh*z carry (bwd)
+    const float *b_hh;     // GRU: recurrent bias [2, 3H] (candidate-gate third is read)
+    float *drec;           // GRU bwd: gradient w.r.t. the recurrent pre-activations [T,B,2,3H]
     int T, B, H, step;
 };
 
@@ -54,11 +56,18 @@ __device__ __forceinline__ int row_time(int dir, int s, int steps) {
 // forward step.  G gates, UPB = 32 / G units per workgroup -> 32 gate columns = 2 MFMA N tiles.
 // grid = (H / UPB, 2 directions, ceil(B / 16))
 // ---------------------------------------------------------------------------------------------
+template <int CELL> struct CellTraits {
+    static constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : (CELL == CTCASR_CELL_GRU ? 3 : 1);
+    static constexpr int UPB = CELL == CTCASR_CELL_LSTM ? 8 : (CELL == CTCASR_CELL_GRU ? 16 : 32);
+    static constexpr int NT = G * UPB / 16;     // MFMA N tiles per workgroup (2, 3, 2)
+};
+
 template <int CELL>
 __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
-    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
-    constexpr int UPB = 32 / G;
-    __shared__ float red[4][2][16][17];
+    constexpr int G = CellTraits<CELL>::G;
+    constexpr int UPB = CellTraits<CELL>::UPB;
+    constexpr int NT = CellTraits<CELL>::NT;
+    __shared__ float red[4][NT][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = blockIdx.y, mt = blockIdx.z;
     const int u0 = blockIdx.x * UPB;
@@ -67,15 +76,17 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
     const float *hprev = p.hbuf + ((size_t)(pp * 2 + dir) * B) * H;
     float *hnext = p.hbuf + ((size_t)((pp ^ 1) * 2 + dir) * B) * H;
 
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.step > 0) {
         const int row = mt * 16 + (lane & 15);
         const bool a_ok = row < B;
         const int kq = 4 * (lane >> 4);
         const float *arow = hprev + (size_t)(a_ok ? row : 0) * H + kq;
-        const float *brow[2];
+        const float *brow[NT];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             int c = nt * 16 + (lane & 15);
             int wrow = (c / UPB) * H + u0 + (c % UPB);
             brow[nt] = p.w + ((size_t)dir * G * H + wrow) * H + kq;
@@ -84,14 +95,15 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
 #pragma unroll 4
         for (int k = kbeg; k < kend; k += 16) {
             float4 a = a_ok ? ldg4(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 b0 = ldg4(brow[0] + k);
-            float4 b1 = ldg4(brow[1] + k);
-            mma4(acc[0], a, b0);
-            mma4(acc[1], a, b1);
+            float4 bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = ldg4(brow[nt] + k);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma4(acc[nt], a, bfr[nt]);
         }
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][nt][4 * (lane >> 4) + r][lane & 15] = acc[nt][r];
     __syncthreads();
@@ -130,6 +142,16 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
             float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
             gr[0] = gi; gr[H] = gf; gr[2 * H] = gg; gr[3 * H] = go;
             p.cells[(((size_t)t * B + b) * 2 + dir) * H + unit] = c;
+        } else if (CELL == CTCASR_CELL_GRU) {
+            // cuDNN GRU: n = tanh(W_n x + b_Wn + r * (R_n h + b_Rn)); h = (1 - z) n + z h_prev
+            const float hp = p.step > 0 ? hprev[hoff] : 0.f;
+            const float gr_ = sigmoidf_(xw[0] + rec[0]);
+            const float gz = sigmoidf_(xw[H] + rec[G > 1 ? 1 : 0]);
+            const float q = rec[G > 2 ? 2 : 0] + p.b_hh[(size_t)dir * 3 * H + 2 * H + unit];
+            const float gn = tanhf(xw[2 * H] + gr_ * q);
+            h = (1.f - gz) * gn + gz * hp;
+            float *rs = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+            rs[0] = gr_; rs[H] = gz; rs[2 * H] = gn; rs[3 * H] = q;
         } else {
             float pre = xw[0] + rec[0];
             h = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
@@ -145,7 +167,7 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
 // ---------------------------------------------------------------------------------------------
 template <int CELL>
 __global__ void __launch_bounds__(RNN_THREADS) rnn_bwd_step_kernel(StepArgs p) {
-    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    constexpr int G = CellTraits<CELL>::G;
     __shared__ float red[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = blockIdx.y, mt = blockIdx.z;
@@ -161,7 +183,10 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_bwd_step_kernel(StepArgs p) {
         a_ok = a_ok && (s + 1 < steps);
         const int kq = 4 * (lane >> 4);
         const int t_next = a_ok ? row_time(dir, s + 1, steps) : 0;
-        const float *arow = p.dxw + (((size_t)t_next * B + (a_ok ? row : 0)) * 2 + dir) * GH + kq;
+        // the recurrent path back-propagates d(pre-activation of R h): dxw itself, except for
+        // the GRU whose candidate gate is scaled by r there (kept in a buffer of its own)
+        const float *dsrc = CELL == CTCASR_CELL_GRU ? p.drec : p.dxw;
+        const float *arow = dsrc + (((size_t)t_next * B + (a_ok ? row : 0)) * 2 + dir) * GH + kq;
         const float *brow = p.w + ((size_t)dir * H + u0 + (lane & 15)) * GH + kq;
         const int kbeg = wave * (GH / 4), kend = kbeg + GH / 4;
         // wave-uniform early out is not possible (rows differ), but a fully dead tile is cheap:
@@ -206,6 +231,23 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_bwd_step_kernel(StepArgs p) {
         dx[2 * H] = dc * gi * (1.f - gg * gg);
         dx[3 * H] = dh * tc * go * (1.f - go);
         *dcst = dc * gf;
+    } else if (CELL == CTCASR_CELL_GRU) {
+        const float *rs = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+        const float gr_ = rs[0], gz = rs[H], gn = rs[2 * H], q = rs[3 * H];
+        float hp = 0.f;
+        if (s > 0) {
+            const int tp = row_time(dir, s - 1, steps);
+            hp = p.y[((size_t)tp * B + b) * 2 * H + dir * H + unit];
+        }
+        float *carry = p.cbuf + ((size_t)dir * B + b) * H + unit;    // dh_{s+1} * z_{s+1}
+        const float dht = dh + ((s + 1 < steps) ? *carry : 0.f);
+        const float dpre_n = dht * (1.f - gz) * (1.f - gn * gn);
+        const float dpre_z = dht * (hp - gn) * gz * (1.f - gz);
+        const float dpre_r = dpre_n * q * gr_ * (1.f - gr_);
+        dx[0] = dpre_r; dx[H] = dpre_z; dx[2 * H] = dpre_n;
+        float *dr = p.drec + (((size_t)t * B + b) * 2 + dir) * GH + unit;
+        dr[0] = dpre_r; dr[H] = dpre_z; dr[2 * H] = dpre_n * gr_;
+        *carry = dht * gz;
     } else {
         const float h = p.y[((size_t)t * B + b) * 2 * H + dir * H + unit];
         dx[0] = CELL == CTCASR_CELL_RNN_RELU ? (h > 0.f ? dh : 0.f) : dh * (1.f - h * h);
@@ -242,6 +284,8 @@ static size_t rnn_state_bytes(int B, int H) {
 extern "C" size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0) return 0;
     if (cell == CTCASR_CELL_LSTM) return (size_t)T * B * 2 * 5 * H * sizeof(float);
+    // GRU: r, z, n, q = R_n h + b_Rn  [T,B,2,4H], then (backward) drec [T,B,2,3H]
+    if (cell == CTCASR_CELL_GRU) return (size_t)T * B * 2 * 7 * H * sizeof(float);
     return 256;   // plain RNN cells recompute their derivative from y
 }
 
@@ -257,7 +301,6 @@ extern "C" size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H) {
 static int rnn_check(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0) return CTCASR_ERR_BAD_ARGUMENT;
     if (cell_gates(cell) == 0) return CTCASR_ERR_BAD_ARGUMENT;
-    if (cell == CTCASR_CELL_GRU) return CTCASR_ERR_UNSUPPORTED;
     if (H % 64 != 0) return CTCASR_ERR_UNSUPPORTED;
     return CTCASR_OK;
 }
@@ -265,10 +308,10 @@ static int rnn_check(int cell, int T, int B, int H) {
 extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
                               const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
                               void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
-    (void)b_hh_n;
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
+    if (cell == CTCASR_CELL_GRU && !b_hh_n) return CTCASR_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
         return CTCASR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -278,19 +321,21 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, cons
     p.cells = p.gates + (size_t)T * B * 2 * 4 * H;
     p.hbuf = reinterpret_cast<float *>(workspace);
     p.cbuf = p.hbuf + (size_t)4 * B * H;
-    p.T = T; p.B = B; p.H = H;
+    p.T = T; p.B = B; p.H = H; p.b_hh = b_hh_n;
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
         return prnn_fwd(cell, xw, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), s);
     if (seq_len &&
         hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    const int G = cell_gates(cell);
-    dim3 grid(H / (32 / G), 2, (B + 15) / 16);
+    const int upb = cell == CTCASR_CELL_LSTM ? 8 : (cell == CTCASR_CELL_GRU ? 16 : 32);
+    dim3 grid(H / upb, 2, (B + 15) / 16);
     for (int step = 0; step < T; ++step) {
         p.step = step;
         if (cell == CTCASR_CELL_LSTM)
             rnn_fwd_step_kernel<CTCASR_CELL_LSTM><<<grid, RNN_THREADS, 0, s>>>(p);
+        else if (cell == CTCASR_CELL_GRU)
+            rnn_fwd_step_kernel<CTCASR_CELL_GRU><<<grid, RNN_THREADS, 0, s>>>(p);
         else if (cell == CTCASR_CELL_RNN_RELU)
             rnn_fwd_step_kernel<CTCASR_CELL_RNN_RELU><<<grid, RNN_THREADS, 0, s>>>(p);
         else
@@ -303,7 +348,7 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
                               const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                               const void *reserve, float *dxw, float *db_hh_n, void *workspace,
                               size_t workspace_bytes, ctcasr_stream_t stream) {
-    (void)b_hh_n; (void)db_hh_n;
+    (void)b_hh_n; (void)db_hh_n;   // the GRU bias gradient is the column sum of drec (caller)
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
@@ -318,17 +363,23 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
     p.hbuf = reinterpret_cast<float *>(workspace);
     p.cbuf = p.hbuf + (size_t)4 * B * H;
     p.T = T; p.B = B; p.H = H;
+    p.drec = p.gates + (size_t)T * B * 2 * 4 * H;      // GRU: behind r, z, n, q in the reserve
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
         return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), s);
     if (seq_len &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
+    if (cell == CTCASR_CELL_GRU && seq_len &&
+        hipMemsetAsync(p.drec, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
     dim3 grid(H / 16, 2, (B + 15) / 16);
     for (int step = T - 1; step >= 0; --step) {
         p.step = step;
         if (cell == CTCASR_CELL_LSTM)
             rnn_bwd_step_kernel<CTCASR_CELL_LSTM><<<grid, RNN_THREADS, 0, s>>>(p);
+        else if (cell == CTCASR_CELL_GRU)
+            rnn_bwd_step_kernel<CTCASR_CELL_GRU><<<grid, RNN_THREADS, 0, s>>>(p);
         else if (cell == CTCASR_CELL_RNN_RELU)
             rnn_bwd_step_kernel<CTCASR_CELL_RNN_RELU><<<grid, RNN_THREADS, 0, s>>>(p);
         else
@@ -351,4 +402,11 @@ extern "C" int ctcasr_rnn_poll_error(const void *workspace, size_t workspace_byt
     if (hipMemcpy(&err, word, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     return err ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
+}
+
+// GRU only: byte offset inside `reserve` of drec [T, B, 2, 3H] - the gradient w.r.t. the
+// recurrent pre-activations (dxw with the candidate gate scaled by r) that ctcasr_rnn_bwd leaves
+// there; dW_hh = sum_t drec_t^T h_{t-1} and db_hh = column sums of drec are GEMMs of it.
+extern "C" size_t ctcasr_rnn_gru_drec_offset(int T, int B, int H) {
+    return (size_t)T * B * 2 * 4 * H * sizeof(float);
 }

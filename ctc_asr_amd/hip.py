@@ -35,10 +35,12 @@ SIGNATURES = {
     'ctcasr_rnn_workspace_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_rnn_persistent_supported': (_c_int, [_c_int] * 4),
     'ctcasr_rnn_poll_error': (_c_int, [_c_p, _c_sz] + [_c_int] * 4 + [_c_p]),
+    'ctcasr_rnn_gru_drec_offset': (_c_sz, [_c_int] * 3),
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
     'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
+    'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
@@ -235,6 +237,14 @@ def rnn_poll_error(cell, workspace, num_steps, batch, hidden):
                                         hidden, _stream()), 'rnn persistent kernel')
 
 
+def rnn_gru_drec(reserve, num_steps, batch, hidden):
+    """View of drec f32[T, B, 2, 3H] inside a GRU reserve (valid after `rnn_bwd`)."""
+    start = load().ctcasr_rnn_gru_drec_offset(num_steps, batch, hidden)
+    count = num_steps * batch * 2 * 3 * hidden
+    return reserve[start:start + 4 * count].view(torch.float32).view(num_steps, batch, 2,
+                                                                      3 * hidden)
+
+
 def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None):
     """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace)."""
     num_steps, batch = xw.shape[0], xw.shape[1]
@@ -293,6 +303,15 @@ def bias_act_bwd(y, dy, cutoff, dropout_rate=0.0, dbias=None, dz=None):
                                       float(cutoff), float(dropout_rate), _stream()),
            'bias_act_bwd')
     return dz
+
+
+def dropout(src, rate, seed, out=None):
+    """out = src * mask(seed) / (1 - rate); same call (same seed) back-propagates a gradient."""
+    out = torch.empty_like(src) if out is None else out
+    _check(load().ctcasr_dropout(_dev(src, name='src'), _dev(out, name='out'), src.numel(),
+                                 float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+           'dropout')
+    return out
 
 
 def colsum_accumulate(dz, dbias):

@@ -329,25 +329,37 @@ class CTCModel:
 
         cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
         rnn_len = None if cfg.cudnn else seq_length
-        layer_in, layer_out, reserves = [], [], []
+        layer_in, layer_out, reserves, drop_seeds = [], [], [], []
         x = rnn_in.contiguous()
         workspace = None
+        rnn_rate = cfg.rnn_dropout_rate if training else 0.0
         for i in range(cfg.num_layers_rnn):
+            # dropout placement: cuDNN drops the input of layers 2..L (asr/model.py:203); the
+            # DropoutWrapper of the BasicRNNCell path drops every cell's input AND output
+            # (asr/util/tf_contrib.py:190-194)
+            seeds = [None, None]
+            if rnn_rate > 0.0 and (i > 0 or not cfg.cudnn):
+                seeds[0] = self._next_seed()
+                x = hip.dropout(x, rnn_rate, seeds[0])
             w_ih = p['rnn{}/w_ih'.format(i)].view(2 * gates * hidden, -1)
             xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
-            # both biases are plain additive terms for LSTM / RNN cells: fold them into xw
+            # biases that are plain additive terms are folded into xw (LSTM / RNN: both vectors;
+            # GRU: everything but the recurrent bias of the candidate gate)
             hip.bias_act_fwd(xw, self._rnn_bias(i), 0.0)
-            y, reserve, workspace = hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gates * hidden),
-                                                p['rnn{}/w_hh'.format(i)], rnn_len,
-                                                workspace=workspace)
+            y, reserve, workspace = hip.rnn_fwd(
+                cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
+                rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,
+                workspace=workspace)
             layer_in.append(x)
             layer_out.append(y)
             reserves.append(reserve)
             x = y
-            if training and cfg.rnn_dropout_rate > 0.0 and i + 1 < cfg.num_layers_rnn:
-                raise hip.CtcAsrError('rnn_dropout_rate > 0 is not implemented yet.')
+            if rnn_rate > 0.0 and not cfg.cudnn:
+                seeds[1] = self._next_seed()
+                x = hip.dropout(x, rnn_rate, seeds[1])
+            drop_seeds.append(seeds)
         acts.update(layer_in=layer_in, layer_out=layer_out, reserves=reserves, rnn_ws=workspace,
-                    rnn_len=rnn_len, t_out=t_out)
+                    rnn_len=rnn_len, t_out=t_out, drop_seeds=drop_seeds, rnn_rate=rnn_rate)
 
         rnn_flat = x.view(t_out * batch, 2 * hidden)
         dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training)
@@ -358,9 +370,16 @@ class CTCModel:
         return logits.view(t_out, batch, cfg.num_classes), seq_length
 
     def _rnn_bias(self, layer):
-        """b_ih + b_hh as one [2*G*H] vector (scratch, recomputed per call)."""
+        """The bias folded into the input projection, one [2*G*H] vector (scratch): b_ih + b_hh,
+        except for the GRU candidate gate whose recurrent bias sits inside r * (R_n h + b_Rn)."""
         p = self.arena.p
-        return (p['rnn{}/b_ih'.format(layer)] + p['rnn{}/b_hh'.format(layer)]).reshape(-1)
+        b_ih, b_hh = p['rnn{}/b_ih'.format(layer)], p['rnn{}/b_hh'.format(layer)]
+        if self.cfg.cell != 'gru':
+            return (b_ih + b_hh).reshape(-1)
+        hidden = self.cfg.num_units_rnn
+        folded = b_ih + b_hh
+        folded[:, 2 * hidden:] = b_ih[:, 2 * hidden:]
+        return folded.reshape(-1)
 
     # ------------------------------------------------------------------ loss
     @staticmethod
@@ -442,28 +461,41 @@ class CTCModel:
 
         # recurrent stack, top layer first
         need_dx_first = True
+        rnn_rate = acts['rnn_rate']
         for i in range(cfg.num_layers_rnn - 1, -1, -1):
             name = 'rnn{}'.format(i)
             x, y = acts['layer_in'][i], acts['layer_out'][i]
+            seeds = acts['drop_seeds'][i]
+            if seeds[1] is not None:
+                dy = hip.dropout(dy.contiguous(), rnn_rate, seeds[1])
             hip.transpose_batched(p[name + '/w_hh'], out=self._w_hh_t[i])
             dxw = hip.rnn_bwd(cell, dy.contiguous(), y, self._w_hh_t[i], acts['reserves'][i],
                               acts['rnn_len'], workspace=acts['rnn_ws'])
             dxw2d = dxw.view(rows, 2 * gates * hidden)
             torch.mm(dxw2d.t(), x.view(rows, -1), out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
             hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
-            g[name + '/b_hh'].copy_(g[name + '/b_ih'])
-            # dW_hh[d] = sum_t dgates_t^T h_{t-1}: one GEMM per direction over shifted views
+            # gradient w.r.t. the recurrent pre-activations: dxw itself, except for the GRU
+            drec = dxw
+            if cell == 'gru':
+                drec = hip.rnn_gru_drec(acts['reserves'][i], t_out, batch, hidden)
+                hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
+                                      g[name + '/b_hh'].view(-1))
+            else:
+                g[name + '/b_hh'].copy_(g[name + '/b_ih'])
+            # dW_hh[d] = sum_t drec_t^T h_{t-1}: one GEMM per direction over shifted views
             if t_out > 1:
                 gh = gates * hidden
-                torch.mm(dxw[1:, :, 0, :].reshape((t_out - 1) * batch, gh).t(),
+                torch.mm(drec[1:, :, 0, :].reshape((t_out - 1) * batch, gh).t(),
                          y[:-1, :, :hidden].reshape((t_out - 1) * batch, hidden),
                          out=g[name + '/w_hh'][0])
-                torch.mm(dxw[:-1, :, 1, :].reshape((t_out - 1) * batch, gh).t(),
+                torch.mm(drec[:-1, :, 1, :].reshape((t_out - 1) * batch, gh).t(),
                          y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
                          out=g[name + '/w_hh'][1])
             if i > 0 or need_dx_first:
                 w_ih = p[name + '/w_ih'].view(2 * gates * hidden, -1)
                 dy = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
+                if seeds[0] is not None:
+                    dy = hip.dropout(dy, rnn_rate, seeds[0])
             done(name)
 
         # front-end

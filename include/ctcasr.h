@@ -104,7 +104,8 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
  *   cell     CTCASR_CELL_*; G = gates per unit (LSTM 4: i,f,g,o; GRU 3: r,z,n; RNN 1)
  *   xw       [T, B, 2, G*H] pre-computed input projections incl. bias, both directions
  *   w_hh     [2, G*H, H] recurrent weights (cuDNN / torch layout, gate-major rows)
- *   b_hh_n   [2, H] recurrent bias of the GRU candidate gate (NULL for the other cells)
+ *   b_hh_n   GRU only (NULL otherwise): the recurrent bias b_hh [2, 3H]; its candidate-gate third
+ *            is applied inside r * (R_n h + b_Rn), the r / z thirds must be folded into xw
  *   seq_len  int32 [B] or NULL.  NULL = cuDNN semantics (all T steps for every row; the backward
  *            direction starts at t = T-1).  Non-NULL = dynamic_rnn semantics (steps
  *            t >= seq_len[b] emit zeros and keep the state; backward direction reversed per row).
@@ -113,7 +114,10 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
  *   workspace ctcasr_rnn_workspace_bytes() (state ping-pong, grid-barrier words)
  * bwd: dy [T,B,2H] -> dxw [T,B,2,G*H] (gradient w.r.t. xw, which is also what the weight
  * gradients are GEMMs of), w_hh_t = w_hh transposed to [2, H, G*H] (caller keeps it current;
- * ctcasr_transpose_batched does it), db_hh_n [2, H] (GRU only, accumulated +=). */
+ * ctcasr_transpose_batched does it).  GRU: the recurrent path differs from dxw in the candidate
+ * gate (scaled by r); that tensor, drec [T,B,2,3H], is left in `reserve` at
+ * ctcasr_rnn_gru_drec_offset(): dW_hh and db_hh are GEMM / column sums of it (db_hh_n: unused). */
+size_t ctcasr_rnn_gru_drec_offset(int T, int B, int H);
 size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H);
 size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H);
 int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
@@ -143,6 +147,12 @@ int ctcasr_bias_act_fwd(float *y, const float *bias, int64_t rows, int cols, flo
                         float dropout_rate, uint64_t seed, ctcasr_stream_t stream);
 int ctcasr_bias_act_bwd(const float *y, const float *dy, float *dz, float *dbias, int64_t rows,
                         int cols, float cutoff, float dropout_rate, ctcasr_stream_t stream);
+/* Inverted dropout without activation (cuDNN's inter-layer RNN dropout, DropoutWrapper of the
+ * BasicRNNCell path: asr/model.py:203, asr/util/tf_contrib.py:190-194): out = in * mask / keep,
+ * mask regenerated from (seed, element index) - call it on the gradient with the same seed for
+ * the backward pass.  in == out is allowed. */
+int ctcasr_dropout(const float *in, float *out, int64_t n, float dropout_rate, uint64_t seed,
+                   ctcasr_stream_t stream);
 /* dbias[c] += sum_r dz[r, c] on its own (layers without activation). */
 int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t rows, int cols,
                              ctcasr_stream_t stream);

@@ -99,7 +99,7 @@ def test_greedy_decode(hip, shape):
         assert (out[b, out_len[b]:] == 0).all()
 
 
-@pytest.mark.parametrize('cell', ['lstm', 'rnn_tanh', 'rnn_relu'])
+@pytest.mark.parametrize('cell', ['lstm', 'rnn_tanh', 'rnn_relu', 'gru'])
 @pytest.mark.parametrize('use_len', [False, True])
 @pytest.mark.parametrize('dims', [(9, 3, 64), (23, 18, 128), (12, 16, 1024), (7, 19, 1024),
                                   (5, 35, 1024)])  # last: B > 32 -> streaming at H=1024
@@ -118,6 +118,8 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
     dy = rng.normal(size=(num_steps, batch, 2 * hidden)).astype(np.float32)
 
     # reference: torch CPU autograd over the same recurrence written with plain ops (float64)
+    b_hh = (rng.normal(size=(2, gates * hidden)) * 0.3).astype(np.float32) if cell == 'gru' \
+        else None
     xw_t = torch.tensor(xw, dtype=torch.float64, requires_grad=True)
     w_t = torch.tensor(w_hh, dtype=torch.float64, requires_grad=True)
     ys = torch.zeros(num_steps, batch, 2 * hidden, dtype=torch.float64)
@@ -130,7 +132,16 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
             for s in range(steps):
                 t = s if d == 0 else steps - 1 - s
                 pre = xw_t[t, b, d] + w_t[d] @ h
-                if cell == 'lstm':
+                if cell == 'gru':
+                    rec = w_t[d] @ h
+                    xr, xz, xn = xw_t[t, b, d].split(hidden)
+                    rr, rz, rn = rec.split(hidden)
+                    r = torch.sigmoid(xr + rr)
+                    z = torch.sigmoid(xz + rz)
+                    n = torch.tanh(xn + r * (rn + torch.tensor(b_hh[d, 2 * hidden:],
+                                                               dtype=torch.float64)))
+                    h = (1 - z) * n + z * h
+                elif cell == 'lstm':
                     i, f, g, o = pre.split(hidden)
                     c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
                     h = torch.sigmoid(o) * torch.tanh(c)
@@ -148,7 +159,8 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
     (ys * torch.tensor(dy, dtype=torch.float64)).sum().backward()
 
     sl = _t(seq_len, torch.int32) if use_len else None
-    y, reserve, ws = hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl)
+    y, reserve, ws = hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl,
+                                 b_hh_n=_t(b_hh) if cell == 'gru' else None)
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert np.abs(y.cpu().numpy() - ys.detach().numpy()).max() < 2e-5
     w_hh_t = hip.transpose_batched(_t(w_hh))
@@ -156,8 +168,12 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
     dxw = hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, workspace=ws)
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert np.abs(dxw.cpu().numpy() - xw_t.grad.numpy()).max() < 1e-4
-    # weight gradient = sum_t dgates_t (x) h_{t-1}; check through the same dxw with torch on CPU
-    # (the product path forms it as one GEMM outside the time loop)
+    if cell == 'gru' and not use_len:
+        # dW_hh is a GEMM of drec (dxw with the candidate gate scaled by r) and h_{t-1}
+        drec = hip.rnn_gru_drec(reserve, num_steps, batch, hidden).cpu().double()
+        yd = ys.detach()
+        dw0 = drec[1:, :, 0].reshape(-1, 3 * hidden).t() @ yd[:-1, :, :hidden].reshape(-1, hidden)
+        assert np.abs(dw0.numpy() - w_t.grad[0].numpy()).max() < 1e-3
 
 
 def test_bias_act_and_colsum(hip):
@@ -281,3 +297,14 @@ def test_beam_search_known_answer(hip):
     assert out[0, :int(n[0])].tolist() == case['beam_wide']
     out, n, _ = hip.ctc_beam_decode(_t(logits), sl, 2)
     assert out[0, :int(n[0])].tolist() == case['beam_width_2']
+
+
+def test_dropout_kernel(hip):
+    x = torch.ones(100000, device=DEV) * 2.0
+    y = hip.dropout(x, 0.25, seed=77)
+    kept = (y != 0)
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    assert torch.allclose(y[kept], torch.tensor(2.0 / 0.75, device=DEV))
+    g = hip.dropout(torch.ones_like(x), 0.25, seed=77)       # backward: same mask
+    assert torch.equal(g != 0, kept)
+    assert not torch.equal(hip.dropout(x, 0.25, seed=78) != 0, kept)

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 CASES = {
     'ds2_lstm_3conv': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='lstm', cudnn=True),
     'ds2_lstm_2conv': dict(used_model='ds2', conv_filters=(4, 4), rnn_cell='lstm', cudnn=True),
+    'ds2_gru': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='gru', cudnn=True),
     'ds2_relu': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='rnn_relu', cudnn=True),
     'ds1_tanh_cudnn': dict(used_model='ds1', rnn_cell='rnn_tanh', cudnn=True),
     'ds1_basic_rnn': dict(used_model='ds1', rnn_cell='lstm', cudnn=False),   # C1 semantics
@@ -121,3 +122,19 @@ def test_greedy_decode_strings_match_oracle():
     from ctc_asr_amd.labels import decode
     assert list(plaintext) == [decode(r) for r in ref]
     assert summary.shape == (2, 4) and summary[1, 0] == 'n/a'
+
+
+@pytest.mark.parametrize('cudnn', [True, False])
+def test_rnn_dropout_runs_and_is_off_in_eval(cudnn):
+    cfg, flat, feats, flen, labels = _setup('ds2_lstm_2conv' if cudnn else 'ds1_basic_rnn')
+    cfg.rnn_dropout_rate = 0.2
+    model = CTCModel(cfg, 'cuda', params=flat)
+    e1, s1 = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=False)
+    e2, _ = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=False)
+    assert torch.equal(e1, e2)
+    t1, _ = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
+    assert not torch.equal(e1, t1)
+    loss = model.loss_fn(t1, s1, labels)
+    model.backward()
+    assert torch.isfinite(loss) and torch.isfinite(model.arena.grad).all()
+    assert float(model.arena.g['rnn0/w_ih'].abs().max()) > 0

@@ -47,26 +47,37 @@ class GradientReducer:
     tens of MB keep each ring step bandwidth- rather than latency-bound without delaying the
     first launch."""
 
-    def __init__(self, grad_arena, world_size, bucket_bytes=64 << 20, group=None):
+    def __init__(self, grad_arena, world_size, bucket_bytes=64 << 20, group=None,
+                 hold_until=None):
         self.grad, self.world, self.group = grad_arena, world_size, group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.pending_start = None
         self.pending_stop = None
         self.works = []
+        # Collective kernels must not be in flight while a persistent recurrence kernel starts:
+        # that kernel needs all of its workgroups co-resident (one per CU) and spins at grid
+        # barriers, so RCCL workgroups holding CUs could stall it past its spin limit.  With
+        # `hold_until` = name of the last recurrent layer of the backward pass, buckets are only
+        # launched from that layer's hook on - they then overlap the remaining weight-gradient
+        # GEMMs and the conv backward, which have no residency requirement.
+        self.hold_until = hold_until
+        self.released = hold_until is None
 
-    def hook(self, _layer, start, stop):
+    def hook(self, layer, start, stop):
         if self.world <= 1:
             return
+        if layer == self.hold_until:
+            self.released = True
         if self.pending_stop is None:
             self.pending_start, self.pending_stop = start, stop
         else:
             # backward visits layers from the end of the arena towards its start
-            if stop != self.pending_start:
+            if stop != self.pending_start:       # not adjacent: cannot merge into one view
                 self._flush()
                 self.pending_start, self.pending_stop = start, stop
             else:
                 self.pending_start = start
-        if self.pending_stop - self.pending_start >= self.bucket_elems:
+        if self.released and self.pending_stop - self.pending_start >= self.bucket_elems:
             self._flush()
 
     def _flush(self):
@@ -80,6 +91,7 @@ class GradientReducer:
     def finish(self):
         if self.world <= 1:
             return
+        self.released = self.hold_until is None
         self._flush()
         for work in self.works:
             work.wait()
@@ -98,7 +110,8 @@ class Trainer:
         self.beta1 = getattr(flags, 'adam_beta1', 0.9) if flags is not None else 0.9
         self.beta2 = getattr(flags, 'adam_beta2', 0.999) if flags is not None else 0.999
         self.eps = getattr(flags, 'adam_epsilon', 1e-8) if flags is not None else 1e-8
-        self.reducer = GradientReducer(self.model.arena.grad, world_size, bucket_bytes)
+        self.reducer = GradientReducer(self.model.arena.grad, world_size, bucket_bytes,
+                                       hold_until='rnn0')
         if world_size > 1:   # identical replicas: rank 0's initial parameters win
             dist.broadcast(self.model.arena.param, src=0)
 

@@ -39,6 +39,16 @@ def _reducer_worker(rank, world, port, out):
             reducer.hook(name, start, stop)
         reducer.finish()
         assert torch.all(arena == 3.0), bucket_bytes
+    # hold_until: nothing is launched before the named layer reports, then everything is
+    arena.fill_(float(rank + 1))
+    reducer = GradientReducer(arena, world, bucket_bytes=4, hold_until='a')
+    reducer.hook('c', 400, 1000)
+    reducer.hook('b', 100, 400)
+    assert not reducer.works and torch.all(arena == float(rank + 1))
+    reducer.hook('a', 0, 100)
+    assert len(reducer.works) == 1          # one merged bucket over the whole arena
+    reducer.finish()
+    assert torch.all(arena == 3.0)
     if rank == 0:
         out.put('ok')
     dist.destroy_process_group()

@@ -64,16 +64,18 @@ extern "C" int ctcasr_log_softmax_bwd(const float *y, const float *dy, float *dx
 // ------------------------------------------------------------------------------------------
 // CTC loss + gradient
 // ------------------------------------------------------------------------------------------
-#define CTC_THREADS 256
-#define CTC_MAX_PER_THREAD 4   // extended labels per thread: S = 2L+1 <= 1024
+#define CTC_THREADS 384
+#define CTC_MAX_PER_THREAD 3   // extended labels per thread: S = 2L+1 <= 1152
 
 // log(exp(a) + exp(b) + exp(c)); the state is kept in double so that |alpha| ~ 1e3 at T'=500
 // does not cost absolute precision, the exp/log of the O(1) differences run in float.
 __device__ __forceinline__ double lse3(double a, double b, double c) {
     double m = fmax(a, fmax(b, c));
     if (m == -INFINITY) return -INFINITY;
-    float s = expf((float)(a - m)) + expf((float)(b - m)) + expf((float)(c - m));
-    return m + (double)logf(s);
+    // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the arguments are O(1) differences and
+    // the sum is in [1, 3], so the absolute error per step stays ~1e-7
+    float s = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
+    return m + (double)__logf(s);
 }
 
 struct CtcLds {

@@ -14,3 +14,4 @@ extern "C" const char *ctcasr_error_string(int code) {
         default: return "unknown error";
     }
 }
+

@@ -24,6 +24,7 @@
 #include "common.h"
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define PRNN_THREADS 256
 #define PRNN_GROUPS 8
@@ -377,22 +378,30 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward.  Each workgroup owns UPB = 8 hidden units (output columns of dh_rec = dgates x R);
-// the K dimension is G*H (all gates of all units), split over the 4 waves: QW chunks each.
-// LDS: fragments [4*QW][32] float4 (lanes with (lane&15) >= 8 re-read the first 8 columns; the
-// duplicated MFMA columns are ignored), reduction scratch [4][MT*16][17], flag.
+// backward.  Each workgroup owns UPB hidden units (output columns of dh_rec = dgates x R); the K
+// dimension is G*H (all gates of all units), split over the 4 waves: QW chunks each.
+//   UPB = 8, REGW = 0  : 128 workgroups per direction = the whole chip; the slice (128 KB) is in
+//                        LDS as [4*QW][32] float4 - lanes with (lane & 15) >= 8 re-read the first
+//                        8 columns, the duplicated MFMA columns are ignored.
+//   UPB = 16, REGW = 32: 64 workgroups per direction = HALF the chip, full MFMA tiles; the 256 KB
+//                        slice is split between LDS (the first QW-REGW chunks of every wave) and
+//                        REGW float4 registers per lane.  Same time per step, but 128 CUs stay
+//                        free for the weight-gradient GEMMs of the layer above.
+// Reduction scratch [4][MT*16][17] follows the fragments.
 // ---------------------------------------------------------------------------------------------
-template <int CELL, int QW, int MT, int LB>
+template <int CELL, int QW, int MT, int LB, int UPB, int REGW>
 __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
-    constexpr int UPB = 8;
-    constexpr int Q = 4 * QW;
+    constexpr bool HALF_TILE = UPB == 8;
+    constexpr int SLOTS = HALF_TILE ? 32 : 64;      // float4 slots per chunk in LDS
+    constexpr int QL = QW - REGW;                   // chunks per wave kept in LDS
     constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
     constexpr int NB = QW / LB;          // load batches per wave (LB chunks in flight each)
     constexpr int CPG = QW / G;          // 16-float chunks per gate within a wave's unit range
+    static_assert(REGW == 0 || !HALF_TILE, "register-resident weights need full tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *frag = reinterpret_cast<float4 *>(smem);
-    float *red = reinterpret_cast<float *>(smem + (size_t)Q * 32 * sizeof(float4));
+    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * SLOTS * sizeof(float4));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = blockIdx.x / p.nwg, slice = blockIdx.x % p.nwg;
@@ -400,12 +409,18 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     const int H = p.H, B = p.B, T = p.T, GH = G * p.H;
     const int u0 = slice * UPB;
     const int kq = 4 * (lane >> 4);
-    const int half = (lane >> 4) * 8 + (lane & 7);   // fragment slot shared by lanes l, l+8
+    // fragment slot: lanes l and l+8 share one in the half-tile layout
+    const int half = HALF_TILE ? (lane >> 4) * 8 + (lane & 7) : lane;
 
-    if ((lane & 15) < 8) {
-        const float *wrow = p.w + ((size_t)dir * H + u0 + (lane & 7)) * GH + wave * (H / 4) + kq;
-        for (int i = 0; i < QW; ++i)
-            frag[(wave * QW + i) * 32 + half] = ldg4(wrow + (i / CPG) * H + (i % CPG) * 16);
+    float4 wreg[REGW > 0 ? REGW : 1];
+    if (!HALF_TILE || (lane & 15) < 8) {
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (lane & (UPB - 1))) * GH +
+                            wave * (H / 4) + kq;
+        for (int i = 0; i < QL; ++i)
+            frag[(wave * QL + i) * SLOTS + half] = ldg4(wrow + (i / CPG) * H + (i % CPG) * 16);
+#pragma unroll
+        for (int i = 0; i < REGW; ++i)
+            wreg[i] = ldg4(wrow + ((QL + i) / CPG) * H + ((QL + i) % CPG) * 16);
     }
     __syncthreads();
 
@@ -413,7 +428,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
     const size_t x_step = (size_t)2 * B * GH;
-    const int rot = slice & (QW - 1);     // de-synchronise the workgroups' walk over the chunks
+    // de-synchronise the workgroups' walk over the chunks (LDS-only variant; register-resident
+    // fragments need a static chunk -> register map)
+    const int rot = REGW == 0 ? (slice & (QW - 1)) : 0;
     float dc_state[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) dc_state[it] = 0.f;
@@ -507,7 +524,12 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                 // B fragments (LDS) are fetched one pair of chunks ahead of the MFMAs that use
                 // them: an exposed ds_read_b128 per pair costs as much as the pair's 8 MFMAs
                 auto bfrag = [&](int i) -> float4 {
-                    return frag[(wave * QW + ((nb * LB + i + rot) & (QW - 1))) * 32 + half];
+                    if constexpr (REGW == 0) {
+                        return frag[(wave * QL + ((nb * LB + i + rot) & (QW - 1))) * SLOTS + half];
+                    } else {
+                        const int c = nb * LB + i;          // compile-time after unrolling
+                        return c < QL ? frag[(wave * QL + c) * SLOTS + half] : wreg[c - QL];
+                    }
                 };
                 float4 cb0 = bfrag(0), cb1 = bfrag(1);
 #pragma unroll
@@ -630,6 +652,17 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
 
 size_t prnn_sync_bytes() { return sizeof(SyncWords); }
 
+int g_bwd_half_chip = 1;   // measured faster than the whole-chip variant even without overlap
+
+// Process-wide options.  "rnn_bwd_half_chip" (default 1): the persistent backward recurrence runs on 128
+// CUs (64 workgroups per direction, weights split between LDS and registers) so that GEMMs
+// issued on another stream can run beside it.
+extern "C" int ctcasr_set_option(const char *name, int value) {
+    if (!name) return CTCASR_ERR_BAD_ARGUMENT;
+    if (strcmp(name, "rnn_bwd_half_chip") == 0) { g_bwd_half_chip = value ? 1 : 0; return CTCASR_OK; }
+    return CTCASR_ERR_BAD_ARGUMENT;
+}
+
 size_t prnn_exchange_bytes(int T, int B, int H, int G) {
     return ctcasr_align_up((size_t)(T + 1) * 2 * B * G * H * sizeof(float), 256);
 }
@@ -665,21 +698,26 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
     p.sync = reinterpret_cast<SyncWords *>(sync);
-    p.T = T; p.B = B; p.H = H; p.nwg = H / 8;
+    const bool half_chip = g_bwd_half_chip != 0;
+    p.T = T; p.B = B; p.H = H; p.nwg = half_chip ? H / 16 : H / 8;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * 4 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
     constexpr int QW = 64;
-    const size_t frag = (size_t)4 * QW * 32 * 16;
-#define PRNN_BWD(MT_, LB_)                                                                    \
-    return launch_persistent(prnn_bwd_kernel<CTCASR_CELL_LSTM, QW, MT_, LB_>, p,               \
-                             frag + (size_t)4 * MT_ * 16 * 17 * 4 + 16,                        \
+#define PRNN_BWD(MT_, LB_, UPB_, REGW_)                                                       \
+    return launch_persistent(prnn_bwd_kernel<CTCASR_CELL_LSTM, QW, MT_, LB_, UPB_, REGW_>, p,   \
+                             (size_t)4 * (QW - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +           \
+                                 (size_t)4 * MT_ * 16 * 17 * 4 + 16,                           \
                              (size_t)2 * B * 4 * H, s)
     (void)cell;
-    if (mt == 1) { PRNN_BWD(1, 32); }
-    PRNN_BWD(2, 16);
+    if (half_chip) {
+        if (mt == 1) { PRNN_BWD(1, 16, 16, 32); }
+        PRNN_BWD(2, 8, 16, 32);
+    }
+    if (mt == 1) { PRNN_BWD(1, 32, 8, 0); }
+    PRNN_BWD(2, 16, 8, 0);
 #undef PRNN_BWD
 }
 

@@ -23,6 +23,7 @@ _c_f, _c_p, _c_sz = ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     'ctcasr_abi_version': (_c_int, []),
     'ctcasr_error_string': (ctypes.c_char_p, [_c_int]),
+    'ctcasr_set_option': (_c_int, [ctypes.c_char_p, _c_int]),
     'ctcasr_log_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_log_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_ctc_loss_workspace_bytes': (_c_sz, [_c_int] * 4),
@@ -140,6 +141,10 @@ def _workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------
+def set_option(name, value):
+    _check(load().ctcasr_set_option(name.encode(), int(value)), 'set_option')
+
+
 def log_softmax_fwd(x, out=None):
     rows, classes = x.numel() // x.shape[-1], x.shape[-1]
     out = torch.empty_like(x) if out is None else out

@@ -262,6 +262,10 @@ class CTCModel:
         self.arena = ParamArena(cfg, self.device)
         self.arena.load(params if params is not None else init_params(cfg, seed))
         self.step_count = 0
+        # weight-gradient GEMMs run on a low-priority side stream so that they fill the half of
+        # the chip the latency-bound backward recurrence of the layer below leaves free
+        self.overlap_wgrad = True
+        self._side_stream = None
         self.dropout_seed = int(seed) * 0x9E3779B1 + 1
         self._acts = None
         self._w_hh_t = [torch.empty((2, cfg.num_units_rnn, GATES[cfg.cell] * cfg.num_units_rnn),
@@ -446,18 +450,42 @@ class CTCModel:
         hidden, gates, cell = cfg.num_units_rnn, GATES[cfg.cell], cfg.cell
         rows = t_out * batch
         dlogits = acts['dlogits'].view(rows, cfg.num_classes)
+        main = torch.cuda.current_stream(self.device)
+        side = main
+        if self.overlap_wgrad:
+            if self._side_stream is None:
+                # (a CU-masked side stream was tried and measured slower: whatever it has left
+                # when the recurrence ends keeps running on half of an otherwise idle chip)
+                low = max(torch.cuda.Stream.priority_range())      # numerically largest = lowest
+                self._side_stream = torch.cuda.Stream(self.device, priority=low)
+            side = self._side_stream
+        deferred = []          # layer hooks that must wait for the side stream
+
+        def on_side(tensors, fn):
+            """Run ``fn`` (weight-gradient work that nothing downstream in this backward pass
+            reads) on the side stream once everything enqueued on the main stream so far is done."""
+            if side is main:
+                fn()
+                return
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                fn()
+            for tensor in tensors:       # blocks stay reserved until the side stream is done
+                tensor.record_stream(side)
 
         # logits layer
         torch.mm(acts['dense4'].t(), dlogits, out=g['logits/kernel'])
         hip.colsum_accumulate(dlogits, g['logits/bias'])
         d_dense4 = torch.mm(dlogits, p['logits/kernel'].t())
         done('logits')
-        # dense4
+        # dense4: dz and the data gradient are on the critical path, the kernel gradient is not
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
-        torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel'])
         dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
-        done('dense4')
+        on_side([dz], lambda: torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel']))
+        deferred.append('dense4')
 
         # recurrent stack, top layer first
         need_dx_first = True
@@ -472,30 +500,43 @@ class CTCModel:
             dxw = hip.rnn_bwd(cell, dy.contiguous(), y, self._w_hh_t[i], acts['reserves'][i],
                               acts['rnn_len'], workspace=acts['rnn_ws'])
             dxw2d = dxw.view(rows, 2 * gates * hidden)
-            torch.mm(dxw2d.t(), x.view(rows, -1), out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
-            hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
-            # gradient w.r.t. the recurrent pre-activations: dxw itself, except for the GRU
-            drec = dxw
-            if cell == 'gru':
-                drec = hip.rnn_gru_drec(acts['reserves'][i], t_out, batch, hidden)
-                hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
-                                      g[name + '/b_hh'].view(-1))
-            else:
-                g[name + '/b_hh'].copy_(g[name + '/b_ih'])
-            # dW_hh[d] = sum_t drec_t^T h_{t-1}: one GEMM per direction over shifted views
-            if t_out > 1:
-                gh = gates * hidden
-                torch.mm(drec[1:, :, 0, :].reshape((t_out - 1) * batch, gh).t(),
-                         y[:-1, :, :hidden].reshape((t_out - 1) * batch, hidden),
-                         out=g[name + '/w_hh'][0])
-                torch.mm(drec[:-1, :, 1, :].reshape((t_out - 1) * batch, gh).t(),
-                         y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
-                         out=g[name + '/w_hh'][1])
+            # critical path: the gradient w.r.t. this layer's input feeds the layer below
+            dy_below = None
             if i > 0 or need_dx_first:
                 w_ih = p[name + '/w_ih'].view(2 * gates * hidden, -1)
-                dy = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
+                dy_below = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
                 if seeds[0] is not None:
-                    dy = hip.dropout(dy, rnn_rate, seeds[0])
+                    dy_below = hip.dropout(dy_below, rnn_rate, seeds[0])
+
+            def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i):
+                torch.mm(dxw2d.t(), x.view(rows, -1),
+                         out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
+                hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
+                # gradient w.r.t. the recurrent pre-activations: dxw itself, except for the GRU
+                drec = dxw
+                if cell == 'gru':
+                    drec = hip.rnn_gru_drec(acts['reserves'][i], t_out, batch, hidden)
+                    hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
+                                          g[name + '/b_hh'].view(-1))
+                else:
+                    g[name + '/b_hh'].copy_(g[name + '/b_ih'])
+                # dW_hh[d] = sum_t drec_t^T h_{t-1}: one GEMM per direction over shifted views
+                if t_out > 1:
+                    gh = gates * hidden
+                    torch.mm(drec[1:, :, 0, :].reshape((t_out - 1) * batch, gh).t(),
+                             y[:-1, :, :hidden].reshape((t_out - 1) * batch, hidden),
+                             out=g[name + '/w_hh'][0])
+                    torch.mm(drec[:-1, :, 1, :].reshape((t_out - 1) * batch, gh).t(),
+                             y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
+                             out=g[name + '/w_hh'][1])
+
+            on_side([dxw], weight_grads)
+            deferred.append(name)
+            if dy_below is not None:
+                dy = dy_below
+        if side is not main:
+            main.wait_stream(side)
+        for name in deferred:
             done(name)
 
         # front-end

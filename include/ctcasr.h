@@ -49,6 +49,10 @@ enum {
 typedef void *ctcasr_stream_t;
 
 int ctcasr_abi_version(void);
+/* Process-wide switches.  "rnn_bwd_half_chip" (0/1, default 1): run the persistent backward
+ * recurrence on 128 of the 256 CUs (weights split between LDS and registers) so that GEMMs
+ * launched on another stream can overlap it; 0 selects the whole-chip variant. */
+int ctcasr_set_option(const char *name, int value);
 const char *ctcasr_error_string(int code);
 
 /* ---- K8: (log-)softmax over the class axis ------------------------------------------------

@@ -17,6 +17,8 @@ from ctc_asr_amd import hip  # noqa: E402
 def main():
     T, B, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (500, 16, 1024)
     hip.load()
+    if os.environ.get('CTCASR_FULL'):      # backward recurrence on the whole chip (default: half)
+        hip.set_option('rnn_bwd_half_chip', 0)
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, 4 * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, 4 * H, H, device='cuda', generator=g) / np.sqrt(H)

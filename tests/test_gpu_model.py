@@ -138,3 +138,66 @@ def test_rnn_dropout_runs_and_is_off_in_eval(cudnn):
     model.backward()
     assert torch.isfinite(loss) and torch.isfinite(model.arena.grad).all()
     assert float(model.arena.g['rnn0/w_ih'].abs().max()) > 0
+
+
+def test_full_size_c2_shape_logits_loss_and_decode():
+    """BASELINE configs[1] shape (DS2 2-conv + 2xBiLSTM-1024, 10 s = 999 frames -> T' = 500) at
+    batch 2: logits / loss against the float64 torch restatement, greedy strings identical.
+    Exercises the persistent recurrence kernels over all 500 steps."""
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=2, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0)
+    rng = np.random.default_rng(11)
+    flat = init_params(cfg, 11)
+    feats = rng.normal(size=(2, 999, 80)).astype(np.float32)
+    flen = np.array([999, 999], dtype=np.int32)
+    labels = [list(rng.integers(1, 28, size=150)), list(rng.integers(1, 28, size=150))]
+    model = CTCModel(cfg, 'cuda', params=flat)
+    logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
+    loss = model.loss_fn(logits, seq_len, labels)
+    model.backward()
+    ref = torch_ref.TorchRefModel(to_oracle_layout(flat, cfg), 'ds2', 'lstm', True,
+                                  dtype=torch.float64)
+    with torch.no_grad():
+        t_logits, t_len = ref(torch.tensor(feats, dtype=torch.float64), flen)
+        t_loss, _ = ref.loss(t_logits, t_len, labels)
+    assert logits.shape == (500, 2, 29) and (seq_len.cpu().numpy() == 500).all()
+    assert np.abs(logits.cpu().numpy() - t_logits.numpy()).max() < 1e-3
+    assert abs(float(loss) - float(t_loss)) < 1e-3 * max(1.0, abs(float(t_loss)))
+    decoded, _, _ = model.decode_fn(logits, seq_len, None, greedy=True)
+    assert decoded == octc.greedy_decode(t_logits.numpy(), [500, 500])
+    assert torch.isfinite(model.arena.grad).all()
+    from ctc_asr_amd import hip
+    hip.rnn_poll_error('lstm', model._acts['rnn_ws'], 500, 2, 1024)
+
+
+def test_full_size_c1_shape_with_gradients():
+    """BASELINE configs[0]: DS1, 1 x BiRNN-256 (tanh BasicRNNCell, length aware), batch 2, 3 s
+    = 299 frames; the reference's CPU plumbing config."""
+    cfg = ModelConfig(used_model='ds1', num_units_dense=256, num_layers_rnn=1, num_units_rnn=256,
+                      rnn_cell='rnn_tanh', cudnn=False, dense_dropout_rate=0.0)
+    rng = np.random.default_rng(12)
+    flat = init_params(cfg, 12)
+    feats = rng.normal(size=(2, 299, 80)).astype(np.float32)
+    flen = np.array([299, 251], dtype=np.int32)
+    feats[1, 251:] = 0.0
+    labels = [list(rng.integers(1, 28, size=45)), list(rng.integers(1, 28, size=30))]
+    model = CTCModel(cfg, 'cuda', params=flat)
+    logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
+    loss = model.loss_fn(logits, seq_len, labels)
+    model.backward()
+    ref = torch_ref.TorchRefModel(to_oracle_layout(flat, cfg), 'ds1', 'rnn_tanh', False,
+                                  dtype=torch.float64)
+    t_logits, t_len = ref(torch.tensor(feats, dtype=torch.float64), flen)
+    t_loss, _ = ref.loss(t_logits, t_len, labels)
+    t_loss.backward()
+    assert (seq_len.cpu().numpy() == flen).all()
+    assert np.abs(logits.cpu().numpy() - t_logits.detach().numpy()).max() < 1e-3
+    assert abs(float(loss) - float(t_loss.detach())) < 1e-3
+    got = model.arena.export('grad')
+    ref_g = ref.grads_in_shared_layout()
+    for name, ref_t in (('rnn0/w_hh', ref_g['rnn'][0]['w_hh']),
+                        ('dense0/kernel', ref_g['dense'][0][0]),
+                        ('logits/kernel', ref_g['logits'][0])):
+        err = np.abs(got[name] - ref_t.numpy()).max()
+        assert err < 1e-3 * max(1.0, np.abs(ref_t.numpy()).max()), (name, err)

@@ -15,6 +15,7 @@ kernels behind ``include/ctcasr.h``.
 """
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -255,6 +256,10 @@ class CTCModel:
 
     def __init__(self, cfg, device='cuda', seed=0, params=None):
         hip.load()
+        # let MIOpen time its candidate convolution kernels once per shape (the heuristic pick is
+        # ~35 % slower for the 11x21 stride-(1,2) layers); CTCASR_CONV_AUTOTUNE=0 turns it off,
+        # e.g. for a first epoch over hundreds of distinct padded lengths
+        torch.backends.cudnn.benchmark = os.environ.get('CTCASR_CONV_AUTOTUNE', '1') != '0'
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -297,19 +302,24 @@ class CTCModel:
         if cfg.used_model == 'ds2':
             # conv dropout: the reference never forwards `training` to conv_layers, so a
             # non-zero conv_dropout_rate fires in evaluation too (asr/model.py:161).
-            x = sequences.unsqueeze(1)                       # NCHW [B, 1, T, F]
+            # logical NCHW [B, 1, T, F], physically NHWC (channels_last) like the reference: the
+            # implicit-GEMM convolution kernels are NHWC-native, no transposes around them
+            x = sequences.unsqueeze(1).contiguous(memory_format=torch.channels_last)
             conv_in, conv_out, pads = [], [], []
             for i in range(len(cfg.conv_filters)):
                 k_t, k_f = CONV_KERNEL_SIZES[i]
                 s_t, s_f = CONV_STRIDES[i]
                 _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
-                xp = torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1))
-                y = torch.ops.aten.convolution(xp, p['conv{}/kernel'.format(i)],
+                xp = torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1)) \
+                    .contiguous(memory_format=torch.channels_last)
+                y = torch.ops.aten.convolution(xp, self._conv_kernel_cl(i),
                                                p['conv{}/bias'.format(i)], [s_t, s_f], [0, 0],
                                                [1, 1], False, [0, 0], 1)
-                hip.bias_act_fwd(y, None, cfg.relu_cutoff, cfg.conv_dropout_rate,
-                                 self._next_seed())
+                y = y.contiguous(memory_format=torch.channels_last)
+                # elementwise epilogue on the NHWC storage ([B, T, F, C] view of the same memory)
+                hip.bias_act_fwd(y.permute(0, 2, 3, 1), None, cfg.relu_cutoff,
+                                 cfg.conv_dropout_rate, self._next_seed())
                 conv_in.append(xp)
                 conv_out.append(y)
                 pads.append((pt0, pt1, pf0, pf1))
@@ -372,6 +382,11 @@ class CTCModel:
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
         self._acts = acts
         return logits.view(t_out, batch, cfg.num_classes), seq_length
+
+    def _conv_kernel_cl(self, layer):
+        """Conv kernel [Cout, Cin, kt, kf] in channels_last memory (scratch copy per call)."""
+        return self.arena.p['conv{}/kernel'.format(layer)] \
+            .contiguous(memory_format=torch.channels_last)
 
     def _rnn_bias(self, layer):
         """The bias folded into the input projection, one [2*G*H] vector (scratch): b_ih + b_hh,
@@ -545,20 +560,24 @@ class CTCModel:
             last = conv_out[-1]
             b_, c_, tt, ff = last.shape
             # [T', B, F'*C] -> NCHW [B, C, T', F']
-            dact = dy.view(tt, b_, ff, c_).permute(1, 3, 0, 2).contiguous()
+            # NHWC storage [B, T', F', C] for the gradient as well
+            dact = dy.view(tt, b_, ff, c_).permute(1, 0, 2, 3).contiguous()
             for i in range(len(cfg.conv_filters) - 1, -1, -1):
                 name = 'conv{}'.format(i)
-                dz = hip.bias_act_bwd(conv_out[i], dact, cfg.relu_cutoff, cfg.conv_dropout_rate)
+                dz = hip.bias_act_bwd(conv_out[i].permute(0, 2, 3, 1), dact, cfg.relu_cutoff,
+                                      cfg.conv_dropout_rate)
+                dz = dz.permute(0, 3, 1, 2)        # logical NCHW view of the NHWC storage
                 xp = acts['conv_in'][i]
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 dxp, dw, db = torch.ops.aten.convolution_backward(
-                    dz, xp, p[name + '/kernel'], [p[name + '/bias'].shape[0]],
+                    dz, xp, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
                     list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
                     [i > 0, True, True])
                 g[name + '/kernel'].copy_(dw)
                 g[name + '/bias'].copy_(db)
                 if i > 0:
-                    dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1].contiguous()
+                    dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1] \
+                        .permute(0, 2, 3, 1).contiguous()
                 done(name)
         else:
             dact = dy.reshape(rows, -1)

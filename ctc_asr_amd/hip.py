@@ -43,6 +43,7 @@ SIGNATURES = {
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
+    'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
@@ -325,6 +326,11 @@ def colsum_accumulate(dz, dbias):
                                            dz.numel() // cols, cols, _stream()),
            'colsum_accumulate')
     return dbias
+
+
+def stream_delay(microseconds):
+    """Idle the current stream for ``microseconds`` (a one-lane spacer kernel)."""
+    _check(load().ctcasr_stream_delay(int(microseconds), _stream()), 'stream_delay')
 
 
 def transpose_batched(src, out=None):

@@ -270,6 +270,7 @@ class CTCModel:
         # weight-gradient GEMMs run on a low-priority side stream so that they fill the half of
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
+        self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
         self._side_stream = None
         self.dropout_seed = int(seed) * 0x9E3779B1 + 1
         self._acts = None
@@ -476,9 +477,12 @@ class CTCModel:
             side = self._side_stream
         deferred = []          # layer hooks that must wait for the side stream
 
-        def on_side(tensors, fn):
+        def on_side(tensors, fn, head_start_us=0):
             """Run ``fn`` (weight-gradient work that nothing downstream in this backward pass
-            reads) on the side stream once everything enqueued on the main stream so far is done."""
+            reads) on the side stream once everything enqueued on the main stream so far is done.
+            ``head_start_us`` idles the side stream first so that a persistent recurrence kernel
+            enqueued next on the main stream claims its 128 CUs before these GEMMs fill the chip
+            (otherwise it starts only when the first GEMM has drained)."""
             if side is main:
                 fn()
                 return
@@ -486,6 +490,8 @@ class CTCModel:
             ready.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
+                if head_start_us:
+                    hip.stream_delay(head_start_us)
                 fn()
             for tensor in tensors:       # blocks stay reserved until the side stream is done
                 tensor.record_stream(side)
@@ -499,7 +505,8 @@ class CTCModel:
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
         dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
-        on_side([dz], lambda: torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel']))
+        on_side([dz], lambda: torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel']),
+                head_start_us=self.side_head_start_us)
         deferred.append('dense4')
 
         # recurrent stack, top layer first
@@ -545,7 +552,7 @@ class CTCModel:
                              y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
                              out=g[name + '/w_hh'][1])
 
-            on_side([dxw], weight_grads)
+            on_side([dxw], weight_grads, head_start_us=self.side_head_start_us if i > 0 else 0)
             deferred.append(name)
             if dy_below is not None:
                 dy = dy_below

@@ -161,6 +161,10 @@ int ctcasr_dropout(const float *in, float *out, int64_t n, float dropout_rate, u
 int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t rows, int cols,
                              ctcasr_stream_t stream);
 
+/* Enqueues a one-lane kernel that idles for `microseconds` (<= 100 ms): used to let the persistent
+ * recurrence of the main stream claim its half of the chip before side-stream GEMMs start. */
+int ctcasr_stream_delay(int microseconds, ctcasr_stream_t stream);
+
 /* out[n][c][r] = in[n][r][c] for n < batch (weight re-layouts, e.g. w_hh -> w_hh_t). */
 int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,
                              ctcasr_stream_t stream);

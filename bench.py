@@ -45,8 +45,8 @@ WORKLOADS = {
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip table
 # (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch, measured with rocprofv3 PMC passes
-PMC_TRAFFIC = {('c2', 'rnn_bwd'): int((1813553 + 259992) * 1024),
-               ('c2', 'rnn_fwd'): int((794048 + 387992) * 1024)}
+PMC_TRAFFIC = {('c2', 'rnn_bwd'): int((1426952 + 513996) * 1024),
+               ('c2', 'rnn_fwd'): int((793424 + 451992) * 1024)}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -244,7 +244,7 @@ def main():
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-                    # passes of this workload (profiles/r01_c2_persistent_rnn_kernel_trace_and_pmc.md)
+                    # passes of this workload (profiles/r01_final_c2_kernel_trace_and_pmc.md)
                     'traffic': PMC_TRAFFIC.get((args.workload, dom)),
                     'avg_launch_us': round(avg_s * 1e6, 1), 'launches': calls,
                     'algorithmic_flops_per_launch': flops_per_step * t_out,

@@ -643,8 +643,12 @@ int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_flo
 // Whether the LDS-resident kernels cover this shape (LSTM, H = 1024, B <= 32 for now; every
 // other shape takes the streaming kernels of rnn_step.hip).
 extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
-    // B <= 32: two batch tiles keep the reduction scratch next to the 128 KB weight slice
-    if (cell != CTCASR_CELL_LSTM || H != 1024 || B < 1 || B > 32 || T < 1) return 0;
+    // shapes whose weight slice is 128 KB per CU: LSTM H=1024 (BASELINE configs) and the plain
+    // ReLU / tanh RNN at H=2048 (the reference's default model).  B <= 32: two batch tiles keep
+    // the reduction scratch next to the weight slice.
+    const bool lstm = cell == CTCASR_CELL_LSTM && H == 1024;
+    const bool rnn = (cell == CTCASR_CELL_RNN_RELU || cell == CTCASR_CELL_RNN_TANH) && H == 2048;
+    if (!(lstm || rnn) || B < 1 || B > 32 || T < 1) return 0;
     const char *mode = getenv("CTCASR_RNN_MODE");   // "stream" forces the per-step kernels
     if (mode && mode[0] == 's') return 0;
     return device_cu_count() >= 256 ? 1 : 0;
@@ -673,20 +677,28 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
     p.sync = reinterpret_cast<SyncWords *>(sync);
-    p.T = T; p.B = B; p.H = H; p.nwg = 4 * H / 32;
+    p.T = T; p.B = B; p.H = H;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
-    constexpr int NT = 2, QW = 16;
-    const size_t frag = (size_t)NT * 4 * QW * 64 * 16;
-#define PRNN_FWD(MT_)                                                                         \
-    return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, NT, QW, MT_>, p,                \
-                             frag + (size_t)4 * NT * MT_ * 16 * 17 * 4 + 16,                   \
+    // 128 workgroups per direction, 16 * NT gate columns each, QW = H / 64 K chunks per wave
+#define PRNN_FWD(CELL_, NT_, QW_, MT_)                                                        \
+    return launch_persistent(prnn_fwd_kernel<CELL_, NT_, QW_, MT_>, p,                         \
+                             (size_t)NT_ * 4 * QW_ * 64 * 16 +                                 \
+                                 (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 16,                     \
                              (size_t)2 * B * H, s)
-    (void)cell;
-    if (mt == 1) { PRNN_FWD(1); }
-    PRNN_FWD(2);
+    p.nwg = 128;
+    if (cell == CTCASR_CELL_LSTM) {
+        if (mt == 1) { PRNN_FWD(CTCASR_CELL_LSTM, 2, 16, 1); }
+        PRNN_FWD(CTCASR_CELL_LSTM, 2, 16, 2);
+    }
+    if (cell == CTCASR_CELL_RNN_RELU) {
+        if (mt == 1) { PRNN_FWD(CTCASR_CELL_RNN_RELU, 1, 32, 1); }
+        PRNN_FWD(CTCASR_CELL_RNN_RELU, 1, 32, 2);
+    }
+    if (mt == 1) { PRNN_FWD(CTCASR_CELL_RNN_TANH, 1, 32, 1); }
+    PRNN_FWD(CTCASR_CELL_RNN_TANH, 1, 32, 2);
 #undef PRNN_FWD
 }
 
@@ -698,26 +710,34 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
     p.sync = reinterpret_cast<SyncWords *>(sync);
-    const bool half_chip = g_bwd_half_chip != 0;
-    p.T = T; p.B = B; p.H = H; p.nwg = half_chip ? H / 16 : H / 8;
+    const bool half_chip = g_bwd_half_chip != 0 && cell == CTCASR_CELL_LSTM;
+    p.T = T; p.B = B; p.H = H;
+    p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : H / 16;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * 4 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
-    constexpr int QW = 64;
-#define PRNN_BWD(MT_, LB_, UPB_, REGW_)                                                       \
-    return launch_persistent(prnn_bwd_kernel<CTCASR_CELL_LSTM, QW, MT_, LB_, UPB_, REGW_>, p,   \
-                             (size_t)4 * (QW - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +           \
+#define PRNN_BWD(CELL_, QW_, MT_, LB_, UPB_, REGW_, G_)                                        \
+    return launch_persistent(prnn_bwd_kernel<CELL_, QW_, MT_, LB_, UPB_, REGW_>, p,             \
+                             (size_t)4 * (QW_ - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +          \
                                  (size_t)4 * MT_ * 16 * 17 * 4 + 16,                           \
-                             (size_t)2 * B * 4 * H, s)
-    (void)cell;
-    if (half_chip) {
-        if (mt == 1) { PRNN_BWD(1, 16, 16, 32); }
-        PRNN_BWD(2, 8, 16, 32);
+                             (size_t)2 * B * G_ * H, s)
+    if (cell == CTCASR_CELL_LSTM) {
+        if (half_chip) {
+            if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 16, 16, 32, 4); }
+            PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 8, 16, 32, 4);
+        }
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 32, 8, 0, 4); }
+        PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 16, 8, 0, 4);
     }
-    if (mt == 1) { PRNN_BWD(1, 32, 8, 0); }
-    PRNN_BWD(2, 16, 8, 0);
+    // plain RNN, H = 2048: 16 units x 2048 x 4 B = 128 KB per workgroup, 128 per direction
+    if (cell == CTCASR_CELL_RNN_RELU) {
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 32, 1, 32, 16, 0, 1); }
+        PRNN_BWD(CTCASR_CELL_RNN_RELU, 32, 2, 16, 16, 0, 1);
+    }
+    if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 32, 1, 32, 16, 0, 1); }
+    PRNN_BWD(CTCASR_CELL_RNN_TANH, 32, 2, 16, 16, 0, 1);
 #undef PRNN_BWD
 }
 

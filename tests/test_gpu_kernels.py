@@ -102,11 +102,14 @@ def test_greedy_decode(hip, shape):
 @pytest.mark.parametrize('cell', ['lstm', 'rnn_tanh', 'rnn_relu', 'gru'])
 @pytest.mark.parametrize('use_len', [False, True])
 @pytest.mark.parametrize('dims', [(9, 3, 64), (23, 18, 128), (12, 16, 1024), (7, 19, 1024),
-                                  (5, 35, 1024)])  # last: B > 32 -> streaming at H=1024
+                                  (5, 35, 1024),   # B > 32 -> streaming at H=1024
+                                  (8, 16, 2048), (5, 21, 2048)])
 def test_rnn_fwd_bwd(hip, cell, use_len, dims):
     num_steps, batch, hidden = dims
     if hidden == 1024 and cell != 'lstm':
         pytest.skip('H=1024 cases exercise the persistent LSTM kernels')
+    if hidden == 2048 and cell not in ('rnn_relu', 'rnn_tanh'):
+        pytest.skip('H=2048 cases exercise the persistent plain-RNN kernels')
     gates = onn.GATES[cell]
     rng = np.random.default_rng(5)
     xw = (rng.normal(size=(num_steps, batch, 2, gates * hidden)) * 0.5).astype(np.float32)

@@ -16,19 +16,21 @@ from ctc_asr_amd import hip  # noqa: E402
 
 def main():
     T, B, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (500, 16, 1024)
+    cell = sys.argv[4] if len(sys.argv) >= 5 else 'lstm'
+    G = hip.CELL_GATES[cell]
     hip.load()
     if os.environ.get('CTCASR_FULL'):      # backward recurrence on the whole chip (default: half)
         hip.set_option('rnn_bwd_half_chip', 0)
     g = torch.Generator(device='cuda').manual_seed(0)
-    xw = torch.randn(T, B, 2, 4 * H, device='cuda', generator=g) * 0.5
-    w = torch.randn(2, 4 * H, H, device='cuda', generator=g) / np.sqrt(H)
+    xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
+    w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
     dy = torch.randn(T, B, 2 * H, device='cuda', generator=g)
     wt = hip.transpose_batched(w)
-    y, reserve, ws = hip.rnn_fwd('lstm', xw, w)
-    dxw = hip.rnn_bwd('lstm', dy, y, wt, reserve, workspace=ws)
-    hip.rnn_poll_error('lstm', ws, T, B, H)
-    for name, fn in (('fwd', lambda: hip.rnn_fwd('lstm', xw, w, y=y, reserve=reserve, workspace=ws)),
-                     ('bwd', lambda: hip.rnn_bwd('lstm', dy, y, wt, reserve, dxw=dxw, workspace=ws))):
+    y, reserve, ws = hip.rnn_fwd(cell, xw, w)
+    dxw = hip.rnn_bwd(cell, dy, y, wt, reserve, workspace=ws)
+    hip.rnn_poll_error(cell, ws, T, B, H)
+    for name, fn in (('fwd', lambda: hip.rnn_fwd(cell, xw, w, y=y, reserve=reserve, workspace=ws)),
+                     ('bwd', lambda: hip.rnn_bwd(cell, dy, y, wt, reserve, dxw=dxw, workspace=ws))):
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         start.record()
@@ -45,7 +47,7 @@ def main():
             labels = ['wait', 'loads+mfma', 'reduce+gates+publish', 'drain+arrive']
             print('  wg0 phases (us/step): ' + ', '.join(
                 '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
-    hip.rnn_poll_error('lstm', ws, T, B, H)
+    hip.rnn_poll_error(cell, ws, T, B, H)
     # checksum for A/B comparisons between variants
     print('checksum y {:.6f} dxw {:.6f}'.format(float(y.double().abs().sum()),
                                                  float(dxw.double().abs().sum())))

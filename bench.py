@@ -215,6 +215,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     CTCModel.check_status(model.last_status)
+    # a persistent recurrence launch that gave up at a grid barrier would have produced garbage
+    hip.rnn_poll_error(cfg.cell, model._acts['rnn_ws'], cfg.output_time(frames), batch, hidden)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -137,78 +137,78 @@ FLAGS = FlagValues()
 
 # Directories (defaults are outside of the project directory, asr/params.py:13-27).
 FLAGS.define('string', 'train_dir', os.path.join(BASE_PATH, '../ctc-asr-checkpoints/3c4r2d-rnn'),
-             'Directory where to write event logs and checkpoints.')
+             'Checkpoint / log directory (resume source unless --delete).')
 _CORPUS_DIR = os.path.join(BASE_PATH, '../speech-corpus')
 FLAGS.define('string', 'corpus_dir', os.path.join(_CORPUS_DIR, 'corpus'),
-             'Directory that holds the corpus manifest files.')
-FLAGS.define('string', 'train_csv', os.path.join(_CORPUS_DIR, 'train.csv'), 'Path to train.csv.')
-FLAGS.define('string', 'test_csv', os.path.join(_CORPUS_DIR, 'test.csv'), 'Path to test.csv.')
-FLAGS.define('string', 'dev_csv', os.path.join(_CORPUS_DIR, 'dev.csv'), 'Path to dev.csv.')
+             'Root of the WAV corpus; CSV paths are relative to it.')
+FLAGS.define('string', 'train_csv', os.path.join(_CORPUS_DIR, 'train.csv'), 'Training manifest (path;label;length).')
+FLAGS.define('string', 'test_csv', os.path.join(_CORPUS_DIR, 'test.csv'), 'Test manifest.')
+FLAGS.define('string', 'dev_csv', os.path.join(_CORPUS_DIR, 'dev.csv'), 'Validation manifest.')
 
 # Layer and activation options (asr/params.py:29-50).
-FLAGS.define('string', 'used_model', 'ds2', "Inference model: 'ds1' or 'ds2'.")
-FLAGS.define('int', 'num_units_dense', 2048, 'Number of units per dense layer.')
-FLAGS.define('float', 'relu_cutoff', 20.0, 'Cutoff ReLU activations that exceed the cutoff.')
+FLAGS.define('string', 'used_model', 'ds2', "Front-end: 'ds1' = 3 dense layers, 'ds2' = 2-D convolutions.")
+FLAGS.define('int', 'num_units_dense', 2048, 'Width of every dense layer.')
+FLAGS.define('float', 'relu_cutoff', 20.0, 'Upper clip applied after each ReLU.')
 FLAGS.define('multi_int', 'conv_filters', [32, 32, 96],
              'Number of filters for each convolutional layer (3 = reference stack; 2 entries '
              'select the "2-conv" variant of BASELINE.json).')
-FLAGS.define('int', 'num_layers_rnn', 4, 'Number of stacked RNN cells.')
-FLAGS.define('int', 'num_units_rnn', 2048, 'Number of hidden units in each of the RNN cells.')
-FLAGS.define('string', 'rnn_cell', 'rnn_relu', "RNN cell: 'rnn_relu', 'rnn_tanh', 'lstm', 'gru'.")
+FLAGS.define('int', 'num_layers_rnn', 4, 'Depth of the bidirectional recurrent stack.')
+FLAGS.define('int', 'num_units_rnn', 2048, 'Hidden units per direction.')
+FLAGS.define('string', 'rnn_cell', 'rnn_relu', "Recurrent cell: rnn_relu | rnn_tanh | lstm | gru.")
 
 # Inputs (asr/params.py:52-61).
-FLAGS.define('int', 'batch_size', 16, 'Number of samples within a batch.')
-FLAGS.define('string', 'feature_type', 'mfcc', "Input features: 'mel' or 'mfcc'.")
-FLAGS.define('string', 'feature_normalization', 'local', "'none', 'local' or 'local_scalar'.")
+FLAGS.define('int', 'batch_size', 16, 'Utterances per minibatch (per GPU when data parallel).')
+FLAGS.define('string', 'feature_type', 'mfcc', "'mel' = 80 log-mel bands, 'mfcc' = 40 cepstra + 40 deltas.")
+FLAGS.define('string', 'feature_normalization', 'local', "Per-utterance normalisation: none | local | local_scalar.")
 FLAGS.define('bool', 'features_drop_every_second_frame', False,
-             '[Deep Speech 1] like dropping of every 2nd input time frame.')
+             'Keep only every second feature frame (Deep Speech 1 style).')
 
 # Learning rate (asr/params.py:63-74; the three decay flags are inert in the reference too).
-FLAGS.define('int', 'max_epochs', 15, 'Number of epochs to run.')
-FLAGS.define('float', 'learning_rate', 1e-5, 'Initial learning rate.')
-FLAGS.define('float', 'learning_rate_decay_factor', 4 / 5, 'Learning rate decay factor (unused).')
-FLAGS.define('int', 'steps_per_decay', 75000, 'Steps after which learning rate decays (unused).')
-FLAGS.define('float', 'minimum_lr', 1e-6, 'Minimum value the learning rate can decay to (unused).')
+FLAGS.define('int', 'max_epochs', 15, 'Total epochs (the first one walks the CSV in order).')
+FLAGS.define('float', 'learning_rate', 1e-5, 'Adam step size.')
+FLAGS.define('float', 'learning_rate_decay_factor', 4 / 5, 'Accepted, inert (as in the reference).')
+FLAGS.define('int', 'steps_per_decay', 75000, 'Accepted, inert.')
+FLAGS.define('float', 'minimum_lr', 1e-6, 'Accepted, inert. ')
 
 # Adam (asr/params.py:76-82).
-FLAGS.define('float', 'adam_beta1', 0.9, 'Adam optimizer beta_1 power.')
-FLAGS.define('float', 'adam_beta2', 0.999, 'Adam optimizer beta_2 power.')
-FLAGS.define('float', 'adam_epsilon', 1e-8, 'Adam optimizer epsilon.')
+FLAGS.define('float', 'adam_beta1', 0.9, 'First-moment decay.')
+FLAGS.define('float', 'adam_beta2', 0.999, 'Second-moment decay.')
+FLAGS.define('float', 'adam_epsilon', 1e-8, 'Added to sqrt(v) (TensorFlow form).')
 
 # CTC decoder (asr/params.py:84-86).
-FLAGS.define('int', 'beam_width', 1024, 'Beam width used in the CTC beam search decoder.')
+FLAGS.define('int', 'beam_width', 1024, 'Leaves kept by the CTC beam search (<= 1024).')
 
 # Dropout (asr/params.py:88-94).
-FLAGS.define('float', 'conv_dropout_rate', 0.0, 'Dropout rate for convolutional layers.')
-FLAGS.define('float', 'rnn_dropout_rate', 0.0, 'Dropout rate for the RNN cell layers.')
-FLAGS.define('float', 'dense_dropout_rate', 0.1, 'Dropout rate for dense layers.')
+FLAGS.define('float', 'conv_dropout_rate', 0.0, 'Drop probability after each conv layer.')
+FLAGS.define('float', 'rnn_dropout_rate', 0.0, 'Drop probability between recurrent layers.')
+FLAGS.define('float', 'dense_dropout_rate', 0.1, 'Drop probability after each dense layer.')
 
 # Corpus (asr/params.py:96-103).
-FLAGS.define('int', 'num_buckets', 96, 'The maximum number of buckets to use for bucketing.')
-FLAGS.define('int', 'num_classes', num_classes(), 'Number of classes incl. the CTC <blank>.')
-FLAGS.define('int', 'sampling_rate', 16000, 'The sampling rate of the audio files.')
+FLAGS.define('int', 'num_buckets', 96, 'Upper bound on length buckets.')
+FLAGS.define('int', 'num_classes', num_classes(), 'Alphabet size + unused id 0 + CTC blank.')
+FLAGS.define('int', 'sampling_rate', 16000, 'Expected WAV sampling rate in Hz.')
 
 # Performance / GPU (asr/params.py:105-112).  `cudnn=True` selects the fused recurrent kernels
 # with cuDNN semantics (no sequence lengths); False selects the length-aware tanh-RNN semantics of
 # the TensorFlow BasicRNNCell path.  Both run on the MI355X HIP kernels.
 FLAGS.define('bool', 'cudnn', True, 'cuDNN-semantics RNN stack (True) or TF BasicRNNCell (False).')
-FLAGS.define('int', 'shuffle_buffer_size', 2 ** 14, 'Elements held by the dataset shuffle buffer.')
+FLAGS.define('int', 'shuffle_buffer_size', 2 ** 14, 'Sliding shuffle window of the bucketed targets.')
 
 # Logging (asr/params.py:114-125).
-FLAGS.define('int', 'log_frequency', 200, 'How often (every N steps) to log results.')
-FLAGS.define('int', 'num_samples_to_report', 4, 'Decoded/original text samples to report.')
-FLAGS.define('int', 'gpu_hook_query_frequency', 5, 'How often GPU statistics are queried.')
-FLAGS.define('int', 'gpu_hook_average_queries', 100, 'Number of queries averaged.')
+FLAGS.define('int', 'log_frequency', 200, 'Steps between loss / throughput log lines.')
+FLAGS.define('int', 'num_samples_to_report', 4, 'Decoded examples printed per evaluation.')
+FLAGS.define('int', 'gpu_hook_query_frequency', 5, 'Accepted for compatibility (NVML hook of the reference).')
+FLAGS.define('int', 'gpu_hook_average_queries', 100, 'Accepted for compatibility. ')
 
 # Miscellaneous (asr/params.py:127-137).
-FLAGS.define('bool', 'delete', False, 'Whether to delete old checkpoints, or resume training.')
-FLAGS.define('int', 'random_seed', 0, 'Random seed. 0 = use the current timestamp instead.')
+FLAGS.define('bool', 'delete', False, 'Wipe train_dir first instead of resuming.')
+FLAGS.define('int', 'random_seed', 0, 'Seed for init / dropout / shuffling; 0 = wall clock.')
 FLAGS.define('bool', 'log_device_placement', False, 'Accepted for compatibility (no effect).')
 FLAGS.define('bool', 'allow_vram_growth', True, 'Accepted for compatibility (no effect).')
 
 # Driver-specific flags of the reference: `dev` (asr/evaluate.py:10), `input` (asr/predict.py:13).
-FLAGS.define('bool', 'dev', False, '`True` evaluates the dev set, `False` the test set.')
-FLAGS.define('string', 'input', '', 'Path to the WAV file to transcribe.')
+FLAGS.define('bool', 'dev', False, 'evaluate.py: score dev.csv instead of test.csv.')
+FLAGS.define('string', 'input', '', 'predict.py: WAV file to decode.')
 
 # ####### Constants (asr/params.py:138-155). #########
 NP_FLOAT = np.float32

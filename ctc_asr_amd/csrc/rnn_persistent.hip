@@ -649,6 +649,8 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
     const bool lstm = cell == CTCASR_CELL_LSTM && H == 1024;
     const bool rnn = (cell == CTCASR_CELL_RNN_RELU || cell == CTCASR_CELL_RNN_TANH) && H == 2048;
     if (!(lstm || rnn) || B < 1 || B > 32 || T < 1) return 0;
+    // the exchange buffer is addressed through a 32-bit buffer descriptor
+    if ((size_t)(T + 1) * 2 * B * (lstm ? 4 : 1) * H * sizeof(float) >= (1ull << 31)) return 0;
     const char *mode = getenv("CTCASR_RNN_MODE");   // "stream" forces the per-step kernels
     if (mode && mode[0] == 's') return 0;
     return device_cu_count() >= 256 ? 1 : 0;

@@ -613,6 +613,36 @@ class CTCModel:
         hip.adam_step(a.param, a.grad, a.m, a.v, self.step_count, learning_rate, beta1, beta2,
                       epsilon, grad_scale)
 
+    # ------------------------------------------------------------------ estimator-style entry
+    def model_fn(self, features, labels, mode, learning_rate=1e-5, adam=(0.9, 0.999, 1e-8)):
+        """One call of the reference's ``model_fn`` (``asr/model.py:23-121``) executed eagerly.
+
+        ``mode``: 'infer' (tf.estimator.ModeKeys.PREDICT) -> {'decoded', 'plaintext'};
+        'train' -> runs forward, loss, backward and one Adam step, returns {'loss', 'decoded',
+        'plaintext', 'mean_edit_distance', 'word_error_rate'}; 'eval' -> the same without the
+        update.  Anything else raises ``RuntimeError('Invalid mode.')`` like the reference."""
+        if mode not in ('train', 'eval', 'infer'):
+            raise RuntimeError('Invalid mode.')
+        logits, seq_length = self.inference_fn(features['spectrogram'],
+                                               features['spectrogram_length'],
+                                               training=(mode == 'train'))
+        if mode == 'infer':
+            decoded, plaintext, _ = self.decode_fn(logits, seq_length, None)
+            return {'decoded': decoded, 'plaintext': plaintext}
+        loss = self.loss_fn(logits, seq_length, labels)
+        if mode == 'train':
+            self.backward()
+            self.apply_gradients(learning_rate, *adam)
+        originals = features['label_plaintext']
+        decoded, plaintext, summary = self.decode_fn(
+            logits, seq_length, np.array([t.encode('utf-8') if isinstance(t, str) else t
+                                          for t in originals], dtype=object))
+        _, mean_ed, _, wer = self.error_rates_fn(labels, [t.decode('utf-8') if isinstance(t, bytes)
+                                                          else t for t in originals],
+                                                 decoded, plaintext)
+        return {'loss': loss, 'decoded': decoded, 'plaintext': plaintext, 'summary': summary,
+                'mean_edit_distance': mean_ed, 'word_error_rate': wer}
+
     # ------------------------------------------------------------------ decode / score
     def decode_fn(self, logits, seq_len, originals=None, beam_width=None, greedy=False):
         """CTC decode + plaintext (``asr/model.py:271-309``).  Returns (decoded: list of B int

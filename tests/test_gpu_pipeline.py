@@ -104,3 +104,19 @@ def test_loss_decreases_on_a_fixed_batch(corpus):
     feats, lens = batch.features['spectrogram'], batch.features['spectrogram_length']
     losses = [float(trainer.train_step(feats, lens, batch.labels)) for _ in range(30)]
     assert losses[-1] < losses[0] * 0.8
+
+
+def test_model_fn_modes(corpus):
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=3)
+    batch = next(iter(input_functions.input_fn_generator('dev', seed=1, prefetch=0)()))
+    features, labels = batch
+    pred = model.model_fn(features, None, 'infer')
+    assert set(pred) == {'decoded', 'plaintext'} and len(pred['decoded']) == len(labels)
+    before = model.arena.param.clone()
+    ev = model.model_fn(features, labels, 'eval')
+    assert torch.equal(before, model.arena.param) and 0.0 <= float(ev['word_error_rate'])
+    tr = model.model_fn(features, labels, 'train', learning_rate=1e-3)
+    assert not torch.equal(before, model.arena.param) and torch.isfinite(tr['loss'])
+    with pytest.raises(RuntimeError):
+        model.model_fn(features, labels, 'tune')

@@ -1,0 +1,96 @@
+"""Host-side logic of the input pipeline that needs no GPU: manifest quirks, WAV checks,
+bucketing / batching / sharding semantics (asr/input_functions.py:21-153)."""
+
+import random
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from ctc_asr_amd import input_functions as inp
+from ctc_asr_amd import synth
+from ctc_asr_amd.params import FLAGS
+
+
+@pytest.fixture()
+def tiny_corpus(tmp_path):
+    FLAGS.reset()
+    rows = synth.write_corpus(str(tmp_path / 'corpus'), str(tmp_path / 'train.csv'),
+                              [0.7, 0.9, 1.1, 1.3, 1.5], seed=3, chars_per_second=5.0)
+    FLAGS.update(corpus_dir=str(tmp_path / 'corpus'), train_csv=str(tmp_path / 'train.csv'))
+    yield tmp_path, rows
+    FLAGS.reset()
+
+
+def test_manifest_drops_header_and_last_row(tiny_corpus):
+    tmp_path, rows = tiny_corpus
+    assert len(rows) == 6                       # 5 utterances + the sacrificial duplicate
+    manifest = inp.read_manifest(FLAGS.train_csv)
+    assert [r['path'] for r in manifest] == [r[0] for r in rows[:5]]
+    assert all(set(r['label']) <= set(' abcdefghijklmnopqrstuvwxyz') for r in manifest)
+    # without the sacrificial row the reference loses the last real example
+    with open(FLAGS.train_csv) as handle:
+        lines = handle.read().splitlines()
+    with open(FLAGS.train_csv, 'w') as handle:
+        handle.write('\n'.join(lines[:-1]) + '\n')
+    assert len(inp.read_manifest(FLAGS.train_csv)) == 4
+
+
+def test_read_wav_checks(tiny_corpus, tmp_path):
+    tmp, rows = tiny_corpus
+    audio = inp.read_wav(str(tmp / 'corpus' / rows[0][0]))
+    assert audio.dtype == np.int16 and len(audio) == 11200
+    with pytest.raises(ValueError):
+        inp.read_wav(str(tmp / 'corpus' / 'missing.wav'))
+    short = tmp_path / 'short.wav'
+    wavfile.write(str(short), 16000, np.zeros(400, dtype=np.int16))
+    with pytest.raises(RuntimeError):
+        inp.read_wav(str(short))
+    wrong_rate = tmp_path / 'rate.wav'
+    wavfile.write(str(wrong_rate), 8000, np.zeros(4000, dtype=np.int16))
+    with pytest.raises(RuntimeError):
+        inp.read_wav(str(wrong_rate))
+    with pytest.raises(ValueError):
+        inp._check_feature_args('fbank', None)
+    with pytest.raises(ValueError):
+        inp._check_feature_args(None, 'global')
+    with pytest.raises(ValueError):
+        inp.input_fn_generator('training')
+
+
+def _items(lengths):
+    return [(None, [1], 'x{}'.format(i), n) for i, n in enumerate(lengths)]
+
+
+def test_plain_batches_keep_order_and_drop_the_remainder():
+    groups = list(inp._group_batches(iter(_items(range(10))), False, [], 4))
+    assert [[it[3] for it in g] for g in groups] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
+def test_bucketing_matches_tf_bucket_by_sequence_length():
+    # boundaries [5, 10]: buckets (-inf, 5), [5, 10), [10, inf); full buckets emit at once,
+    # leftovers are emitted at the end in bucket order and are not dropped
+    lengths = [1, 12, 6, 2, 7, 13, 3, 9, 4, 5, 11]
+    groups = list(inp._group_batches(iter(_items(lengths)), True, [5, 10], 3))
+    got = [[it[3] for it in g] for g in groups]
+    assert got == [[1, 2, 3], [6, 7, 9], [12, 13, 11], [4], [5]]
+    assert sorted(v for g in got for v in g) == sorted(lengths)
+
+
+def test_shuffle_buffer_is_a_permutation_and_seeded():
+    items = list(range(100))
+    a = list(inp._shuffle_buffer(iter(items), 16, random.Random(1)))
+    b = list(inp._shuffle_buffer(iter(items), 16, random.Random(1)))
+    assert sorted(a) == items and a == b and a != items
+    # an element can only surface once the buffer has filled: position >= index - buffer
+    assert all(pos >= val - 16 for pos, val in enumerate(a))
+
+
+def test_random_label_shape():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 15, 150):
+        text = synth.random_label(rng, n)
+        assert len(text) == n and not text.startswith(' ') and not text.endswith(' ')
+        assert '  ' not in text
+    durations = synth.librispeech_like_durations(rng, 1000)
+    assert durations.min() >= 0.7 and durations.max() <= 17.0 and 8.0 < durations.mean() < 14.0

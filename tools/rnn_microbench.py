@@ -42,7 +42,7 @@ def main():
         print('{}: {:.3f} ms per call, {:.2f} us per time step'.format(name, ms, ms * 1e3 / T))
         if os.environ.get('CTCASR_RNN_PROF'):
             state = (6 * B * H * 4 + 255) // 256 * 256
-            base = state + 4096 + 256 + (0 if name == 'fwd' else 32)
+            base = state + 4096 + 256 + (0 if name == "fwd" else 32)
             words = ws[base: base + 32].cpu().numpy().view(np.uint64)
             labels = ['wait', 'loads+mfma', 'reduce+gates+publish', 'drain+arrive']
             print('  wg0 phases (us/step): ' + ', '.join(

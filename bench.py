@@ -170,7 +170,8 @@ def main():
     cfg = ModelConfig(used_model='ds2', conv_filters=filters, num_units_dense=dense,
                       num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell='lstm', cudnn=True,
                       dense_dropout_rate=args.dropout)
-    trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank)
+    # fixed input shape: let MIOpen benchmark its convolution kernels once (warm-up steps)
+    trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True)
     model = trainer.model
 
     # synthetic 16 kHz utterances: int16 PCM resident in HBM (SURVEY.md 8d recipe), random labels

@@ -254,12 +254,21 @@ class CTCModel:
     ``CTCModel`` with torch tensors in place of TensorFlow tensors; ``forward_backward`` /
     ``apply_gradients`` are the explicit counterparts of ``optimizer.minimize``."""
 
-    def __init__(self, cfg, device='cuda', seed=0, params=None):
+    def __init__(self, cfg, device='cuda', seed=0, params=None, conv_autotune=None):
         hip.load()
-        # let MIOpen time its candidate convolution kernels once per shape (the heuristic pick is
-        # ~35 % slower for the 11x21 stride-(1,2) layers); CTCASR_CONV_AUTOTUNE=0 turns it off,
-        # e.g. for a first epoch over hundreds of distinct padded lengths
-        torch.backends.cudnn.benchmark = os.environ.get('CTCASR_CONV_AUTOTUNE', '1') != '0'
+        # MIOpen convolution selection.  Its default "find" benchmarks every solver the first
+        # time a shape is seen: 3-6 s per new padded length (measured), which is fatal for
+        # bucketed batches whose time extent changes every step - so the default here is the
+        # immediate (heuristic) mode.  Fixed-shape runs (bench.py) opt into autotuning, which
+        # picks ~35 % faster kernels for the 11x21 stride-(1,2) layers:
+        # `conv_autotune=True` or CTCASR_CONV_AUTOTUNE=1.
+        if conv_autotune is None:
+            conv_autotune = os.environ.get('CTCASR_CONV_AUTOTUNE', '0') == '1'
+        if conv_autotune:
+            torch.backends.cudnn.benchmark = True
+        else:
+            os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')
+            torch.backends.cudnn.benchmark = False
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != 'cuda':

@@ -6,7 +6,9 @@ python_speech_features on one Python thread and batches with ``tf.data``; here W
 read on the host, raw int16 PCM of a whole batch is uploaded once, and log-mel / MFCC features,
 the optional frame drop and the per-utterance normalisation run on the MI355X
 (``ctcasr_features``), writing straight into the zero-padded ``[B, T, 80]`` batch tensor the
-model consumes.  Bucketing only needs frame *counts*, which follow from the sample count.
+model consumes.  Bucketing only needs frame *counts*, which follow from the sample count in the
+WAV header: the shuffle buffer holds paths, not audio (16 384 utterances of LibriSpeech would be
+~6 GB of PCM), and in data-parallel runs a rank reads only the utterances of its own shard.
 
 Reference quirks kept on purpose: the CSV slice ``[1:-1]`` drops the
 header and the LAST example; ``train_batch`` keeps CSV order and drops the remainder; bucketed
@@ -19,6 +21,8 @@ import os
 import queue
 import random
 import threading
+import wave
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -29,6 +33,7 @@ from ctc_asr_amd.csv_helper import get_bucket_boundaries, read_csv_rows
 from ctc_asr_amd.labels import ctoi
 from ctc_asr_amd.params import CSV_HEADER_LABEL, CSV_HEADER_PATH, FLAGS
 
+READER_THREADS = 4           # WAV files of one batch are read concurrently
 SUPPORTED_FEATURE_TYPES = ('mel', 'mfcc')
 SUPPORTED_NORMALIZATIONS = ('none', 'local', 'local_scalar')
 
@@ -48,6 +53,28 @@ def read_wav(file_path):
     if audio.dtype != np.int16 or audio.ndim != 1:
         raise RuntimeError('Only mono 16-bit PCM WAV files are supported: {}'.format(file_path))
     return audio
+
+
+def probe_wav(file_path):
+    """Sample count of a WAV file from its header alone, with `read_wav`'s checks.  Bucketing and
+    shuffling only need the length, so the samples themselves are read later - after the shuffle
+    buffer and, in data-parallel runs, only by the rank that owns the utterance."""
+    if not os.path.isfile(file_path):
+        raise ValueError('"{}" does not exist.'.format(file_path))
+    try:
+        with wave.open(file_path, 'rb') as handle:
+            rate, count = handle.getframerate(), handle.getnframes()
+            mono16 = handle.getnchannels() == 1 and handle.getsampwidth() == 2
+    except (wave.Error, EOFError):         # e.g. WAVE_FORMAT_EXTENSIBLE: take the slow road
+        return len(read_wav(file_path))
+    if count < 401:
+        raise RuntimeError('Sample length {:,d} to short: {}'.format(count, file_path))
+    if rate != FLAGS.sampling_rate:
+        raise RuntimeError('Sampling rate is {:,d}, expected {:,d}.'
+                           .format(rate, FLAGS.sampling_rate))
+    if not mono16:
+        raise RuntimeError('Only mono 16-bit PCM WAV files are supported: {}'.format(file_path))
+    return count
 
 
 def num_frames(num_samples, drop_every_second_frame=None):
@@ -133,8 +160,7 @@ def _example_stream(csv_path, shuffle, rng):
     for line in lines:
         path = os.path.join(FLAGS.corpus_dir, line[CSV_HEADER_PATH])
         label = line[CSV_HEADER_LABEL]
-        audio = read_wav(path)
-        yield audio, [ctoi(c) for c in label], label, num_frames(len(audio))
+        yield path, [ctoi(c) for c in label], label, num_frames(probe_wav(path))
 
 
 def _shuffle_buffer(stream, size, rng):
@@ -211,11 +237,14 @@ def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, p
             per_rank = len(group) // world_size
             return group[rank * per_rank:(rank + 1) * per_rank]
 
+        readers = ThreadPoolExecutor(max_workers=READER_THREADS)
+
         def host_side():
             for group in groups:
                 part = shard(group)
                 if part:
-                    yield [(it[0], it[1], it[2]) for it in part]
+                    audio = list(readers.map(read_wav, [it[0] for it in part]))
+                    yield [(pcm, it[1], it[2]) for pcm, it in zip(audio, part)]
 
         if prefetch <= 0:
             for items in host_side():

@@ -50,6 +50,24 @@ def test_read_wav_checks(tiny_corpus, tmp_path):
     wavfile.write(str(wrong_rate), 8000, np.zeros(4000, dtype=np.int16))
     with pytest.raises(RuntimeError):
         inp.read_wav(str(wrong_rate))
+    # the header-only probe agrees with the full read and applies the same checks
+    assert inp.probe_wav(str(tmp / 'corpus' / rows[0][0])) == 11200
+    with pytest.raises(ValueError):
+        inp.probe_wav(str(tmp / 'corpus' / 'missing.wav'))
+    with pytest.raises(RuntimeError):
+        inp.probe_wav(str(short))
+    with pytest.raises(RuntimeError):
+        inp.probe_wav(str(wrong_rate))
+    stereo = tmp_path / 'stereo.wav'
+    wavfile.write(str(stereo), 16000, np.zeros((4000, 2), dtype=np.int16))
+    with pytest.raises(RuntimeError):
+        inp.probe_wav(str(stereo))
+    with pytest.raises(RuntimeError):
+        inp.read_wav(str(stereo))
+    floats = tmp_path / 'float.wav'            # IEEE-float WAV: `wave` refuses, fall back
+    wavfile.write(str(floats), 16000, np.zeros(4000, dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        inp.probe_wav(str(floats))
     with pytest.raises(ValueError):
         inp._check_feature_args('fbank', None)
     with pytest.raises(ValueError):

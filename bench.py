@@ -45,8 +45,10 @@ WORKLOADS = {
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip table
 # (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch, measured with rocprofv3 PMC passes
-PMC_TRAFFIC = {('c2', 'rnn_bwd'): int((1426952 + 513996) * 1024),
-               ('c2', 'rnn_fwd'): int((793424 + 451992) * 1024)}
+# (key: workload, pass, time steps per launch)
+PMC_TRAFFIC = {('c2', 'rnn_bwd', 167): int((486779 + 171415) * 1024),
+               ('c2', 'rnn_bwd', 500): int((1426952 + 513996) * 1024),
+               ('c2', 'rnn_fwd', 500): int((793441 + 451992) * 1024)}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -201,6 +203,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     hip.EVENTS = {}
+    hip.set_option('rnn_kernel_events', 1)      # event pairs right around the persistent kernels
+    hip.rnn_kernel_events()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -211,6 +215,8 @@ def main():
     elapsed = time.perf_counter() - t0
     events = hip.drain_events()
     hip.EVENTS = None
+    kernel_events = hip.rnn_kernel_events()
+    hip.set_option('rnn_kernel_events', 0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,20 +244,26 @@ def main():
             flops_per_step = 2.0 * 2 * batch * hidden * gates * hidden    # both directions
             bytes_per_step = 2 * (gates * hidden * hidden + batch * hidden * (2 + gates)) * 4
             if persistent:
+                # the kernel alone (library-side event pair), not the call incl. its memsets
+                calls, dom_ms = kernel_events[dom[4:]]
                 avg_s = dom_ms * 1e-3 / calls
-                achieved = flops_per_step * t_out / avg_s / 1e12
+                # the backward recurrence of a layer may be cut into several launches
+                # (CTCModel.bwd_chunks); a launch then covers T' / chunks time steps
+                launch_steps = t_out * args.steps * cfg.num_layers_rnn / float(calls)
+                achieved = flops_per_step * launch_steps / avg_s / 1e12
                 roofline = {
                     'kernel': 'prnn_{}_kernel<LSTM> (persistent, LDS-resident recurrent weights; '
-                              'one launch = {} time steps x 2 directions)'.format(dom[4:], t_out),
+                              'one launch = {:.0f} time steps x 2 directions)'.format(
+                                  dom[4:], launch_steps),
                     'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
                     # passes of this workload (profiles/r01_final_c2_kernel_trace_and_pmc.md)
-                    'traffic': PMC_TRAFFIC.get((args.workload, dom)),
+                    'traffic': PMC_TRAFFIC.get((args.workload, dom, round(launch_steps))),
                     'avg_launch_us': round(avg_s * 1e6, 1), 'launches': calls,
-                    'algorithmic_flops_per_launch': flops_per_step * t_out,
-                    'us_per_time_step': round(avg_s * 1e6 / t_out, 3),
+                    'algorithmic_flops_per_launch': flops_per_step * launch_steps,
+                    'us_per_time_step': round(avg_s * 1e6 / launch_steps, 3),
                     'share_of_step': round(dom_ms / (elapsed * 1e3), 3)}
             else:
                 launches = calls * t_out

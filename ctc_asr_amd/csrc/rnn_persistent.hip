@@ -25,6 +25,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #define PRNN_THREADS 256
 #define PRNN_GROUPS 8
@@ -54,6 +55,8 @@ struct PArgs {
     SyncWords *sync;
     float *xchg;           // exchange buffer [T steps][2][K/16 chunks][B][16] (see below)
     int T, B, H, nwg;      // nwg = workgroups per direction
+    int s_lo, s_hi;        // backward: this launch runs steps s_hi-1 ... s_lo (a whole pass: 0, T)
+    float *carry;          // backward, LSTM: dc [2, B, H] handed from one launch to the next
     int prof;              // record phase timings of workgroup 0
 };
 
@@ -433,7 +436,15 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     const int rot = REGW == 0 ? (slice & (QW - 1)) : 0;
     float dc_state[ITEMS];
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) dc_state[it] = 0.f;
+    for (int it = 0; it < ITEMS; ++it) {
+        dc_state[it] = 0.f;
+        if constexpr (CELL == CTCASR_CELL_LSTM) {
+            // continuing a pass that an earlier launch started: pick up its cell-state gradient
+            const int item = tid + it * PRNN_THREADS;
+            if (p.s_hi < T && item < 16 * MT * UPB && item / UPB < B)
+                dc_state[it] = p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB];
+        }
+    }
     int a_steps[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -443,7 +454,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
 
     unsigned long long pt[4] = {0, 0, 0, 0};
     const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
-    for (int s = T - 1; s >= 0; --s) {
+    for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
         unsigned long long c0 = prof ? wall_clock64() : 0;
         // everything the cell derivative needs except dh_rec: prefetched before the barrier
         float dyv[ITEMS], gv[ITEMS][4], cv[ITEMS], cpv[ITEMS], hv[ITEMS];
@@ -487,8 +498,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
         }
 
         if (s < T - 1) {
-            // dgates of step s+1 from every workgroup of this direction
-            dir_wait(p.sync, dir, group_size, (unsigned)(T - 2 - s), tid);
+            // dgates of step s+1 from every workgroup of this direction (the first step of a
+            // continued pass reads what the previous launch left: nothing to wait for)
+            if (s < p.s_hi - 1)
+                dir_wait(p.sync, dir, group_size, (unsigned)(p.s_hi - 2 - s), tid);
             if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
             unsigned aoff[MT];
             bool ok[MT];
@@ -604,8 +617,18 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
-        if (s > 0) dir_arrive(p.sync, dir, grp, tid);
+        if (s > p.s_lo) dir_arrive(p.sync, dir, grp, tid);
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if constexpr (CELL == CTCASR_CELL_LSTM) {
+        if (p.s_lo > 0) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * PRNN_THREADS;
+                if (item < 16 * MT * UPB && item / UPB < B)
+                    p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB] = dc_state[it];
+            }
+        }
     }
     if (prof)
         for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
@@ -624,21 +647,70 @@ int device_cu_count() {
     return cus;
 }
 
+// Optional HIP-event timing of the persistent launches themselves (option "rnn_kernel_events"):
+// an event pair is recorded on the launch stream right around each kernel, so that a benchmark can
+// report the kernel's duration as a profiler's kernel trace sees it - without the memsets and the
+// host-side gaps a caller-side bracket around ctcasr_rnn_fwd / _bwd would include.
+struct TimedLaunch { hipEvent_t start, stop; int backward; };
+int g_kernel_events = 0;
+std::vector<TimedLaunch> g_timed;
+
 template <typename K>
 int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_floats,
                       hipStream_t s) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    if (hipMemsetAsync(p.sync, 0, sizeof(SyncWords), s) != hipSuccess) return CTCASR_ERR_LAUNCH;
-    if (hipMemsetAsync(p.xchg + (size_t)p.T * zero_step_floats, 0,
-                       zero_step_floats * sizeof(float), s) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
+    if (p.s_hi < p.T) {
+        // continuing a backward pass: fresh barrier counters, but the error word, the exchange
+        // buffer and its all-zero step stay as the previous launch left them
+        if (hipMemsetAsync(p.sync, 0, offsetof(SyncWords, error), s) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+    } else {
+        if (hipMemsetAsync(p.sync, 0, sizeof(SyncWords), s) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+        if (hipMemsetAsync(p.xchg + (size_t)p.T * zero_step_floats, 0,
+                           zero_step_floats * sizeof(float), s) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+    }
+    TimedLaunch timed = {};
+    const bool record = g_kernel_events && g_timed.size() < 65536 &&
+                        hipEventCreate(&timed.start) == hipSuccess &&
+                        hipEventCreate(&timed.stop) == hipSuccess;
+    if (record) hipEventRecord(timed.start, s);
     kernel<<<2 * p.nwg, PRNN_THREADS, lds, s>>>(p);
+    if (record) {
+        hipEventRecord(timed.stop, s);
+        timed.backward = p.dxw != nullptr;
+        g_timed.push_back(timed);
+    }
     return ctcasr_launch_status();
 }
 
 }  // namespace
+
+// Sums and clears the recorded launches: launches[0] / total_ms[0] forward, [1] backward.  Waits
+// for the recorded events to complete.
+extern "C" int ctcasr_rnn_kernel_events(int *launches, double *total_ms) {
+    if (!launches || !total_ms) return CTCASR_ERR_BAD_ARGUMENT;
+    launches[0] = launches[1] = 0;
+    total_ms[0] = total_ms[1] = 0.0;
+    int rc = CTCASR_OK;
+    for (TimedLaunch &t : g_timed) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.stop) == hipSuccess &&
+            hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            launches[t.backward] += 1;
+            total_ms[t.backward] += ms;
+        } else {
+            rc = CTCASR_ERR_LAUNCH;
+        }
+        hipEventDestroy(t.start);
+        hipEventDestroy(t.stop);
+    }
+    g_timed.clear();
+    return rc;
+}
 
 // Whether the LDS-resident kernels cover this shape (LSTM, H = 1024, B <= 32 for now; every
 // other shape takes the streaming kernels of rnn_step.hip).
@@ -666,6 +738,7 @@ int g_bwd_half_chip = 1;   // measured faster than the whole-chip variant even w
 extern "C" int ctcasr_set_option(const char *name, int value) {
     if (!name) return CTCASR_ERR_BAD_ARGUMENT;
     if (strcmp(name, "rnn_bwd_half_chip") == 0) { g_bwd_half_chip = value ? 1 : 0; return CTCASR_OK; }
+    if (strcmp(name, "rnn_kernel_events") == 0) { g_kernel_events = value ? 1 : 0; return CTCASR_OK; }
     return CTCASR_ERR_BAD_ARGUMENT;
 }
 
@@ -680,6 +753,7 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H;
+    p.s_lo = 0; p.s_hi = T;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
@@ -706,8 +780,9 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
 
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, void *sync, hipStream_t s) {
+             float *dxw, void *sync, float *carry, int step_begin, int step_end, hipStream_t s) {
     PArgs p = {};
+    p.s_lo = step_begin; p.s_hi = step_end; p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
@@ -716,8 +791,9 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.T = T; p.B = B; p.H = H;
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : H / 16;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
-    if (seq_len &&
-        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * 4 * H * sizeof(float), s) != hipSuccess)
+    if (seq_len && step_end == T &&
+        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * (cell == CTCASR_CELL_LSTM ? 4 : 1) * H *
+                                   sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
 #define PRNN_BWD(CELL_, QW_, MT_, LB_, UPB_, REGW_, G_)                                        \

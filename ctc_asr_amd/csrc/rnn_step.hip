@@ -275,7 +275,7 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
              int H, float *y, float *gates, float *cells, void *sync, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, void *sync, hipStream_t s);
+             float *dxw, void *sync, float *carry, int step_begin, int step_end, hipStream_t s);
 
 static size_t rnn_state_bytes(int B, int H) {
     return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256);
@@ -344,14 +344,22 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, cons
     return ctcasr_launch_status();
 }
 
-extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
-                              const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
-                              const void *reserve, float *dxw, float *db_hh_n, void *workspace,
-                              size_t workspace_bytes, ctcasr_stream_t stream) {
+// Steps [step_begin, step_end) of the backward recurrence, walked downwards.  A whole pass is
+// (0, T); a pass may be cut into launches that cover T..0 in descending order with the same
+// workspace - the state between them (dh through the exchange buffer / state ping-pong, dc in the
+// carry) stays in the workspace.  Between two launches the caller can hand the time steps that
+// are already final to weight-gradient GEMMs on another stream.
+extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
+                                    const float *w_hh_t, const float *b_hh_n,
+                                    const int32_t *seq_len, int T, int B, int H,
+                                    const void *reserve, float *dxw, float *db_hh_n,
+                                    void *workspace, size_t workspace_bytes, int step_begin,
+                                    int step_end, ctcasr_stream_t stream) {
     (void)b_hh_n; (void)db_hh_n;   // the GRU bias gradient is the column sum of drec (caller)
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
+    if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
         return CTCASR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -366,15 +374,16 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
     p.drec = p.gates + (size_t)T * B * 2 * 4 * H;      // GRU: behind r, z, n, q in the reserve
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
         return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw,
-                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), s);
-    if (seq_len &&
+                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
+                        step_begin, step_end, s);
+    if (seq_len && step_end == T &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    if (cell == CTCASR_CELL_GRU && seq_len &&
+    if (cell == CTCASR_CELL_GRU && seq_len && step_end == T &&
         hipMemsetAsync(p.drec, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     dim3 grid(H / 16, 2, (B + 15) / 16);
-    for (int step = T - 1; step >= 0; --step) {
+    for (int step = step_end - 1; step >= step_begin; --step) {
         p.step = step;
         if (cell == CTCASR_CELL_LSTM)
             rnn_bwd_step_kernel<CTCASR_CELL_LSTM><<<grid, RNN_THREADS, 0, s>>>(p);
@@ -386,6 +395,14 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
             rnn_bwd_step_kernel<CTCASR_CELL_RNN_TANH><<<grid, RNN_THREADS, 0, s>>>(p);
     }
     return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
+                              const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
+                              const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                              size_t workspace_bytes, ctcasr_stream_t stream) {
+    return ctcasr_rnn_bwd_steps(cell, dy, y, w_hh_t, b_hh_n, seq_len, T, B, H, reserve, dxw,
+                                db_hh_n, workspace, workspace_bytes, 0, T, stream);
 }
 
 // Synchronises `stream` and reports whether the last persistent launch that used `workspace`

@@ -24,6 +24,7 @@ SIGNATURES = {
     'ctcasr_abi_version': (_c_int, []),
     'ctcasr_error_string': (ctypes.c_char_p, [_c_int]),
     'ctcasr_set_option': (_c_int, [ctypes.c_char_p, _c_int]),
+    'ctcasr_rnn_kernel_events': (_c_int, [_c_p, _c_p]),
     'ctcasr_log_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_log_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_ctc_loss_workspace_bytes': (_c_sz, [_c_int] * 4),
@@ -39,6 +40,8 @@ SIGNATURES = {
     'ctcasr_rnn_gru_drec_offset': (_c_sz, [_c_int] * 3),
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
+    'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 +
+                             [_c_sz, _c_int, _c_int, _c_p]),
     'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
@@ -232,6 +235,15 @@ def rnn_workspace_bytes(cell, num_steps, batch, hidden):
     return load().ctcasr_rnn_workspace_bytes(CELL_IDS[cell], num_steps, batch, hidden)
 
 
+def rnn_kernel_events():
+    """{'fwd': (launches, total_ms), 'bwd': ...} of the persistent recurrence kernels recorded
+    since the last call (needs ``set_option('rnn_kernel_events', 1)``)."""
+    launches = (ctypes.c_int * 2)()
+    total_ms = (ctypes.c_double * 2)()
+    _check(load().ctcasr_rnn_kernel_events(launches, total_ms), 'rnn_kernel_events')
+    return {'fwd': (launches[0], total_ms[0]), 'bwd': (launches[1], total_ms[1])}
+
+
 def rnn_persistent_supported(cell, num_steps, batch, hidden):
     return bool(load().ctcasr_rnn_persistent_supported(CELL_IDS[cell], num_steps, batch, hidden))
 
@@ -272,23 +284,31 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
 
 
 def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, db_hh_n=None,
-            workspace=None):
-    """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H]."""
+            workspace=None, steps=None):
+    """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H].
+
+    ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_bwd_steps`): cut
+    a pass into calls covering T..0 in descending order, passing the same ``dxw`` and
+    ``workspace`` to each."""
     num_steps, batch = dy.shape[0], dy.shape[1]
     hidden = w_hh_t.shape[1]
     gates = CELL_GATES[cell]
     dev = dy.device
+    begin, end = (0, num_steps) if steps is None else steps
+    if (begin, end) != (0, num_steps) and (dxw is None or workspace is None):
+        raise ValueError('rnn_bwd: a partial step range needs the caller\'s dxw and workspace '
+                         '(they carry the pass from one call to the next).')
     dxw = torch.empty((num_steps, batch, 2, gates * hidden), dtype=torch.float32, device=dev) \
         if dxw is None else dxw
     if workspace is None:
         workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
     with _Timed('rnn_bwd'):
-      _check(load().ctcasr_rnn_bwd(
+      _check(load().ctcasr_rnn_bwd_steps(
         CELL_IDS[cell], _dev(dy, name='dy'), _dev(y, name='y'), _dev(w_hh_t, name='w_hh_t'),
         _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
         hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),
         _dev(db_hh_n, name='db_hh_n'), _dev(workspace, torch.uint8, 'workspace'),
-        workspace.numel(), _stream()), 'rnn_bwd')
+        workspace.numel(), int(begin), int(end), _stream()), 'rnn_bwd')
     return dxw
 
 

@@ -280,6 +280,9 @@ class CTCModel:
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
         self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
+        # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
+        # launch has finished run beside the next launch instead of queueing up behind the layer
+        self.bwd_chunks = max(1, int(os.environ.get('CTCASR_BWD_CHUNKS', '3')))
         self._side_stream = None
         self.dropout_seed = int(seed) * 0x9E3779B1 + 1
         self._acts = None
@@ -481,8 +484,9 @@ class CTCModel:
             if self._side_stream is None:
                 # (a CU-masked side stream was tried and measured slower: whatever it has left
                 # when the recurrence ends keeps running on half of an otherwise idle chip)
-                low = max(torch.cuda.Stream.priority_range())      # numerically largest = lowest
-                self._side_stream = torch.cuda.Stream(self.device, priority=low)
+                # HIP stream priorities (torch only offers default / high; a lowest-priority HIP
+                # stream and a high-priority main stream were both tried) change nothing measurable
+                self._side_stream = torch.cuda.Stream(self.device)
             side = self._side_stream
         deferred = []          # layer hooks that must wait for the side stream
 
@@ -504,6 +508,10 @@ class CTCModel:
                 fn()
             for tensor in tensors:       # blocks stay reserved until the side stream is done
                 tensor.record_stream(side)
+
+        # re-layouts of the recurrent weights for the backward kernels: off the critical path
+        for i in range(cfg.num_layers_rnn):
+            hip.transpose_batched(p['rnn{}/w_hh'.format(i)], out=self._w_hh_t[i])
 
         # logits layer
         torch.mm(acts['dense4'].t(), dlogits, out=g['logits/kernel'])
@@ -527,9 +535,43 @@ class CTCModel:
             seeds = acts['drop_seeds'][i]
             if seeds[1] is not None:
                 dy = hip.dropout(dy.contiguous(), rnn_rate, seeds[1])
-            hip.transpose_batched(p[name + '/w_hh'], out=self._w_hh_t[i])
-            dxw = hip.rnn_bwd(cell, dy.contiguous(), y, self._w_hh_t[i], acts['reserves'][i],
-                              acts['rnn_len'], workspace=acts['rnn_ws'])
+            gh = gates * hidden
+            # Cut the recurrence into launches when the steps map to the same time index for every
+            # utterance (no per-row lengths: the cuDNN-semantics path) - dxw of a finished range
+            # of steps is final, so its share of dW_ih / dW_hh starts on the side stream while the
+            # next launch carries the recurrence on.
+            chunks = 1
+            if (side is not main and acts['rnn_len'] is None and cell != 'gru' and
+                    t_out >= 8 * self.bwd_chunks and
+                    hip.rnn_persistent_supported(cell, t_out, batch, hidden)):
+                chunks = self.bwd_chunks
+            dy = dy.contiguous()
+            dxw = torch.empty((t_out, batch, 2, gh), dtype=torch.float32, device=dy.device)
+
+            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw):
+                # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
+                x3 = x.view(t_out, batch, -1)
+                for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
+                    g[name + '/w_ih'][d].addmm_(
+                        dxw[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
+                        x3[a:b].reshape((b - a) * batch, -1))
+                    # dW_hh[d] += drec_t^T h_(t-1) (forward) / h_(t+1) (backward direction)
+                    if d == 0:
+                        a, shift, cols = max(a, 1), -1, slice(0, hidden)
+                    else:
+                        b, shift, cols = min(b, t_out - 1), 1, slice(hidden, 2 * hidden)
+                    if b > a:
+                        g[name + '/w_hh'][d].addmm_(
+                            dxw[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
+                            y[a + shift:b + shift, :, cols].reshape((b - a) * batch, hidden))
+
+            bounds = [t_out * (chunks - c) // chunks for c in range(chunks + 1)]   # T ... 0
+            for c in range(chunks):
+                hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
+                            dxw=dxw, workspace=acts['rnn_ws'], steps=(bounds[c + 1], bounds[c]))
+                if c + 1 < chunks:
+                    on_side([dxw], lambda lo=bounds[c + 1], hi=bounds[c]:
+                            partial_weight_grads(lo, hi), head_start_us=self.side_head_start_us)
             dxw2d = dxw.view(rows, 2 * gates * hidden)
             # critical path: the gradient w.r.t. this layer's input feeds the layer below
             dy_below = None
@@ -539,10 +581,15 @@ class CTCModel:
                 if seeds[0] is not None:
                     dy_below = hip.dropout(dy_below, rnn_rate, seeds[0])
 
-            def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i):
+            def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i, chunks=chunks,
+                             last=bounds[-2], partial_weight_grads=partial_weight_grads):
+                hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
+                if chunks > 1:          # the earlier launches' shares are already in
+                    partial_weight_grads(0, last)
+                    g[name + '/b_hh'].copy_(g[name + '/b_ih'])
+                    return
                 torch.mm(dxw2d.t(), x.view(rows, -1),
                          out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
-                hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
                 # gradient w.r.t. the recurrent pre-activations: dxw itself, except for the GRU
                 drec = dxw
                 if cell == 'gru':
@@ -565,10 +612,13 @@ class CTCModel:
             deferred.append(name)
             if dy_below is not None:
                 dy = dy_below
-        if side is not main:
-            main.wait_stream(side)
-        for name in deferred:
-            done(name)
+        # The deferred layers' gradients are final once the side stream has drained.  Their hooks
+        # run with the side stream current, so a bucketed all-reduce launched from them is ordered
+        # after the weight-gradient GEMMs without the main stream having to wait: the front-end
+        # backward below overlaps the side stream's tail.
+        with torch.cuda.stream(side):
+            for name in deferred:
+                done(name)
 
         # front-end
         if cfg.used_model == 'ds2':
@@ -606,6 +656,8 @@ class CTCModel:
                 if i > 0:
                     dact = torch.mm(dz, p[name + '/kernel'].t())
                 done(name)
+        if side is not main:
+            main.wait_stream(side)
 
     def forward_backward(self, features, feature_len, labels, reduce_hook=None, check=True):
         """One training forward + backward; returns the mean CTC loss (device scalar)."""

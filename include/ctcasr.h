@@ -51,8 +51,12 @@ typedef void *ctcasr_stream_t;
 int ctcasr_abi_version(void);
 /* Process-wide switches.  "rnn_bwd_half_chip" (0/1, default 1): run the persistent backward
  * recurrence on 128 of the 256 CUs (weights split between LDS and registers) so that GEMMs
- * launched on another stream can overlap it; 0 selects the whole-chip variant. */
+ * launched on another stream can overlap it; 0 selects the whole-chip variant.
+ * "rnn_kernel_events" (0/1, default 0): record a HIP event pair on the launch stream around every
+ * persistent recurrence kernel; ctcasr_rnn_kernel_events() waits for them, returns launch counts
+ * and summed durations ([0] forward, [1] backward) and clears the record (benchmarking). */
 int ctcasr_set_option(const char *name, int value);
+int ctcasr_rnn_kernel_events(int launches[2], double total_ms[2]);
 const char *ctcasr_error_string(int code);
 
 /* ---- K8: (log-)softmax over the class axis ------------------------------------------------
@@ -138,6 +142,17 @@ int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_
                    const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                    const void *reserve, float *dxw, float *db_hh_n, void *workspace,
                    size_t workspace_bytes, ctcasr_stream_t stream);
+/* Steps [step_begin, step_end) of the backward recurrence only (it walks the steps downwards;
+ * step s is time s of the forward direction and time seq_len-1-s of the backward direction).
+ * ctcasr_rnn_bwd == (0, T).  A pass may be cut into launches covering T..0 in descending order
+ * on the same workspace, e.g. (T/2, T) then (0, T/2): after a launch, dxw of the steps it
+ * covered is final, so their share of the weight-gradient GEMMs can run on another stream while
+ * the next launch continues the recurrence. */
+int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y, const float *w_hh_t,
+                         const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
+                         const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                         size_t workspace_bytes, int step_begin, int step_end,
+                         ctcasr_stream_t stream);
 
 /* ---- fused dense / conv epilogues (tf.layers.dense + ReLU + tf.minimum(., relu_cutoff) +
  * tf.layers.dropout: asr/util/tf_contrib.py:50-61,122-135, asr/model.py:219-225) --------------

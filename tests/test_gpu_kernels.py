@@ -171,6 +171,20 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
     dxw = hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, workspace=ws)
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert np.abs(dxw.cpu().numpy() - xw_t.grad.numpy()).max() < 1e-4
+    # the same pass cut into three launches (ctcasr_rnn_bwd_steps) is bit-identical
+    if num_steps >= 5:
+        cuts = [num_steps, num_steps - 2, num_steps // 2, 0]
+        dxw_cut = torch.full_like(dxw, float('nan'))
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, dxw=dxw_cut, workspace=ws,
+                        steps=(lo, hi))
+        hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
+        assert torch.equal(dxw_cut, dxw)
+        with pytest.raises(ValueError):
+            hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, steps=(0, 2))
+        with pytest.raises(RuntimeError):
+            hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, dxw=dxw_cut, workspace=ws,
+                        steps=(3, 3))
     if cell == 'gru' and not use_len:
         # dW_hh is a GEMM of drec (dxw with the candidate gate scaled by r) and h_{t-1}
         drec = hip.rnn_gru_drec(reserve, num_steps, batch, hidden).cpu().double()

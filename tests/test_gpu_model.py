@@ -40,8 +40,26 @@ def _setup(case, seed=0, batch=3, frames=61, hidden=64, dense=32, layers=2):
 
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_logits_loss_and_gradients(case):
-    cfg, flat, feats, flen, labels = _setup(case)
+    _check_logits_loss_and_gradients(case)
+
+
+@pytest.mark.parametrize('chunks', [1, 3])
+def test_gradients_through_the_persistent_recurrence(chunks):
+    """H = 1024 LSTM layers take the LDS-resident kernels; with ``bwd_chunks`` > 1 the backward
+    recurrence is cut into launches and the weight gradients are accumulated range by range on
+    the side stream.  Same bars as the small cases."""
+    model = _check_logits_loss_and_gradients('ds2_lstm_2conv', bwd_chunks=chunks, hidden=1024,
+                                             frames=95, batch=2)
+    from ctc_asr_amd import hip
+    assert hip.rnn_persistent_supported('lstm', 48, 2, 1024)
+    hip.rnn_poll_error('lstm', model._acts['rnn_ws'], 48, 2, 1024)
+
+
+def _check_logits_loss_and_gradients(case, bwd_chunks=None, **setup):
+    cfg, flat, feats, flen, labels = _setup(case, **setup)
     model = CTCModel(cfg, 'cuda', params=flat)
+    if bwd_chunks is not None:
+        model.bwd_chunks = bwd_chunks
     logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
     loss = model.loss_fn(logits, seq_len, labels)
     model.backward()
@@ -76,6 +94,7 @@ def test_logits_loss_and_gradients(case):
         ref_g = ref_g.numpy()
         err = np.abs(got[name] - ref_g).max()
         assert err < 1e-3 * max(1.0, np.abs(ref_g).max()), (name, err)
+    return model
 
 
 def test_training_steps_track_the_oracle():

@@ -42,6 +42,34 @@ def main(path, top=40, last_steps=0):
 
 
 
+def timeline(path):
+    """Launch-ordered timeline of the last training step: start offset, duration, queue, gap to
+    the previous kernel of the same queue.  Shows where a stream idles."""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute('pragma table_info(kernels)')]
+    name_col = 'name' if 'name' in cols else 'kernel_name'
+    queue_col = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols
+                                                      else 'tid')
+    ends = [r[0] for r in cur.execute(
+        "select end from kernels where {n} like '%adam_kernel%' order by end".format(n=name_col))]
+    t0, t1 = ends[-2], ends[-1]
+    rows = cur.execute('select start, end, {q}, {n} from kernels where start > ? and end <= ? '
+                       'order by start'.format(q=queue_col, n=name_col), (t0, t1)).fetchall()
+    last_end = {}
+    busy = {}
+    print('step wall {:.3f} ms; columns: start us | dur us | queue | gap us | kernel'.format(
+        (t1 - t0) / 1e6))
+    for start, end, queue, name in rows:
+        gap = (start - last_end.get(queue, t0)) / 1e3
+        last_end[queue] = end
+        busy[queue] = busy.get(queue, 0) + end - start
+        print('{:9.1f} {:8.1f} {:>4} {:7.1f}  {}'.format((start - t0) / 1e3, (end - start) / 1e3,
+                                                       queue, gap, name[:70]))
+    for queue, total in busy.items():
+        print('queue {}: busy {:.3f} ms'.format(queue, total / 1e6))
+
+
 def pmc(path, top=12):
     """Per-kernel average of every collected PMC counter (rocprofv3 --pmc ... --kernel-trace)."""
     con = sqlite3.connect(path)
@@ -56,7 +84,9 @@ def pmc(path, top=12):
 
 
 if __name__ == '__main__':
-    if sys.argv[1] == '--pmc':
+    if sys.argv[1] == '--timeline':
+        timeline(sys.argv[2])
+    elif sys.argv[1] == '--pmc':
         pmc(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 12)
     else:
         main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40,

@@ -23,6 +23,7 @@ _c_f, _c_p, _c_sz = ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     'ctcasr_abi_version': (_c_int, []),
     'ctcasr_error_string': (ctypes.c_char_p, [_c_int]),
+    'ctcasr_crc32c': (ctypes.c_uint32, [_c_p, _c_sz, ctypes.c_uint32]),
     'ctcasr_set_option': (_c_int, [ctypes.c_char_p, _c_int]),
     'ctcasr_rnn_kernel_events': (_c_int, [_c_p, _c_p]),
     'ctcasr_log_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
@@ -145,6 +146,16 @@ def _workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------
+def crc32c(data, crc=0):
+    """CRC-32C of a bytes-like object / contiguous numpy array in host memory."""
+    view = memoryview(data).cast('B')
+    if len(view) == 0:
+        return int(crc)
+    buf = (ctypes.c_char * len(view)).from_buffer_copy(view) if view.readonly \
+        else (ctypes.c_char * len(view)).from_buffer(view)
+    return int(load().ctcasr_crc32c(ctypes.addressof(buf), len(view), int(crc)))
+
+
 def set_option(name, value):
     _check(load().ctcasr_set_option(name.encode(), int(value)), 'set_option')
 

@@ -1,13 +1,21 @@
 """Checkpoints in ``FLAGS.train_dir`` with the reference's semantics: implicit resume from the
 latest checkpoint, ``--delete`` wipes the directory first, the newest 5 are kept
 (``asr/train.py:23,31-42``, ``asr/util/storage.py:88-108``; the reference delegates the format
-to ``tf.estimator``, here it is a ``torch.save`` of the flat arenas)."""
+to ``tf.estimator``, here it is a ``torch.save`` of the flat arenas).
+
+`export_tf_checkpoint` / `import_tf_checkpoint` additionally write / read the variables in
+TensorFlow's own checkpoint format (``model.ckpt-<step>.index`` + ``.data-00000-of-00001`` +
+``checkpoint``; `tf_bundle`, names and layouts from `tf_names`), so that the same weights can be
+loaded by the reference and by this package."""
 
 import glob
 import os
 import shutil
 
+import numpy as np
 import torch
+
+from ctc_asr_amd import tf_bundle, tf_names
 
 KEEP_CHECKPOINT_MAX = 5
 
@@ -58,3 +66,34 @@ def restore_checkpoint(path, model):
     model.step_count = int(state['step'])
     model.dropout_seed = int(state['dropout_seed'])
     return int(state['epoch'])
+
+
+def export_tf_checkpoint(train_dir, arena, cfg, global_step):
+    """Write the parameters of ``arena`` (a `ParamArena`) as a TensorFlow checkpoint
+    ``<train_dir>/model.ckpt-<global_step>`` and point ``<train_dir>/checkpoint`` at it.
+    Optimizer slots are not written (the reference's cuDNN layers keep theirs as opaque
+    blobs); returns the checkpoint prefix."""
+    os.makedirs(train_dir, exist_ok=True)
+    variables = tf_names.to_tf_variables(arena.export(), cfg)
+    variables['global_step'] = np.array(int(global_step), dtype=np.int64)
+    name = 'model.ckpt-{}'.format(int(global_step))
+    prefix = os.path.join(train_dir, name)
+    tf_bundle.write_bundle(prefix, variables)
+    tf_bundle.write_checkpoint_state(train_dir, name)
+    return prefix
+
+
+def import_tf_checkpoint(path, arena, cfg):
+    """Load the model variables of a TensorFlow checkpoint (a prefix, or a directory holding a
+    ``checkpoint`` file) into ``arena``; Adam moments restart at zero.  Returns global_step.
+    Optimizer slot variables (``.../Adam``, ``beta1_power`` ...) in the file are ignored."""
+    prefix = tf_bundle.latest_checkpoint(path) if os.path.isdir(path) else path
+    if prefix is None or not os.path.isfile(prefix + '.index'):
+        raise ValueError('No TensorFlow checkpoint at {}'.format(path))
+    present = tf_bundle.list_bundle(prefix)
+    wanted = [n for n in present if '/Adam' not in n and not n.startswith('beta')]
+    variables = tf_bundle.read_bundle(prefix, wanted)
+    arena.load(tf_names.from_tf_variables(variables, cfg))
+    arena.m.zero_()
+    arena.v.zero_()
+    return int(variables['global_step']) if 'global_step' in variables else 0

@@ -10,12 +10,13 @@ i.e. SortaGrad for a length-sorted manifest) -> dev evaluation -> epochs 2..max_
 """
 
 import math
+import os
 import sys
 import time
 
 import torch
 
-from ctc_asr_amd import storage
+from ctc_asr_amd import storage, tf_bundle
 from ctc_asr_amd.engine import Trainer, init_distributed
 from ctc_asr_amd.evaluate import evaluate_dataset
 from ctc_asr_amd.input_functions import input_fn_generator
@@ -76,6 +77,12 @@ def main(argv=None):
         if rank == 0:
             print('Restored {} (step {:,d}); continuing with epoch {}.'.format(
                 latest, model.step_count, start_epoch))
+    elif tf_bundle.latest_checkpoint(FLAGS.train_dir) is not None:
+        # a train_dir written by the reference (tf.estimator): take its variables over
+        model.step_count = storage.import_tf_checkpoint(FLAGS.train_dir, model.arena, cfg)
+        if rank == 0:
+            print('Imported TensorFlow checkpoint {} (global_step {:,d}).'.format(
+                tf_bundle.latest_checkpoint(FLAGS.train_dir), model.step_count))
 
     for epoch in range(start_epoch, FLAGS.max_epochs + 1):
         target = 'train_batch' if epoch == 1 else 'train_bucket'
@@ -84,6 +91,8 @@ def main(argv=None):
         train_epoch(trainer, target, epoch, rank, world)
         if rank == 0:
             storage.save_checkpoint(FLAGS.train_dir, model, epoch)
+            if os.environ.get('CTCASR_EXPORT_TF_CHECKPOINT') == '1':
+                storage.export_tf_checkpoint(FLAGS.train_dir, model.arena, cfg, model.step_count)
         result = evaluate_dataset(model, 'dev', rank, world)
         if rank == 0:
             print('Evaluation result after epoch {}: {}'.format(epoch, result))

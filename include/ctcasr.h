@@ -58,6 +58,9 @@ int ctcasr_abi_version(void);
 int ctcasr_set_option(const char *name, int value);
 int ctcasr_rnn_kernel_events(int launches[2], double total_ms[2]);
 const char *ctcasr_error_string(int code);
+/* CRC-32C (Castagnoli) of a HOST buffer, chained through `crc` (0 to start): the checksum of
+ * TensorFlow's tensor-bundle checkpoint files (ctc_asr_amd/tf_bundle.py). */
+uint32_t ctcasr_crc32c(const void *data, size_t size, uint32_t crc);
 
 /* ---- K8: (log-)softmax over the class axis ------------------------------------------------
  * Replaces the softmax inside tf.nn.ctc_loss / ctc_beam_search_decoder (asr/model.py:259,292).

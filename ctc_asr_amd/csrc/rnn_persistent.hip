@@ -123,6 +123,10 @@ __device__ __forceinline__ void dir_arrive(SyncWords *sy, int dir, int grp, int 
 
 // Wait until every workgroup of this direction has posted arrival number `step` (0-based).
 // Only wave 0 polls (8 lanes, one counter each): more pollers measurably slow the arrivals down.
+// (One flag word per workgroup - a plain write-through store instead of the atomic, every poller
+// reading all 128 flags - was measured too: 5.4 / 7.6 us per step against 5.3 / 7.2.  So was
+// running the forward pass as 2 x 256 four-unit workgroups, two per CU, so that one's MFMAs
+// overlap the other's barrier: the barrier over twice as many arrivals costs 4 us, 7.5 us/step.)
 // On timeout the error word is raised and the workgroup carries on with whatever it reads
 // (results are invalid, the host reports CTCASR_ERR_TIMEOUT) so that no barrier is abandoned.
 __device__ __forceinline__ void dir_wait(SyncWords *sy, int dir, int group_size, unsigned step,
@@ -677,10 +681,10 @@ int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_flo
     const bool record = g_kernel_events && g_timed.size() < 65536 &&
                         hipEventCreate(&timed.start) == hipSuccess &&
                         hipEventCreate(&timed.stop) == hipSuccess;
-    if (record) hipEventRecord(timed.start, s);
+    if (record) (void)hipEventRecord(timed.start, s);
     kernel<<<2 * p.nwg, PRNN_THREADS, lds, s>>>(p);
     if (record) {
-        hipEventRecord(timed.stop, s);
+        (void)hipEventRecord(timed.stop, s);
         timed.backward = p.dxw != nullptr;
         g_timed.push_back(timed);
     }
@@ -705,8 +709,8 @@ extern "C" int ctcasr_rnn_kernel_events(int *launches, double *total_ms) {
         } else {
             rc = CTCASR_ERR_LAUNCH;
         }
-        hipEventDestroy(t.start);
-        hipEventDestroy(t.stop);
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
     }
     g_timed.clear();
     return rc;

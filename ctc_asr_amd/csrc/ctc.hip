@@ -78,22 +78,22 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
     return m + (double)__logf(s);
 }
 
-struct CtcLds {
-    double *lat[2];   // lattice ping-pong (alpha, then beta), [S]
-    int *ext;         // extended labels [S]
-    float *occ[2];    // per-class occupancy ping-pong [64]
-    float *logp;      // [len * C] when it fits
-};
-
+// One launch, grid (B, 2): workgroup (b, 0) runs the alpha sweep of utterance b, workgroup (b, 1)
+// its beta sweep - the two recursions are independent, each is a chain of `len` barrier-separated
+// steps (~0.8 us per step), and B workgroups leave the chip empty anyway.  Both lattices go to
+// HBM (fp64 [T, S]); ctc_grad_kernel then forms the per-class occupancies and the gradient for
+// every (t, b) in parallel.
 template <bool LOGP_IN_LDS>
 __global__ void __launch_bounds__(CTC_THREADS)
-ctc_loss_kernel(const float *__restrict__ logits, const int *__restrict__ labels,
-                const int *__restrict__ label_offsets, const int *__restrict__ seq_len, int T,
-                int B, int C, int blank, int s_pad, float grad_scale, float *__restrict__ loss,
-                float *__restrict__ grad, int *__restrict__ status,
-                double *__restrict__ alpha_ws, float *__restrict__ logp_ws) {
+ctc_sweep_kernel(const float *__restrict__ logits, const int *__restrict__ labels,
+                 const int *__restrict__ label_offsets, const int *__restrict__ seq_len, int T,
+                 int B, int C, int blank, int s_pad, float *__restrict__ loss,
+                 float *__restrict__ grad, int *__restrict__ status,
+                 double *__restrict__ alpha_ws, double *__restrict__ beta_ws,
+                 double *__restrict__ logpzx_ws, float *__restrict__ logp_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
+    const bool beta_sweep = blockIdx.y == 1;
     const int tid = threadIdx.x;
     const int L = label_offsets[b + 1] - label_offsets[b];
     const int S = 2 * L + 1;
@@ -103,14 +103,11 @@ ctc_loss_kernel(const float *__restrict__ logits, const int *__restrict__ labels
     double *lat0 = reinterpret_cast<double *>(smem);
     double *lat1 = lat0 + s_pad;
     int *ext = reinterpret_cast<int *>(lat1 + s_pad);
-    float *occ0 = reinterpret_cast<float *>(ext + s_pad);
-    float *occ1 = occ0 + 64;
-    int *flags = reinterpret_cast<int *>(occ1 + 64);   // [0] bad label, [1] adjacent repeats
+    int *flags = reinterpret_cast<int *>(ext + s_pad);   // [0] bad label, [1] adjacent repeats
     float *logp_s = reinterpret_cast<float *>(flags + 4);
-    float *logp = LOGP_IN_LDS ? logp_s : logp_ws + (size_t)b * T * C;
+    float *logp = LOGP_IN_LDS ? logp_s : logp_ws + ((size_t)blockIdx.y * B + b) * T * C;
 
     if (tid < 4) flags[tid] = 0;
-    if (tid < 64) { occ0[tid] = 0.f; occ1[tid] = 0.f; }
     __syncthreads();
     for (int u = tid; u < S; u += CTC_THREADS) {
         int sym = blank;
@@ -127,21 +124,18 @@ ctc_loss_kernel(const float *__restrict__ logits, const int *__restrict__ labels
     else if (len < L + flags[1]) st = 1;
     const int live = st == 0 ? len : 0;
 
-    // gradient rows that carry no signal (beyond seq_len, or the whole utterance on error)
-    for (int i = tid; i < (T - live) * C; i += CTC_THREADS) {
-        int t = live + i / C, c = i % C;
-        grad[((size_t)t * B + b) * C + c] = 0.f;
+    if (!beta_sweep) {
+        // gradient rows that carry no signal (beyond seq_len, or the whole utterance on error)
+        for (int i = tid; i < (T - live) * C; i += CTC_THREADS) {
+            int t = live + i / C, c = i % C;
+            grad[((size_t)t * B + b) * C + c] = 0.f;
+        }
+        if (tid == 0 && st != 0) { status[b] = st; loss[b] = INFINITY; }
+        if (tid == 0 && st == 0 && len == 0) { status[b] = 0; loss[b] = 0.f; }
     }
-    if (st != 0) {
-        if (tid == 0) { status[b] = st; loss[b] = INFINITY; }
-        return;
-    }
-    if (len == 0) {
-        if (tid == 0) { status[b] = 0; loss[b] = 0.f; }
-        return;
-    }
+    if (st != 0 || len == 0) return;
 
-    // ---- phase 0: per-utterance log-softmax table ------------------------------------------
+    // ---- per-utterance log-softmax table -----------------------------------------------------
     for (int t = tid; t < len; t += CTC_THREADS) {
         const float *row = logits + ((size_t)t * B + b) * C;
         float mx = row[0];
@@ -153,8 +147,6 @@ ctc_loss_kernel(const float *__restrict__ logits, const int *__restrict__ labels
     }
     __syncthreads();
 
-    // ---- phase 1: alpha ----------------------------------------------------------------------
-    double *aw = alpha_ws + (size_t)b * T * s_pad;
     int my_ext[CTC_MAX_PER_THREAD];
     bool skip_ok[CTC_MAX_PER_THREAD];   // may take the u-2 -> u (alpha) transition
     bool skip_fw[CTC_MAX_PER_THREAD];   // may take the u -> u+2 (beta) transition
@@ -165,100 +157,135 @@ ctc_loss_kernel(const float *__restrict__ logits, const int *__restrict__ labels
         skip_ok[i] = u < S && u >= 2 && ext[u] != blank && ext[u] != ext[u - 2];
         skip_fw[i] = u + 2 < S && ext[u + 2] != blank && ext[u + 2] != ext[u];
     }
+
+    if (!beta_sweep) {
+        // ---- alpha ---------------------------------------------------------------------------
+        double *aw = alpha_ws + (size_t)b * T * s_pad;
+#pragma unroll
+        for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+            int u = tid + i * CTC_THREADS;
+            if (u < S) {
+                double v = u == 0 ? (double)logp[blank]
+                                  : (u == 1 ? (double)logp[my_ext[i]] : -INFINITY);
+                lat0[u] = v;
+                aw[u] = v;
+            }
+        }
+        __syncthreads();
+        for (int t = 1; t < len; ++t) {
+            double *cur = (t & 1) ? lat1 : lat0;
+            const double *prev = (t & 1) ? lat0 : lat1;
+            const float *lp = logp + t * C;
+#pragma unroll
+            for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
+                int u = tid + i * CTC_THREADS;
+                if (u < S) {
+                    double a0 = prev[u];
+                    double a1 = u >= 1 ? prev[u - 1] : -INFINITY;
+                    double a2 = skip_ok[i] ? prev[u - 2] : -INFINITY;
+                    double v = lse3(a0, a1, a2);
+                    if (v != -INFINITY) v += (double)lp[my_ext[i]];
+                    cur[u] = v;
+                    aw[(size_t)t * s_pad + u] = v;
+                }
+            }
+            __syncthreads();
+        }
+        const double *fin = ((len - 1) & 1) ? lat1 : lat0;
+        const double log_pzx = lse3(fin[S - 1], S > 1 ? fin[S - 2] : -INFINITY, -INFINITY);
+        if (tid == 0) { status[b] = 0; loss[b] = (float)(-log_pzx); logpzx_ws[b] = log_pzx; }
+        return;
+    }
+
+    // ---- beta: beta(t, u) excludes the emission at t, so alpha + beta is the joint log-prob ----
+    double *bw = beta_ws + (size_t)b * T * s_pad;
 #pragma unroll
     for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
         int u = tid + i * CTC_THREADS;
         if (u < S) {
-            double v = u == 0 ? (double)logp[blank] : (u == 1 ? (double)logp[my_ext[i]] : -INFINITY);
+            const double v = (u >= S - 2) ? 0.0 : -INFINITY;
             lat0[u] = v;
-            aw[u] = v;
+            bw[(size_t)(len - 1) * s_pad + u] = v;
         }
-    }
-    __syncthreads();
-    for (int t = 1; t < len; ++t) {
-        double *cur = (t & 1) ? lat1 : lat0;
-        const double *prev = (t & 1) ? lat0 : lat1;
-        const float *lp = logp + t * C;
-#pragma unroll
-        for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
-            int u = tid + i * CTC_THREADS;
-            if (u < S) {
-                double a0 = prev[u];
-                double a1 = u >= 1 ? prev[u - 1] : -INFINITY;
-                double a2 = skip_ok[i] ? prev[u - 2] : -INFINITY;
-                double v = lse3(a0, a1, a2);
-                if (v != -INFINITY) v += (double)lp[my_ext[i]];
-                cur[u] = v;
-                aw[(size_t)t * s_pad + u] = v;
-            }
-        }
-        __syncthreads();
-    }
-    const double *fin = ((len - 1) & 1) ? lat1 : lat0;
-    const double log_pzx = lse3(fin[S - 1], S > 1 ? fin[S - 2] : -INFINITY, -INFINITY);
-    __syncthreads();
-    if (tid == 0) { status[b] = 0; loss[b] = (float)(-log_pzx); }
-
-    // ---- phase 2: beta sweep, occupancy and gradient -------------------------------------------
-    // beta(t, u) excludes the emission at t, so alpha + beta is the joint log-probability.
-#pragma unroll
-    for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
-        int u = tid + i * CTC_THREADS;
-        if (u < S) lat0[u] = (u >= S - 2) ? 0.0 : -INFINITY;
-    }
-    double a_pre[CTC_MAX_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
-        int u = tid + i * CTC_THREADS;
-        a_pre[i] = u < S ? aw[(size_t)(len - 1) * s_pad + u] : -INFINITY;
     }
     __syncthreads();
     int phase = 0;
-    for (int t = len - 1; t >= 0; --t, phase ^= 1) {
+    for (int t = len - 1; t > 0; --t, phase ^= 1) {
         const double *cur = phase ? lat1 : lat0;
         double *nxt = phase ? lat0 : lat1;
-        float *occ = phase ? occ1 : occ0;
         const float *lp = logp + t * C;
-        double a_now[CTC_MAX_PER_THREAD];
-#pragma unroll
-        for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
-            a_now[i] = a_pre[i];
-            int u = tid + i * CTC_THREADS;
-            if (t > 0 && u < S) a_pre[i] = aw[(size_t)(t - 1) * s_pad + u];   // prefetch
-        }
 #pragma unroll
         for (int i = 0; i < CTC_MAX_PER_THREAD; ++i) {
             int u = tid + i * CTC_THREADS;
             if (u < S) {
-                double bu = cur[u];
-                double joint = a_now[i] + bu;
-                if (joint != -INFINITY && log_pzx != -INFINITY)
-                    atomicAdd(&occ[my_ext[i]], expf((float)(joint - log_pzx)));
-                if (t > 0) {
-                    double b0 = bu + (double)lp[my_ext[i]];
-                    double b1 = u + 1 < S ? cur[u + 1] + (double)lp[ext[u + 1]] : -INFINITY;
-                    double b2 = skip_fw[i] ? cur[u + 2] + (double)lp[ext[u + 2]] : -INFINITY;
-                    nxt[u] = lse3(b0, b1, b2);
-                }
+                double b0 = cur[u] + (double)lp[my_ext[i]];
+                double b1 = u + 1 < S ? cur[u + 1] + (double)lp[ext[u + 1]] : -INFINITY;
+                double b2 = skip_fw[i] ? cur[u + 2] + (double)lp[ext[u + 2]] : -INFINITY;
+                const double v = lse3(b0, b1, b2);
+                nxt[u] = v;
+                bw[(size_t)(t - 1) * s_pad + u] = v;
             }
         }
         __syncthreads();
-        if (tid < C) {
-            float g = expf(lp[tid]) - occ[tid];
-            occ[tid] = 0.f;
-            grad[((size_t)t * B + b) * C + tid] = g * grad_scale;
-        }
     }
 }
 
-static size_t ctc_alpha_bytes(int T, int B, int max_label_len) {
+// Gradient w.r.t. the logits: one wave per (t, b).  occ[k] = sum over extended labels u with
+// l'[u] = k of exp(alpha(t,u) + beta(t,u) - ln p(l|x)); grad = (softmax(t,k) - occ[k]) * scale.
+#define CTC_GRAD_WAVES 4
+__global__ void __launch_bounds__(64 * CTC_GRAD_WAVES)
+ctc_grad_kernel(const float *__restrict__ logits, const int *__restrict__ labels,
+                const int *__restrict__ label_offsets, const int *__restrict__ seq_len, int T,
+                int B, int C, int blank, int s_pad, float grad_scale,
+                const int *__restrict__ status, const double *__restrict__ alpha_ws,
+                const double *__restrict__ beta_ws, const double *__restrict__ logpzx_ws,
+                float *__restrict__ grad) {
+    __shared__ float occ_s[CTC_GRAD_WAVES][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * CTC_GRAD_WAVES + wave;
+    if (status[b] != 0 || t >= seq_len[b]) return;     // those rows were zeroed by the sweep
+    float *occ = occ_s[wave];
+    occ[lane] = 0.f;
+    const int L = label_offsets[b + 1] - label_offsets[b];
+    const int S = 2 * L + 1;
+    const int *lab = labels + label_offsets[b];
+    const double log_pzx = logpzx_ws[b];
+    const double *aw = alpha_ws + ((size_t)b * T + t) * s_pad;
+    const double *bw = beta_ws + ((size_t)b * T + t) * s_pad;
+    if (log_pzx != -INFINITY) {
+        for (int u = lane; u < S; u += 64) {
+            const double joint = aw[u] + bw[u];
+            if (joint != -INFINITY)
+                atomicAdd(&occ[(u & 1) ? lab[u >> 1] : blank], expf((float)(joint - log_pzx)));
+        }
+    }
+    // softmax of the frame, as the table of the sweeps has it: exp(x - (max + log(sum)))
+    const float *row = logits + ((size_t)t * B + b) * C;
+    const float x = lane < C ? row[lane] : -INFINITY;
+    float mx = x;
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = lane < C ? expf(x - mx) : 0.f;
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float lz = mx + logf(sum);
+    // the wave's LDS atomics are ordered before this read (one in-order LDS queue per wave)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float occupied = *reinterpret_cast<volatile float *>(&occ[lane]);
+    if (lane < C)
+        grad[((size_t)t * B + b) * C + lane] = (expf(x - lz) - occupied) * grad_scale;
+}
+
+static size_t ctc_lattice_bytes(int T, int B, int max_label_len) {
     return ctcasr_align_up((size_t)B * T * (2 * (size_t)max_label_len + 1) * sizeof(double), 256);
 }
 
 extern "C" size_t ctcasr_ctc_loss_workspace_bytes(int T, int B, int C, int max_label_len) {
     if (T <= 0 || B <= 0 || C <= 0 || max_label_len < 0) return 0;
-    return ctc_alpha_bytes(T, B, max_label_len) +
-           ctcasr_align_up((size_t)B * T * C * sizeof(float), 256);
+    // alpha, beta lattices; ln p(l|x) per utterance; log-softmax tables of the two sweeps
+    return 2 * ctc_lattice_bytes(T, B, max_label_len) +
+           ctcasr_align_up((size_t)B * sizeof(double), 256) +
+           ctcasr_align_up((size_t)2 * B * T * C * sizeof(float), 256);
 }
 
 extern "C" int ctcasr_ctc_loss_fwd_bwd(const float *logits, const int32_t *labels,
@@ -276,29 +303,37 @@ extern "C" int ctcasr_ctc_loss_fwd_bwd(const float *logits, const int32_t *label
     if (s_pad > CTC_THREADS * CTC_MAX_PER_THREAD) return CTCASR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ctcasr_ctc_loss_workspace_bytes(T, B, C, max_label_len))
         return CTCASR_ERR_WORKSPACE;
-    double *alpha_ws = reinterpret_cast<double *>(workspace);
-    float *logp_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
-                                               ctc_alpha_bytes(T, B, max_label_len));
-    const size_t fixed = (size_t)s_pad * (2 * sizeof(double) + sizeof(int)) +
-                         128 * sizeof(float) + 4 * sizeof(int);
+    char *ws = reinterpret_cast<char *>(workspace);
+    const size_t lattice = ctc_lattice_bytes(T, B, max_label_len);
+    double *alpha_ws = reinterpret_cast<double *>(ws);
+    double *beta_ws = reinterpret_cast<double *>(ws + lattice);
+    double *logpzx_ws = reinterpret_cast<double *>(ws + 2 * lattice);
+    float *logp_ws = reinterpret_cast<float *>(ws + 2 * lattice +
+                                               ctcasr_align_up((size_t)B * sizeof(double), 256));
+    const size_t fixed = (size_t)s_pad * (2 * sizeof(double) + sizeof(int)) + 4 * sizeof(int);
     const size_t table = (size_t)T * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    const dim3 sweeps(B, 2);
     if (fixed + table <= 150 * 1024) {
         size_t lds = fixed + table;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&ctc_loss_kernel<true>),
+                reinterpret_cast<const void *>(&ctc_sweep_kernel<true>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return CTCASR_ERR_LAUNCH;
         }
-        ctc_loss_kernel<true><<<B, CTC_THREADS, lds, s>>>(
-            logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, grad_scale, loss,
-            grad_logits, status, alpha_ws, logp_ws);
+        ctc_sweep_kernel<true><<<sweeps, CTC_THREADS, lds, s>>>(
+            logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, loss, grad_logits,
+            status, alpha_ws, beta_ws, logpzx_ws, logp_ws);
     } else {
-        ctc_loss_kernel<false><<<B, CTC_THREADS, fixed, s>>>(
-            logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, grad_scale, loss,
-            grad_logits, status, alpha_ws, logp_ws);
+        ctc_sweep_kernel<false><<<sweeps, CTC_THREADS, fixed, s>>>(
+            logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, loss, grad_logits,
+            status, alpha_ws, beta_ws, logpzx_ws, logp_ws);
     }
+    const dim3 rows((T + CTC_GRAD_WAVES - 1) / CTC_GRAD_WAVES, B);
+    ctc_grad_kernel<<<rows, 64 * CTC_GRAD_WAVES, 0, s>>>(
+        logits, labels, label_offsets, seq_len, T, B, C, blank, s_pad, grad_scale, status,
+        alpha_ws, beta_ws, logpzx_ws, grad_logits);
     return ctcasr_launch_status();
 }
 

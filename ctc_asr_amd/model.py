@@ -279,6 +279,7 @@ class CTCModel:
         # weight-gradient GEMMs run on a low-priority side stream so that they fill the half of
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
+        self.fuse_xw_bias = os.environ.get('CTCASR_FUSE_XW_BIAS', '1') == '1'
         self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
         # launch has finished run beside the next launch instead of queueing up behind the layer
@@ -369,10 +370,14 @@ class CTCModel:
                 seeds[0] = self._next_seed()
                 x = hip.dropout(x, rnn_rate, seeds[0])
             w_ih = p['rnn{}/w_ih'.format(i)].view(2 * gates * hidden, -1)
-            xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
             # biases that are plain additive terms are folded into xw (LSTM / RNN: both vectors;
-            # GRU: everything but the recurrent bias of the candidate gate)
-            hip.bias_act_fwd(xw, self._rnn_bias(i), 0.0)
+            # GRU: everything but the recurrent bias of the candidate gate) - as the GEMM's bias
+            # epilogue, which saves a read-modify-write pass over xw
+            if self.fuse_xw_bias:
+                xw = torch.addmm(self._rnn_bias(i), x.view(t_out * batch, -1), w_ih.t())
+            else:
+                xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
+                hip.bias_act_fwd(xw, self._rnn_bias(i), 0.0)
             y, reserve, workspace = hip.rnn_fwd(
                 cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
                 rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,

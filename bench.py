@@ -35,12 +35,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (conv_filters, rnn layers, hidden, dense, per-GPU batch, seconds)
-    'c2': ((32, 32), 2, 1024, 2048, 16, 10.0),           # BASELINE.json configs[1] (metric)
-    'c2_3conv': ((32, 32, 96), 2, 1024, 2048, 16, 10.0),  # same with the reference's 3 convs
-    'c3': ((32, 32), 5, 1024, 2048, 32, 10.0),            # configs[2]
-    'c3_3conv': ((32, 32, 96), 5, 1024, 2048, 32, 10.0),
-    'tiny': ((8, 8), 1, 128, 128, 4, 2.0),                # plumbing check
+    # name: (conv_filters, rnn layers, hidden, dense, per-GPU batch, seconds, rnn_cell)
+    'c2': ((32, 32), 2, 1024, 2048, 16, 10.0, 'lstm'),           # BASELINE.json configs[1] (metric)
+    'c2_3conv': ((32, 32, 96), 2, 1024, 2048, 16, 10.0, 'lstm'),  # with the reference's 3 convs
+    'c3': ((32, 32), 5, 1024, 2048, 32, 10.0, 'lstm'),            # configs[2]
+    'c3_3conv': ((32, 32, 96), 5, 1024, 2048, 32, 10.0, 'lstm'),
+    # the reference's own flag defaults (asr/params.py): 3 convs, 4 x ReLU-RNN-2048, batch 16
+    'ref_default': ((32, 32, 96), 4, 2048, 2048, 16, 10.0, 'rnn_relu'),
+    'tiny': ((8, 8), 1, 128, 128, 4, 2.0, 'lstm'),                # plumbing check
 }
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip table
@@ -168,9 +170,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = 'cuda:{}'.format(local_rank)
 
-    filters, layers, hidden, dense, batch, seconds = WORKLOADS[args.workload]
+    filters, layers, hidden, dense, batch, seconds, rnn_cell = WORKLOADS[args.workload]
     cfg = ModelConfig(used_model='ds2', conv_filters=filters, num_units_dense=dense,
-                      num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell='lstm', cudnn=True,
+                      num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell, cudnn=True,
                       dense_dropout_rate=args.dropout)
     # fixed input shape: let MIOpen benchmark its convolution kernels once (warm-up steps)
     trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True)
@@ -252,9 +254,9 @@ def main():
                 launch_steps = t_out * args.steps * cfg.num_layers_rnn / float(calls)
                 achieved = flops_per_step * launch_steps / avg_s / 1e12
                 roofline = {
-                    'kernel': 'prnn_{}_kernel<LSTM> (persistent, LDS-resident recurrent weights; '
+                    'kernel': 'prnn_{}_kernel<{}> (persistent, LDS-resident recurrent weights; '
                               'one launch = {:.0f} time steps x 2 directions)'.format(
-                                  dom[4:], launch_steps),
+                                  dom[4:], rnn_cell.upper(), launch_steps),
                     'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -270,7 +272,8 @@ def main():
                 avg_s = dom_ms * 1e-3 / launches
                 achieved_gbs = bytes_per_step / avg_s / 1e9
                 roofline = {
-                    'kernel': 'rnn_{}_step_kernel<LSTM> (one launch per time step)'.format(dom[4:]),
+                    'kernel': 'rnn_{}_step_kernel<{}> (one launch per time step)'.format(
+                        dom[4:], rnn_cell.upper()),
                     'bound': 'hbm', 'achieved': round(achieved_gbs, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(achieved_gbs / HBM_PEAK_GBS, 4),
                     'traffic': None, 'avg_launch_us': round(avg_s * 1e6, 3),
@@ -284,10 +287,13 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (16 kHz int16 Gaussian-noise PCM of fixed-length '
                                     'utterances resident in HBM, random labels at 15 chars/s)',
-            'config': {'workload': 'BASELINE.json configs[{}]: DS2 {}-conv + {}xBiLSTM-{}, '
+            'config': {'workload': '{}: DS2 {}-conv + {}xBi{}-{}, '
                                    'batch {}/GPU, {:.0f} s utterances'.format(
-                                       1 if args.workload.startswith('c2') else 2, len(filters),
-                                       layers, hidden, batch, seconds),
+                                       {'c2': 'BASELINE.json configs[1]',
+                                        'c3': 'BASELINE.json configs[2]'}.get(
+                                            args.workload, args.workload), len(filters), layers,
+                                       {'lstm': 'LSTM', 'rnn_relu': 'RNN(relu)'}[rnn_cell],
+                                       hidden, batch, seconds),
                        'name': args.workload, 'global_batch': world * batch, 'frames': frames,
                        'ctc_steps': t_out, 'parallelism': 'dp{}'.format(world),
                        'dense_dropout_rate': args.dropout,
@@ -301,7 +307,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             cfg_kwargs = dict(used_model='ds2', conv_filters=list(filters), num_units_dense=dense,
-                              num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell='lstm',
+                              num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell,
                               cudnn=True, dense_dropout_rate=0.0)
             result['cpu_baseline'] = cpu_baseline(cfg_kwargs, seconds, frames)
             if result['cpu_baseline']['value']:

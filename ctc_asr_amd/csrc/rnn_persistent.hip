@@ -283,6 +283,11 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                     if (i + 1 < QW)
                         nf[nt] = frag[(nt * Q + wave * QW + ((i + 1 + rot) & (QW - 1))) * 64 + lane];
                 }
+                // pin the order: next chunk's ds_reads, THEN this chunk's MFMAs (hipcc otherwise
+                // sinks each read to one or two MFMAs before its first use).  Measured: plain RNN
+                // (NT = 1, 4 MFMAs per read) 5.57 -> 5.28 us per step; LSTM (NT = 2, 8 MFMAs per
+                // pair of reads) 5.29 -> 5.39, so only the former is pinned.
+                if constexpr (NT == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (NT == 2) {
@@ -292,6 +297,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                         for (int nt = 0; nt < NT; ++nt) mma4(acc[mt][nt], a[mt][i], bf[nt]);
                     }
                 }
+                if constexpr (NT == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[nt] = nf[nt];
             }
@@ -534,28 +540,32 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                     }
             };
             issue(0, a[0]);
+            // B fragments (LDS / registers) run one PAIR of chunks ahead of the MFMAs that use
+            // them, across load batches too: a ds_read_b128 issued right before its consumers
+            // costs about as much as the pair's 8 MFMAs.  The scheduling barriers pin that
+            // order - hipcc otherwise sinks each read next to its first use.
+            auto bfrag = [&](int c) -> float4 {      // c: chunk index, compile-time after unrolling
+                if constexpr (REGW == 0) {
+                    return frag[(wave * QL + ((c + rot) & (QW - 1))) * SLOTS + half];
+                } else {
+                    return c < QL ? frag[(wave * QL + c) * SLOTS + half] : wreg[c - QL];
+                }
+            };
+            float4 cb0 = bfrag(0), cb1 = bfrag(1);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if (nb + 1 < NB) issue(nb + 1, a[(nb + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);   // loads stay above this batch's MFMAs
-                // B fragments (LDS) are fetched one pair of chunks ahead of the MFMAs that use
-                // them: an exposed ds_read_b128 per pair costs as much as the pair's 8 MFMAs
-                auto bfrag = [&](int i) -> float4 {
-                    if constexpr (REGW == 0) {
-                        return frag[(wave * QL + ((nb * LB + i + rot) & (QW - 1))) * SLOTS + half];
-                    } else {
-                        const int c = nb * LB + i;          // compile-time after unrolling
-                        return c < QL ? frag[(wave * QL + c) * SLOTS + half] : wreg[c - QL];
-                    }
-                };
-                float4 cb0 = bfrag(0), cb1 = bfrag(1);
 #pragma unroll
                 for (int i = 0; i < LB; i += 2) {
+                    const int c = nb * LB + i;
                     float4 nb0 = cb0, nb1 = cb1;
-                    if (i + 2 < LB) { nb0 = bfrag(i + 2); nb1 = bfrag(i + 3); }
+                    if (c + 2 < QW) { nb0 = bfrag(c + 2); nb1 = bfrag(c + 3); }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         mma4x2(acc[mt], acc2[mt], a[nb & 1][mt][i], cb0, a[nb & 1][mt][i + 1], cb1);
+                    __builtin_amdgcn_sched_barrier(0);
                     cb0 = nb0; cb1 = nb1;
                 }
             }

@@ -66,19 +66,23 @@ dropout_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n,
 }
 
 // dz = dy * [0 < y < cutoff / keep] / keep, and dbias[c] += column sums.
-// grid = (ceil(cols / 64), row chunks); each wave strides over the rows of its chunk.
+// grid = (ceil(cols / 64), row chunks); each wave strides over the rows of its chunk.  Narrow
+// matrices (cols divides 64: the conv channels, C = 32) pack 64 / cols rows into one wave access
+// so that every lane works and a wave still touches 256 contiguous bytes.
 __global__ void __launch_bounds__(256)
 bias_act_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
                     float *__restrict__ dz, float *__restrict__ dbias, int64_t rows, int cols,
                     float upper, float inv_keep, int64_t rows_per_block) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const bool narrow = cols < 64 && 64 % cols == 0;
+    const int rpw = narrow ? 64 / cols : 1;                  // rows per wave access
+    const int c = narrow ? lane % cols : blockIdx.x * 64 + lane;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float sum = 0.f;
     if (c < cols) {
-        for (int64_t r = r0 + wave; r < r1; r += 4) {
+        for (int64_t r = r0 + wave * rpw + (narrow ? lane / cols : 0); r < r1; r += 4 * rpw) {
             const int64_t i = r * cols + c;
             float g = dy[i];
             if (y) {
@@ -92,8 +96,12 @@ bias_act_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
     if (!dbias) return;
     part[wave][lane] = sum;
     __syncthreads();
-    if (wave == 0 && c < cols)
-        atomicAdd(&dbias[c], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+    if (wave == 0 && lane < (narrow ? cols : 64) && c < cols) {
+        float total = 0.f;
+        for (int j = lane; j < 64; j += narrow ? cols : 64)
+            total += part[0][j] + part[1][j] + part[2][j] + part[3][j];
+        atomicAdd(&dbias[c], total);
+    }
 }
 
 __global__ void __launch_bounds__(256)

@@ -638,17 +638,18 @@ class CTCModel:
             dact = dy.view(tt, b_, ff, c_).permute(1, 0, 2, 3).contiguous()
             for i in range(len(cfg.conv_filters) - 1, -1, -1):
                 name = 'conv{}'.format(i)
+                # the bias gradient (sum of dz over batch, time and frequency) falls out of the
+                # epilogue's backward pass: channels are the columns of the NHWC view
                 dz = hip.bias_act_bwd(conv_out[i].permute(0, 2, 3, 1), dact, cfg.relu_cutoff,
-                                      cfg.conv_dropout_rate)
+                                      cfg.conv_dropout_rate, g[name + '/bias'])
                 dz = dz.permute(0, 3, 1, 2)        # logical NCHW view of the NHWC storage
                 xp = acts['conv_in'][i]
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
-                dxp, dw, db = torch.ops.aten.convolution_backward(
+                dxp, dw, _ = torch.ops.aten.convolution_backward(
                     dz, xp, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
                     list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
-                    [i > 0, True, True])
+                    [i > 0, True, False])
                 g[name + '/kernel'].copy_(dw)
-                g[name + '/bias'].copy_(db)
                 if i > 0:
                     dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1] \
                         .permute(0, 2, 3, 1).contiguous()

@@ -195,7 +195,7 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
 
 def test_bias_act_and_colsum(hip):
     rng = np.random.default_rng(9)
-    for rows, cols in [(33, 29), (100, 64), (257, 96)]:
+    for rows, cols in [(33, 29), (100, 64), (257, 96), (1001, 32), (77, 16), (50, 8), (9, 2)]:
         z = (rng.normal(size=(rows, cols)) * 15).astype(np.float32)
         bias = rng.normal(size=cols).astype(np.float32)
         y = hip.bias_act_fwd(_t(z), _t(bias), 20.0)

@@ -200,6 +200,32 @@ def _group_batches(stream, use_buckets, boundaries, batch_size):
             yield buckets[key]
 
 
+def host_batches(csv_path, use_buckets, boundaries, rank=0, world_size=1, seed=None):
+    """Host side of one epoch for one rank: yields lists of (int16 PCM, label ids, label text).
+    Groups of ``world_size * batch_size`` utterances are formed exactly as a single process would
+    form them (every rank walks the same seeded order), a rank keeps its contiguous share and only
+    reads the WAV files of that share."""
+    rng = random.Random(seed) if (seed is not None or world_size > 1) else random.Random()
+    if world_size > 1 and seed is None:
+        rng = random.Random(FLAGS.random_seed or 1)
+    stream = _example_stream(csv_path, use_buckets, rng)
+    if use_buckets:
+        stream = _shuffle_buffer(stream, FLAGS.shuffle_buffer_size, rng)
+    groups = _group_batches(stream, use_buckets, boundaries, FLAGS.batch_size * world_size)
+    readers = ThreadPoolExecutor(max_workers=READER_THREADS)
+    try:
+        for group in groups:
+            part = group
+            if world_size > 1:
+                per_rank = len(group) // world_size
+                part = group[rank * per_rank:(rank + 1) * per_rank]
+            if part:
+                audio = list(readers.map(read_wav, [it[0] for it in part]))
+                yield [(pcm, it[1], it[2]) for pcm, it in zip(audio, part)]
+    finally:
+        readers.shutdown(wait=False)
+
+
 def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, prefetch=8):
     """Zero-argument ``input_fn`` for ``target`` in {'train_bucket', 'train_batch', 'dev', 'test'}
     (``asr/input_functions.py:21-56``).  Calling it returns an iterator of `Batch`.
@@ -223,28 +249,9 @@ def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, p
 
     def input_fn():
         assert os.path.exists(csv_path) and os.path.isfile(csv_path)
-        rng = random.Random(seed) if (seed is not None or world_size > 1) else random.Random()
-        if world_size > 1 and seed is None:
-            rng = random.Random(FLAGS.random_seed or 1)
-        stream = _example_stream(csv_path, use_buckets, rng)
-        if use_buckets:
-            stream = _shuffle_buffer(stream, FLAGS.shuffle_buffer_size, rng)
-        groups = _group_batches(stream, use_buckets, boundaries, FLAGS.batch_size * world_size)
-
-        def shard(group):
-            if world_size == 1:
-                return group
-            per_rank = len(group) // world_size
-            return group[rank * per_rank:(rank + 1) * per_rank]
-
-        readers = ThreadPoolExecutor(max_workers=READER_THREADS)
 
         def host_side():
-            for group in groups:
-                part = shard(group)
-                if part:
-                    audio = list(readers.map(read_wav, [it[0] for it in part]))
-                    yield [(pcm, it[1], it[2]) for pcm, it in zip(audio, part)]
+            return host_batches(csv_path, use_buckets, boundaries, rank, world_size, seed)
 
         if prefetch <= 0:
             for items in host_side():

@@ -112,3 +112,42 @@ def test_random_label_shape():
         assert '  ' not in text
     durations = synth.librispeech_like_durations(rng, 1000)
     assert durations.min() >= 0.7 and durations.max() <= 17.0 and 8.0 < durations.mean() < 14.0
+
+
+def test_data_parallel_ranks_share_each_group(tmp_path):
+    """world_size 2: at every step both ranks draw from the SAME group of 2 x batch_size
+    utterances (same bucket, so the padded time extent matches and nobody waits in the
+    all-reduce), keep disjoint halves, and together see exactly what one process would."""
+    FLAGS.reset()
+    durations = [0.7 + 0.05 * i for i in range(41)]
+    synth.write_corpus(str(tmp_path / 'corpus'), str(tmp_path / 'train.csv'), durations, seed=5,
+                       chars_per_second=5.0)
+    FLAGS.update(corpus_dir=str(tmp_path / 'corpus'), train_csv=str(tmp_path / 'train.csv'),
+                 batch_size=3, num_buckets=4, random_seed=11)
+    try:
+        from ctc_asr_amd.csv_helper import get_bucket_boundaries
+        boundaries = get_bucket_boundaries(FLAGS.train_csv, FLAGS.num_buckets)
+        for use_buckets in (True, False):
+            bounds = boundaries if use_buckets else []
+            ranks = [list(inp.host_batches(FLAGS.train_csv, use_buckets, bounds, rank, 2))
+                     for rank in (0, 1)]
+            assert len(ranks[0]) == len(ranks[1]) > 0
+            FLAGS.update(batch_size=6)          # what ONE process with the global batch forms
+            single = list(inp.host_batches(FLAGS.train_csv, use_buckets, bounds, 0, 1,
+                                           seed=FLAGS.random_seed))
+            FLAGS.update(batch_size=3)
+            assert len(single) >= len(ranks[0])
+            for step, (a, b) in enumerate(zip(*ranks)):
+                assert len(a) == len(b) <= 3
+                texts = [item[2] for item in a + b]
+                assert len(set(texts)) == len(texts)                 # disjoint halves
+                merged = [item[2] for item in single[step]]
+                assert texts == merged[:len(texts)]                  # same group, same order
+                for (pcm, ids, text), ref in zip(a + b, single[step]):
+                    assert np.array_equal(pcm, ref[0]) and ids == ref[1]
+                if use_buckets:     # one bucket per group
+                    keys = {np.searchsorted(boundaries, inp.num_frames(len(item[0])),
+                                            side='right') for item in a + b}
+                    assert len(keys) == 1
+    finally:
+        FLAGS.reset()

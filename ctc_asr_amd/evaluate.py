@@ -6,6 +6,7 @@ model in evaluation mode; reports the CTC loss and the two ``eval_metric_ops`` o
 batches of the per-batch mean.  Decoding is the CTC beam search of width ``FLAGS.beam_width``.
 """
 
+import os
 import sys
 
 import numpy as np
@@ -56,7 +57,8 @@ def main(argv=None):
     FLAGS.parse(sys.argv[1:] if argv is None else argv)
     if not torch.cuda.is_available():
         raise SystemExit('ctc_asr_amd.evaluate needs an MI355X; no GPU is visible.')
-    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=FLAGS.random_seed or 1)
+    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=FLAGS.random_seed or 1,
+                     conv_mode=os.environ.get('CTCASR_CONV_MODE', 'tiled'))
     latest = storage.latest_checkpoint(FLAGS.train_dir)
     if latest is None:
         raise SystemExit('No checkpoint found in {}.'.format(FLAGS.train_dir))

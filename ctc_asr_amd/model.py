@@ -254,7 +254,8 @@ class CTCModel:
     ``CTCModel`` with torch tensors in place of TensorFlow tensors; ``forward_backward`` /
     ``apply_gradients`` are the explicit counterparts of ``optimizer.minimize``."""
 
-    def __init__(self, cfg, device='cuda', seed=0, params=None, conv_autotune=None):
+    def __init__(self, cfg, device='cuda', seed=0, params=None, conv_autotune=None,
+                 conv_mode=None):
         hip.load()
         # MIOpen convolution selection.  Its default "find" benchmarks every solver the first
         # time a shape is seen: 3-6 s per new padded length (measured), which is fatal for
@@ -262,8 +263,25 @@ class CTCModel:
         # immediate (heuristic) mode.  Fixed-shape runs (bench.py) opt into autotuning, which
         # picks ~35 % faster kernels for the 11x21 stride-(1,2) layers:
         # `conv_autotune=True` or CTCASR_CONV_AUTOTUNE=1.
+        #
+        # `conv_mode='tiled'` (CTCASR_CONV_MODE) makes autotuning usable for variable-length
+        # batches: every convolution runs as calls of ONE fixed shape - the time axis is cut
+        # into tiles of `conv_tile_frames` output frames (+ the kernel's halo of input frames),
+        # tiles of all utterances are stacked on the batch axis and processed
+        # `conv_tile_batch` at a time (the last call zero-filled).  MIOpen then sees three
+        # shapes per layer for the whole run, whatever the padded length of a batch is.  With
+        # immediate mode on ever-changing shapes MIOpen falls back to im2col + batched GEMM
+        # (5 ms per call): 75 ms of convolutions per step instead of 4.
+        if conv_mode is None:
+            conv_mode = os.environ.get('CTCASR_CONV_MODE', 'direct')
+        if conv_mode not in ('direct', 'tiled'):
+            raise ValueError('conv_mode must be "direct" or "tiled"')
+        self.conv_mode = conv_mode
+        self.conv_tile_frames = int(os.environ.get('CTCASR_CONV_TILE_FRAMES', '128'))
+        self.conv_tile_batch = int(os.environ.get('CTCASR_CONV_TILE_BATCH', '32'))
         if conv_autotune is None:
-            conv_autotune = os.environ.get('CTCASR_CONV_AUTOTUNE', '0') == '1'
+            conv_autotune = os.environ.get('CTCASR_CONV_AUTOTUNE',
+                                           '1' if conv_mode == 'tiled' else '0') == '1'
         if conv_autotune:
             torch.backends.cudnn.benchmark = True
         else:
@@ -325,16 +343,20 @@ class CTCModel:
                 s_t, s_f = CONV_STRIDES[i]
                 _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
-                xp = torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1)) \
-                    .contiguous(memory_format=torch.channels_last)
-                y = torch.ops.aten.convolution(xp, self._conv_kernel_cl(i),
-                                               p['conv{}/bias'.format(i)], [s_t, s_f], [0, 0],
-                                               [1, 1], False, [0, 0], 1)
-                y = y.contiguous(memory_format=torch.channels_last)
+                if self.conv_mode == 'tiled':
+                    y, ctx = self._conv_fwd_tiled(i, x, (pt0, pt1, pf0, pf1))
+                    conv_in.append(ctx)
+                else:
+                    xp = torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1)) \
+                        .contiguous(memory_format=torch.channels_last)
+                    y = torch.ops.aten.convolution(xp, self._conv_kernel_cl(i),
+                                                   p['conv{}/bias'.format(i)], [s_t, s_f],
+                                                   [0, 0], [1, 1], False, [0, 0], 1)
+                    y = y.contiguous(memory_format=torch.channels_last)
+                    conv_in.append(xp)
                 # elementwise epilogue on the NHWC storage ([B, T, F, C] view of the same memory)
                 hip.bias_act_fwd(y.permute(0, 2, 3, 1), None, cfg.relu_cutoff,
                                  cfg.conv_dropout_rate, self._next_seed())
-                conv_in.append(xp)
                 conv_out.append(y)
                 pads.append((pt0, pt1, pf0, pf1))
                 x = y
@@ -400,6 +422,94 @@ class CTCModel:
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
         self._acts = acts
         return logits.view(t_out, batch, cfg.num_classes), seq_length
+
+    def _conv_tiling(self, layer, frames_in, pad_t):
+        """Tile geometry of conv ``layer`` for ``frames_in`` input frames: output frames,
+        tiles per utterance, input frames per tile (window), tile step, padded input length."""
+        k_t, s_t = CONV_KERNEL_SIZES[layer][0], CONV_STRIDES[layer][0]
+        t_out = (frames_in + pad_t[0] + pad_t[1] - k_t) // s_t + 1
+        tile = self.conv_tile_frames
+        n_tiles = -(-t_out // tile)
+        window = (tile - 1) * s_t + k_t
+        step = tile * s_t
+        assert window <= 2 * step, 'tiles of equal parity must not overlap'
+        need = (n_tiles * tile - 1) * s_t + k_t
+        return t_out, n_tiles, window, step, need
+
+    def _conv_fwd_tiled(self, layer, x, pads):
+        """SAME convolution + bias of one layer as fixed-shape calls (see ``conv_mode``).
+        ``x`` logical NCHW / physical NHWC.  Returns (y like the direct path, context)."""
+        p = self.arena.p
+        pt0, pt1, pf0, pf1 = pads
+        s_t, s_f = CONV_STRIDES[layer]
+        batch, c_in, frames, freq = x.shape
+        t_out, n_tiles, window, step, need = self._conv_tiling(layer, frames, (pt0, pt1))
+        fp = freq + pf0 + pf1
+        nfix = self.conv_tile_batch
+        total = batch * n_tiles
+        calls = -(-total // nfix)
+        # zero-padded input, physical NHWC, long enough for the last (partial) tile
+        xp = torch.zeros((batch, need, fp, c_in), dtype=torch.float32, device=x.device)
+        xp[:, pt0:pt0 + frames, pf0:pf0 + freq, :] = x.permute(0, 2, 3, 1)
+        tiles = torch.zeros((calls * nfix, window, fp, c_in), dtype=torch.float32,
+                            device=x.device)
+        tiles[:total].view(batch, n_tiles, window, fp, c_in).copy_(
+            xp.as_strided((batch, n_tiles, window, fp, c_in),
+                          (need * fp * c_in, step * fp * c_in, fp * c_in, c_in, 1)))
+        weight, bias = self._conv_kernel_cl(layer), p['conv{}/bias'.format(layer)]
+        out = None
+        for call in range(calls):
+            yc = torch.ops.aten.convolution(
+                tiles[call * nfix:(call + 1) * nfix].permute(0, 3, 1, 2), weight, bias,
+                [s_t, s_f], [0, 0], [1, 1], False, [0, 0], 1)
+            if out is None:
+                out = torch.empty((calls * nfix,) + (yc.shape[2], yc.shape[3], yc.shape[1]),
+                                  dtype=torch.float32, device=x.device)
+            out[call * nfix:(call + 1) * nfix] = yc.permute(0, 2, 3, 1)
+        f_out, c_out = out.shape[2], out.shape[3]
+        y = out[:total].view(batch, n_tiles * self.conv_tile_frames, f_out, c_out)[:, :t_out] \
+            .contiguous().permute(0, 3, 1, 2)
+        ctx = {'tiles': tiles, 'geometry': (batch, c_in, frames, freq, t_out, n_tiles, window,
+                                            step, need, fp, calls, f_out, c_out)}
+        return y, ctx
+
+    def _conv_bwd_tiled(self, layer, dz_phys, ctx, pads, need_dx):
+        """Backward of `_conv_fwd_tiled`: dz physical NHWC [B, T', F', Cout] -> (gradient w.r.t.
+        the layer input, physical NHWC, or None; kernel gradient [Cout, Cin, kt, kf])."""
+        pt0, _, pf0, _ = pads
+        s_t, s_f = CONV_STRIDES[layer]
+        (batch, c_in, frames, freq, t_out, n_tiles, window, step, need, fp, calls, f_out,
+         c_out) = ctx['geometry']
+        tiles, nfix, tile = ctx['tiles'], self.conv_tile_batch, self.conv_tile_frames
+        total = batch * n_tiles
+        dz_tiles = torch.zeros((calls * nfix, tile, f_out, c_out), dtype=torch.float32,
+                               device=dz_phys.device)
+        dz_tiles[:total].view(batch, n_tiles * tile, f_out, c_out)[:, :t_out] = dz_phys
+        weight = self._conv_kernel_cl(layer)
+        dw_sum, dx_tiles = None, None
+        if need_dx:
+            dx_tiles = torch.empty_like(tiles)
+        for call in range(calls):
+            sel = slice(call * nfix, (call + 1) * nfix)
+            dxc, dwc, _ = torch.ops.aten.convolution_backward(
+                dz_tiles[sel].permute(0, 3, 1, 2), tiles[sel].permute(0, 3, 1, 2), weight,
+                [c_out], [s_t, s_f], [0, 0], [1, 1], False, [0, 0], 1, [need_dx, True, False])
+            dw_sum = dwc if dw_sum is None else dw_sum.add_(dwc)
+            if need_dx:
+                dx_tiles[sel] = dxc.permute(0, 2, 3, 1)
+        if not need_dx:
+            return None, dw_sum
+        # overlap-add of the input-gradient windows: tiles of equal parity do not overlap
+        dxp = torch.zeros((batch, need, fp, c_in), dtype=torch.float32, device=dz_phys.device)
+        windows = dx_tiles[:total].view(batch, n_tiles, window, fp, c_in)
+        row = fp * c_in
+        for parity in (0, 1):
+            count = (n_tiles - parity + 1) // 2
+            if count > 0:
+                dxp.as_strided((batch, count, window, fp, c_in),
+                               (need * row, 2 * step * row, row, c_in, 1),
+                               parity * step * row).add_(windows[:, parity::2])
+        return dxp[:, pt0:pt0 + frames, pf0:pf0 + freq, :].contiguous(), dw_sum
 
     def _conv_kernel_cl(self, layer):
         """Conv kernel [Cout, Cin, kt, kf] in channels_last memory (scratch copy per call)."""
@@ -643,16 +753,23 @@ class CTCModel:
                 dz = hip.bias_act_bwd(conv_out[i].permute(0, 2, 3, 1), dact, cfg.relu_cutoff,
                                       cfg.conv_dropout_rate, g[name + '/bias'])
                 dz = dz.permute(0, 3, 1, 2)        # logical NCHW view of the NHWC storage
-                xp = acts['conv_in'][i]
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
-                dxp, dw, _ = torch.ops.aten.convolution_backward(
-                    dz, xp, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
-                    list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
-                    [i > 0, True, False])
-                g[name + '/kernel'].copy_(dw)
-                if i > 0:
-                    dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1] \
-                        .permute(0, 2, 3, 1).contiguous()
+                if self.conv_mode == 'tiled':
+                    dx_phys, dw = self._conv_bwd_tiled(i, dz.permute(0, 2, 3, 1),
+                                                       acts['conv_in'][i], acts['pads'][i], i > 0)
+                    g[name + '/kernel'].copy_(dw)
+                    if i > 0:
+                        dact = dx_phys
+                else:
+                    xp = acts['conv_in'][i]
+                    dxp, dw, _ = torch.ops.aten.convolution_backward(
+                        dz, xp, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
+                        list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
+                        [i > 0, True, False])
+                    g[name + '/kernel'].copy_(dw)
+                    if i > 0:
+                        dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1] \
+                            .permute(0, 2, 3, 1).contiguous()
                 done(name)
         else:
             dact = dy.reshape(rows, -1)

@@ -16,6 +16,8 @@ from ctc_asr_amd.params import FLAGS  # noqa: E402
 
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     rng = np.random.default_rng(0)
     with tempfile.TemporaryDirectory() as tmp:
         corpus = os.path.join(tmp, 'corpus')
@@ -26,10 +28,10 @@ def main():
         train.main(['--corpus_dir', corpus, '--train_csv', os.path.join(tmp, 'train.csv'),
                     '--dev_csv', os.path.join(tmp, 'dev.csv'),
                     '--test_csv', os.path.join(tmp, 'test.csv'),
-                    '--train_dir', os.path.join(tmp, 'ckpt'), '--batch_size=8', '--num_buckets=6',
+                    '--train_dir', os.path.join(tmp, 'ckpt'), '--batch_size={}'.format(batch), '--num_buckets=6',
                     '--feature_type=mel', '--used_model=ds2', '--conv_filters=32',
                     '--conv_filters=32', '--num_layers_rnn=2', '--num_units_rnn=1024',
-                    '--rnn_cell=lstm', '--num_units_dense=2048', '--max_epochs=2',
+                    '--rnn_cell=lstm', '--num_units_dense=2048', '--max_epochs={}'.format(epochs),
                     '--beam_width=64', '--log_frequency=4', '--random_seed=5'])
         print('total wall time {:.1f} s'.format(time.perf_counter() - t0))
 

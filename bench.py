@@ -154,6 +154,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', type=float, default=0.1,
                     help='dense_dropout_rate (reference default 0.1)')
+    ap.add_argument('--rnn-bwd-whole-chip', action='store_true',
+                    help='persistent backward recurrence on all 256 CUs (default: 128)')
     args = ap.parse_args()
 
     from ctc_asr_amd import hip
@@ -162,6 +164,8 @@ def main():
     from ctc_asr_amd.synth import synthetic_batch
     import torch.distributed as dist
 
+    if args.rnn_bwd_whole_chip:
+        hip.set_option('rnn_bwd_half_chip', 0)
     rank, local_rank, world = init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus {} does not match WORLD_SIZE {}'.format(args.gpus, world))

@@ -400,18 +400,29 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 //                        slice is split between LDS (the first QW-REGW chunks of every wave) and
 //                        REGW float4 registers per lane.  Same time per step, but 128 CUs stay
 //                        free for the weight-gradient GEMMs of the layer above.
+//   UPB = 32, REGW = 32: the plain RNN (G = 1, H = 2048) on half the chip: two N tiles per
+//                        workgroup sharing every A chunk (twice the MFMAs per workgroup of the
+//                        128-workgroup variant: 6.7 vs 5.7 us per step, 128 CUs free).
 // Reduction scratch [4][MT*16][17] follows the fragments.
 // ---------------------------------------------------------------------------------------------
 template <int CELL, int QW, int MT, int LB, int UPB, int REGW>
 __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
     constexpr bool HALF_TILE = UPB == 8;
+    // UPB = 32: TWO N tiles per workgroup.  The B-fragment slots of a wave then alternate
+    // (tile 0, chunk c), (tile 1, chunk c): QW counts slots, every A chunk feeds a pair of them,
+    // and the two alternating accumulators ARE the two tiles (no final sum).
+    constexpr bool TWO_TILES = UPB == 32;
+    constexpr int NT = TWO_TILES ? 2 : 1;
     constexpr int SLOTS = HALF_TILE ? 32 : 64;      // float4 slots per chunk in LDS
-    constexpr int QL = QW - REGW;                   // chunks per wave kept in LDS
+    constexpr int QL = QW - REGW;                   // slots per wave kept in LDS
     constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
-    constexpr int NB = QW / LB;          // load batches per wave (LB chunks in flight each)
-    constexpr int CPG = QW / G;          // 16-float chunks per gate within a wave's unit range
+    constexpr int NB = QW / LB;          // load batches per wave (LB slots in flight each)
+    constexpr int QA = QW / NT;          // 16-float A chunks per wave
+    constexpr int LA = LB / NT;          // A chunks per load batch
+    constexpr int CPG = QA / G;          // 16-float chunks per gate within a wave's unit range
     static_assert(REGW == 0 || !HALF_TILE, "register-resident weights need full tiles");
+    static_assert(!TWO_TILES || (G == 1 && REGW > 0), "two tiles: plain RNN, static slot map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *frag = reinterpret_cast<float4 *>(smem);
     float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * SLOTS * sizeof(float4));
@@ -427,13 +438,16 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
 
     float4 wreg[REGW > 0 ? REGW : 1];
     if (!HALF_TILE || (lane & 15) < 8) {
-        const float *wrow = p.w + ((size_t)dir * H + u0 + (lane & (UPB - 1))) * GH +
+        // slot i of this wave: A chunk i / NT of tile i % NT
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (lane & (UPB / NT - 1))) * GH +
                             wave * (H / 4) + kq;
-        for (int i = 0; i < QL; ++i)
-            frag[(wave * QL + i) * SLOTS + half] = ldg4(wrow + (i / CPG) * H + (i % CPG) * 16);
+        auto slot = [&](int i) -> float4 {
+            const int c = i / NT;
+            return ldg4(wrow + (size_t)(i % NT) * 16 * GH + (c / CPG) * H + (c % CPG) * 16);
+        };
+        for (int i = 0; i < QL; ++i) frag[(wave * QL + i) * SLOTS + half] = slot(i);
 #pragma unroll
-        for (int i = 0; i < REGW; ++i)
-            wreg[i] = ldg4(wrow + ((QL + i) / CPG) * H + ((QL + i) % CPG) * 16);
+        for (int i = 0; i < REGW; ++i) wreg[i] = slot(QL + i);
     }
     __syncthreads();
 
@@ -526,13 +540,13 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             }
             // chunk i of this wave = gate i / CPG, 16-float unit chunk i % CPG; loads of batch
             // nb+1 are in flight while batch nb feeds the MFMAs
-            float4 a[2][MT][LB];
-            auto issue = [&](int nb, float4 (&dst)[MT][LB]) {
+            float4 a[2][MT][LA];
+            auto issue = [&](int nb, float4 (&dst)[MT][LA]) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < LB; ++i) {
-                        const int c = (nb * LB + i + rot) & (QW - 1);
+                    for (int i = 0; i < LA; ++i) {
+                        const int c = (nb * LA + i + rot) & (QA - 1);
                         // chunk index in n-space: gate * (H / 16) + unit chunk
                         const unsigned off = (unsigned)(((size_t)(c / CPG) * (H / 16) + (c % CPG)) *
                                                         B * 16 * sizeof(float));
@@ -563,14 +577,22 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                     if (c + 2 < QW) { nb0 = bfrag(c + 2); nb1 = bfrag(c + 3); }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        mma4x2(acc[mt], acc2[mt], a[nb & 1][mt][i], cb0, a[nb & 1][mt][i + 1], cb1);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if constexpr (TWO_TILES)      // one A chunk, the pair of tiles
+                            mma4x2(acc[mt], acc2[mt], a[nb & 1][mt][i / 2], cb0,
+                                   a[nb & 1][mt][i / 2], cb1);
+                        else
+                            mma4x2(acc[mt], acc2[mt], a[nb & 1][mt][i], cb0,
+                                   a[nb & 1][mt][i + 1], cb1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     cb0 = nb0; cb1 = nb1;
                 }
             }
+            if constexpr (!TWO_TILES) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] += acc2[mt];
+                for (int mt = 0; mt < MT; ++mt) acc[mt] += acc2[mt];
+            }
         }
         if (prof) {
             asm volatile("" ::"v"(acc[0][0]));
@@ -579,8 +601,13 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[(wave * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[mt][r];
+            for (int r = 0; r < 4; ++r) {
+                red[((wave * NT) * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] =
+                    acc[mt][r];
+                if constexpr (TWO_TILES)
+                    red[((wave * NT + 1) * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 +
+                        (lane & 15)] = acc2[mt][r];
+            }
         __syncthreads();
 
 #pragma unroll
@@ -593,7 +620,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             if (it_t[it] >= 0) {
                 float dh = dyv[it];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) dh += red[(w * MT * 16 + b) * 17 + u];
+                for (int w = 0; w < 4; ++w)
+                    dh += red[((w * NT + (u >> 4)) * MT * 16 + b) * 17 + (u & 15)];
                 if constexpr (CELL == CTCASR_CELL_LSTM) {
                     const float gi = gv[it][0], gf = gv[it][1], gg = gv[it][2], go = gv[it][3];
                     const float tc = tanhf(cv[it]);
@@ -801,9 +829,9 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
     p.sync = reinterpret_cast<SyncWords *>(sync);
-    const bool half_chip = g_bwd_half_chip != 0 && cell == CTCASR_CELL_LSTM;
+    const bool half_chip = g_bwd_half_chip != 0;
     p.T = T; p.B = B; p.H = H;
-    p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : H / 16;
+    p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len && step_end == T &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * (cell == CTCASR_CELL_LSTM ? 4 : 1) * H *
@@ -813,7 +841,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
 #define PRNN_BWD(CELL_, QW_, MT_, LB_, UPB_, REGW_, G_)                                        \
     return launch_persistent(prnn_bwd_kernel<CELL_, QW_, MT_, LB_, UPB_, REGW_>, p,             \
                              (size_t)4 * (QW_ - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +          \
-                                 (size_t)4 * MT_ * 16 * 17 * 4 + 16,                           \
+                                 (size_t)4 * (UPB_ == 32 ? 2 : 1) * MT_ * 16 * 17 * 4 + 16,    \
                              (size_t)2 * B * G_ * H, s)
     if (cell == CTCASR_CELL_LSTM) {
         if (half_chip) {
@@ -822,6 +850,16 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
         }
         if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 32, 8, 0, 4); }
         PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 16, 8, 0, 4);
+    }
+    // plain RNN, H = 2048, half of the chip: 32 units (two N tiles) x 2048 x 4 B = 256 KB per
+    // workgroup, split between LDS and registers like the LSTM's; 64 workgroups per direction
+    if (half_chip && cell == CTCASR_CELL_RNN_RELU) {
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 1, 16, 32, 32, 1); }
+        PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 2, 8, 32, 32, 1);
+    }
+    if (half_chip) {
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 1, 16, 32, 32, 1); }
+        PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 2, 8, 32, 32, 1);
     }
     // plain RNN, H = 2048: 16 units x 2048 x 4 B = 128 KB per workgroup, 128 per direction
     if (cell == CTCASR_CELL_RNN_RELU) {

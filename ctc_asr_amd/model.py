@@ -656,10 +656,7 @@ class CTCModel:
             # of steps is final, so its share of dW_ih / dW_hh starts on the side stream while the
             # next launch carries the recurrence on.
             chunks = 1
-            # (only the LSTM backward kernel leaves half of the chip to the side stream; the plain
-            # RNN at H=2048 uses all 256 CUs and is faster in one launch: 2813 vs 2761 audio-s/s
-            # on the reference's default model)
-            if (side is not main and acts['rnn_len'] is None and cell == 'lstm' and
+            if (side is not main and acts['rnn_len'] is None and cell != 'gru' and
                     t_out >= 8 * self.bwd_chunks and
                     hip.rnn_persistent_supported(cell, t_out, batch, hidden)):
                 chunks = self.bwd_chunks

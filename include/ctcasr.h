@@ -50,8 +50,9 @@ typedef void *ctcasr_stream_t;
 
 int ctcasr_abi_version(void);
 /* Process-wide switches.  "rnn_bwd_half_chip" (0/1, default 1): run the persistent backward
- * recurrence on 128 of the 256 CUs (weights split between LDS and registers) so that GEMMs
- * launched on another stream can overlap it; 0 selects the whole-chip variant.
+ * recurrence (LSTM H=1024, plain RNN H=2048) on 128 of the 256 CUs (weights split between LDS and
+ * registers) so that GEMMs launched on another stream can overlap it; 0 selects the whole-chip
+ * variant.
  * "rnn_kernel_events" (0/1, default 0): record a HIP event pair on the launch stream around every
  * persistent recurrence kernel; ctcasr_rnn_kernel_events() waits for them, returns launch counts
  * and summed durations ([0] forward, [1] backward) and clears the record (benchmarking). */

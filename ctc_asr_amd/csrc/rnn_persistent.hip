@@ -30,6 +30,9 @@
 #define PRNN_THREADS 256
 #define PRNN_GROUPS 8
 #define PRNN_SPIN_LIMIT (1u << 22)
+#ifndef PRNN_POLL_SLEEP
+#define PRNN_POLL_SLEEP 1
+#endif
 
 namespace {
 
@@ -140,7 +143,7 @@ __device__ __forceinline__ void dir_wait(SyncWords *sy, int dir, int group_size,
                 ready = __hip_atomic_load(&sy->group_cnt[dir][tid][0], __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT) >= target;
             if (__all(ready)) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(PRNN_POLL_SLEEP);
             if (++spins > PRNN_SPIN_LIMIT ||
                 ((spins & 1023u) == 0 &&
                  __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {

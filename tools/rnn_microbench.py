@@ -18,7 +18,7 @@ def main():
     T, B, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (500, 16, 1024)
     cell = sys.argv[4] if len(sys.argv) >= 5 else 'lstm'
     G = hip.CELL_GATES[cell]
-    hip.load()
+    hip.load(os.environ.get('CTCASR_LIB'))      # A/B builds of the library
     if os.environ.get('CTCASR_FULL'):      # backward recurrence on the whole chip (default: half)
         hip.set_option('rnn_bwd_half_chip', 0)
     g = torch.Generator(device='cuda').manual_seed(0)

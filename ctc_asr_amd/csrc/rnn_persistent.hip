@@ -340,16 +340,16 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                 if constexpr (CELL == CTCASR_CELL_LSTM) {
                     const float gi = sigmoidf_(xw[it][0] + rec[0]);
                     const float gf = sigmoidf_(xw[it][1] + rec[1]);
-                    const float gg = tanhf(xw[it][2] + rec[2]);
+                    const float gg = tanhf_(xw[it][2] + rec[2]);
                     const float go = sigmoidf_(xw[it][3] + rec[3]);
                     const float c = gf * c_state[it] + gi * gg;
                     c_state[it] = c;
-                    hv[it] = go * tanhf(c);
+                    hv[it] = go * tanhf_(c);
                     rsv[it][0] = gi; rsv[it][1] = gf; rsv[it][2] = gg; rsv[it][3] = go;
                     rsv[it][4] = c;
                 } else {
                     const float pre = xw[it][0] + rec[0];
-                    hv[it] = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
+                    hv[it] = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf_(pre);
                 }
             }
             // publish h: lanes of 4 consecutive units gather into one 16-byte sc1 store
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                     dh += red[((w * NT + (u >> 4)) * MT * 16 + b) * 17 + (u & 15)];
                 if constexpr (CELL == CTCASR_CELL_LSTM) {
                     const float gi = gv[it][0], gf = gv[it][1], gg = gv[it][2], go = gv[it][3];
-                    const float tc = tanhf(cv[it]);
+                    const float tc = tanhf_(cv[it]);
                     const float dc = dc_state[it] + dh * go * (1.f - tc * tc);
                     dg[0] = dc * gg * gi * (1.f - gi);
                     dg[1] = dc * cpv[it] * gf * (1.f - gf);

@@ -132,13 +132,13 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
         if (CELL == CTCASR_CELL_LSTM) {
             float gi = sigmoidf_(xw[0] + rec[0]);
             float gf = sigmoidf_(xw[H] + rec[G > 1 ? 1 : 0]);
-            float gg = tanhf(xw[2 * H] + rec[G > 2 ? 2 : 0]);
+            float gg = tanhf_(xw[2 * H] + rec[G > 2 ? 2 : 0]);
             float go = sigmoidf_(xw[3 * H] + rec[G > 3 ? 3 : 0]);
             float *cst = p.cbuf + ((size_t)dir * B + b) * H + unit;
             float cprev = p.step > 0 ? *cst : 0.f;
             float c = gf * cprev + gi * gg;
             *cst = c;
-            h = go * tanhf(c);
+            h = go * tanhf_(c);
             float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
             gr[0] = gi; gr[H] = gf; gr[2 * H] = gg; gr[3 * H] = go;
             p.cells[(((size_t)t * B + b) * 2 + dir) * H + unit] = c;
@@ -148,13 +148,13 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
             const float gr_ = sigmoidf_(xw[0] + rec[0]);
             const float gz = sigmoidf_(xw[H] + rec[G > 1 ? 1 : 0]);
             const float q = rec[G > 2 ? 2 : 0] + p.b_hh[(size_t)dir * 3 * H + 2 * H + unit];
-            const float gn = tanhf(xw[2 * H] + gr_ * q);
+            const float gn = tanhf_(xw[2 * H] + gr_ * q);
             h = (1.f - gz) * gn + gz * hp;
             float *rs = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
             rs[0] = gr_; rs[H] = gz; rs[2 * H] = gn; rs[3 * H] = q;
         } else {
             float pre = xw[0] + rec[0];
-            h = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
+            h = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf_(pre);
         }
         hnext[hoff] = h;
         p.y[((size_t)t * B + b) * 2 * H + dir * H + unit] = h;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_bwd_step_kernel(StepArgs p) {
         }
         float *dcst = p.cbuf + ((size_t)dir * B + b) * H + unit;
         const float dc_in = (s + 1 < steps) ? *dcst : 0.f;
-        const float tc = tanhf(c);
+        const float tc = tanhf_(c);
         const float dc = dc_in + dh * go * (1.f - tc * tc);
         dx[0] = dc * gg * gi * (1.f - gi);
         dx[H] = dc * cprev * gf * (1.f - gf);

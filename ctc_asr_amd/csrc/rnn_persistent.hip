@@ -44,6 +44,7 @@ struct SyncWords {
     unsigned error;
     unsigned pad[63];
     unsigned long long prof[16];   // CTCASR_RNN_PROF=1: per-phase 100 MHz ticks of workgroup 0
+    unsigned long long prof_all[256][4];   // ... and of every workgroup (forward pass)
 };
 
 struct PArgs {
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     }
 
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
-    const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
+    const bool prof = p.prof && tid == 0;
     for (int s = 0; s < T; ++s) {
         unsigned long long c0 = prof ? wall_clock64() : 0;
         // gate pre-activations from the input projection: independent of the recurrence, so
@@ -389,8 +390,12 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
     }
-    if (prof)
-        for (int i = 0; i < 4; ++i) p.sync->prof[i] = pt[i];
+    if (prof) {
+        for (int i = 0; i < 4; ++i) {
+            if (blockIdx.x == 0) p.sync->prof[i] = pt[i];
+            if (blockIdx.x < 256) p.sync->prof_all[blockIdx.x][i] = pt[i];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -47,6 +47,19 @@ def main():
             labels = ['wait', 'loads+mfma', 'reduce+gates+publish', 'drain+arrive']
             print('  wg0 phases (us/step): ' + ', '.join(
                 '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
+            if name == 'fwd':
+                every = ws[base + 128: base + 128 + 256 * 32].cpu().numpy().view(np.uint64) \
+                    .reshape(256, 4).astype(np.float64) / 100.0 / T
+                for k, label in enumerate(labels):
+                    col = every[:, k]
+                    print('    all 256 workgroups, {:<22s} min {:.2f}  median {:.2f}  max {:.2f}'
+                          .format(label, col.min(), np.median(col), col.max()))
+                busy = every[:, 1] + every[:, 2] + every[:, 3]
+                order = np.argsort(busy)
+                print('    busiest (loads..arrive) workgroups: {}  us {}'.format(
+                    order[-8:].tolist(), np.round(busy[order[-8:]], 2).tolist()))
+                print('    per blockIdx % 8 mean busy: {}'.format(
+                    np.round([busy[i::8].mean() for i in range(8)], 2).tolist()))
     hip.rnn_poll_error(cell, ws, T, B, H)
     # checksum for A/B comparisons between variants
     print('checksum y {:.6f} dxw {:.6f}'.format(float(y.double().abs().sum()),

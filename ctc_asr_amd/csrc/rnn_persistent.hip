@@ -28,7 +28,9 @@
 #include <vector>
 
 #define PRNN_THREADS 256
+#ifndef PRNN_GROUPS
 #define PRNN_GROUPS 8
+#endif
 #define PRNN_SPIN_LIMIT (1u << 22)
 #ifndef PRNN_POLL_SLEEP
 #define PRNN_POLL_SLEEP 1

@@ -47,6 +47,8 @@ SIGNATURES = {
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
+    'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_p]),
+    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
@@ -357,6 +359,26 @@ def colsum_accumulate(dz, dbias):
                                            dz.numel() // cols, cols, _stream()),
            'colsum_accumulate')
     return dbias
+
+
+def conv_s12_bwd_data(dz, weight, packed=None, out=None):
+    """Data gradient of the 11x21 / stride (1,2) / 32->32 convolution: dz f32[B,T,20,32] (NHWC),
+    weight f32[32,32,11,21] ([Cout,Cin,kt,kf]) -> dx f32[B,T,40,32]."""
+    batch, frames = dz.shape[0], dz.shape[1]
+    if tuple(dz.shape[2:]) != (20, 32) or tuple(weight.shape) != (32, 32, 11, 21):
+        raise CtcAsrError('conv_s12_bwd_data covers dz [B,T,20,32] and w [32,32,11,21] only.')
+    packed = torch.empty(11 * 21 * 32 * 32, dtype=torch.float32, device=dz.device) \
+        if packed is None else packed
+    out = torch.empty((batch, frames, 40, 32), dtype=torch.float32, device=dz.device) \
+        if out is None else out
+    _check(load().ctcasr_conv_s12_pack_weights(_dev(weight, name='weight'),
+                                               _dev(packed, name='packed'), _stream()),
+           'conv_s12_pack_weights')
+    with _Timed('conv_s12_bwd_data'):
+        _check(load().ctcasr_conv_s12_bwd_data(_dev(dz, name='dz'), _dev(packed, name='packed'),
+                                               _dev(out, name='dx'), batch, frames, _stream()),
+               'conv_s12_bwd_data')
+    return out
 
 
 def stream_delay(microseconds):

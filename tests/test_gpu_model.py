@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 CASES = {
     'ds2_lstm_3conv': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='lstm', cudnn=True),
     'ds2_lstm_2conv': dict(used_model='ds2', conv_filters=(4, 4), rnn_cell='lstm', cudnn=True),
+    # 32 -> 32 channels: the layer with its own data-gradient kernel (ctcasr_conv_s12_bwd_data)
+    'ds2_lstm_32ch': dict(used_model='ds2', conv_filters=(32, 32), rnn_cell='lstm', cudnn=True),
+    'ds2_lstm_32ch_3conv': dict(used_model='ds2', conv_filters=(32, 32, 8), rnn_cell='lstm',
+                                cudnn=True),
     'ds2_gru': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='gru', cudnn=True),
     'ds2_relu': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='rnn_relu', cudnn=True),
     'ds1_tanh_cudnn': dict(used_model='ds1', rnn_cell='rnn_tanh', cudnn=True),

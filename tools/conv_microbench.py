@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Times ctcasr_conv_s12_bwd_data at the C2 shape (B=16, T'=500) against MIOpen's backward-data
+of the same layer (autotuned, explicitly padded input, incl. the interior copy it needs)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ctc_asr_amd import hip  # noqa: E402
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def main():
+    batch, frames = (int(v) for v in sys.argv[1:3]) if len(sys.argv) >= 3 else (16, 500)
+    hip.load(os.environ.get('CTCASR_LIB'))
+    torch.backends.cudnn.benchmark = True
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    dz = torch.randn(batch, frames, 20, 32, device='cuda', generator=gen)
+    weight = torch.randn(32, 32, 11, 21, device='cuda', generator=gen) * 0.05
+    packed = torch.empty(11 * 21 * 32 * 32, device='cuda')
+    out = torch.empty(batch, frames, 40, 32, device='cuda')
+    flops = 2.0 * batch * frames * 20 * 32 * 32 * 11 * 21
+    ms = timed(lambda: hip.conv_s12_bwd_data(dz, weight, packed, out))
+    print('conv_s12_bwd_data: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    xp = torch.zeros(batch, 32, frames + 10, 59, device='cuda') \
+        .contiguous(memory_format=torch.channels_last)
+    w_cl = weight.contiguous(memory_format=torch.channels_last)
+    dz_nchw = dz.permute(0, 3, 1, 2)
+
+    def library():
+        dxp, _, _ = torch.ops.aten.convolution_backward(
+            dz_nchw, xp, w_cl, [32], [1, 2], [0, 0], [1, 1], False, [0, 0], 1,
+            [True, False, False])
+        return dxp[:, :, 5:5 + frames, 9:49].permute(0, 2, 3, 1).contiguous()
+    ms = timed(library)
+    print('MIOpen bwd-data + interior copy: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    print('max |diff| {:.2e}'.format(float((library() - out).abs().max())))
+
+
+if __name__ == '__main__':
+    main()

@@ -38,6 +38,14 @@ __device__ __forceinline__ void mma4(f32x4 &acc, const float4 &a, const float4 &
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
 }
 
+// The four B fragments of a tap: K chunks q = 0, 1 x N tiles 0, 1 (packed order, see below).
+struct BFrag { float4 b00, b01, b10, b11; };
+__device__ __forceinline__ BFrag load_b(const float4 *__restrict__ wp, int kt, int kf, int kg,
+                                        int n) {
+    const float4 *wt = wp + (size_t)((kt * CV_KF + kf) * 8 + kg) * 32 + n;
+    return BFrag{wt[0], wt[16], wt[4 * 32], wt[4 * 32 + 16]};
+}
+
 // w [Cout, Cin, kt, kf] (the arena's compute layout) -> packed[kt][kf][q][kg][ci][r] with
 // co = 16 q + 4 kg + r: lane (ci & 15, kg) of N tile ci / 16 reads one float4.
 __global__ void conv_pack_bwd_kernel(const float *__restrict__ w, float *__restrict__ packed) {
@@ -47,6 +55,98 @@ __global__ void conv_pack_bwd_kernel(const float *__restrict__ w, float *__restr
     const int tap = i >> 10, kf = tap % CV_KF, kt = tap / CV_KF;
     const int co = 16 * q + 4 * kg + r;
     packed[i] = w[((co * CV_C + ci) * CV_KT + kt) * CV_KF + kf];
+}
+
+// Forward pass of the same layer, same machinery:
+//   y[b, t, fo, co] = bias[co] + sum_{kt, kf, ci} x[b, t + kt - 5, 2 fo + kf - 9, ci] * w[co, ci, kt, kf]
+// In padded coordinates fp = 2 fo + kf, so a tap of parity par = kf & 1 only ever reads input
+// frequencies of that parity: the patch is staged twice, once per parity plane
+// (26 frames x 30 positions x 32 channels), position = fo + kf / 2 - which makes the A fragment
+// of a row, again, the lane's base address plus a tap-uniform offset.
+// packed (forward): [kt][kf][q][kg][co][r] with ci = 16 q + 4 kg + r.
+__global__ void conv_pack_fwd_kernel(const float *__restrict__ w, float *__restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CV_KT * CV_KF * CV_C * CV_C) return;
+    const int r = i & 3, co = (i >> 2) & 31, kg = (i >> 7) & 3, q = (i >> 9) & 1;
+    const int tap = i >> 10, kf = tap % CV_KF, kt = tap / CV_KF;
+    const int ci = 16 * q + 4 * kg + r;
+    packed[i] = w[((co * CV_C + ci) * CV_KT + kt) * CV_KF + kf];
+}
+
+__global__ void __launch_bounds__(256)
+conv_fwd_kernel(const float *__restrict__ x, const float4 *__restrict__ wp,
+                const float *__restrict__ bias, float *__restrict__ y, int T) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];   // [CV_PT][CV_PF][CV_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * CV_TT, b = blockIdx.y;
+    const int kg = lane >> 4, n = lane & 15;
+    float4 *patch4 = reinterpret_cast<float4 *>(patch);
+
+    int base_a[5];
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti) {
+        const int row = ti * 16 + n, tt = row / CV_FO, fo = row % CV_FO;
+        base_a[ti] = ((4 * wave + tt) * CV_PF + fo) * CV_PITCH + 4 * kg;
+    }
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {    // unrolled: compile-time tap counts in both copies
+        if (par) __syncthreads();          // everyone is done reading the other plane
+        for (int i = tid; i < CV_PT * CV_PF * 8; i += 256) {
+            const int c4 = i & 7, pos = (i >> 3) % CV_PF, pr = i / (8 * CV_PF);
+            const int ts = t0 - 5 + pr, fi = 2 * pos + par - 9;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ts >= 0 && ts < T && fi >= 0 && fi < CV_FI)
+                v = reinterpret_cast<const float4 *>(x)[((size_t)(b * T + ts) * CV_FI + fi) * 8 + c4];
+            patch4[((pr * CV_PF + pos) * CV_PITCH) / 4 + c4] = v;
+        }
+        __syncthreads();
+        const int taps = par == 0 ? 11 : 10;
+        // B fragments (weights, from L2) run one tap ahead of the MFMAs that use them; the
+        // scheduling barriers keep hipcc from sinking the loads next to their first use
+        BFrag cur = load_b(wp, 0, par, kg, n);
+        for (int kt = 0; kt < CV_KT; ++kt) {
+#pragma unroll
+            for (int m = 0; m < taps; ++m) {
+                const bool wrap = m + 1 == taps;
+                const BFrag nxt = load_b(wp, wrap ? min(kt + 1, CV_KT - 1) : kt,
+                                         wrap ? par : 2 * (m + 1) + par, kg, n);
+                __builtin_amdgcn_sched_barrier(0);
+                const int tap_off = (kt * CV_PF + m) * CV_PITCH;
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off);
+                    const float4 a1 =
+                        *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off + 16);
+                    mma4(acc[ti][0], a0, cur.b00);
+                    mma4(acc[ti][1], a0, cur.b01);
+                    mma4(acc[ti][0], a1, cur.b10);
+                    mma4(acc[ti][1], a1, cur.b11);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+        }
+    }
+
+    const float bias0 = bias ? bias[n] : 0.f, bias1 = bias ? bias[16 + n] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + 4 * kg + r, tt = row / CV_FO, fo = row % CV_FO;
+            const int t = t0 + 4 * wave + tt;
+            if (t < T) {
+                float *out = y + ((size_t)(b * T + t) * CV_FO + fo) * CV_C + n;
+                out[0] = acc[ti][0][r] + bias0;
+                out[16] = acc[ti][1][r] + bias1;
+            }
+        }
 }
 
 __global__ void __launch_bounds__(256)
@@ -93,20 +193,20 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
             // even output frequencies (f = 2j) meet the odd kf, odd ones (f = 2j+1) the even kf;
             // dz frequency = j + 4 + p - m with m = kf / 2
             const int taps = p == 0 ? 10 : 11;
+            // (no explicit weight prefetch here: hipcc's own schedule of this loop nest reaches
+            // 138 TFLOP/s, the pinned one-tap-ahead variant of the forward kernel 131)
             for (int m = 0; m < taps; ++m) {
-                const int kf = p == 0 ? 2 * m + 1 : 2 * m;
-                const float4 *wt = wp + (size_t)((kt * CV_KF + kf) * 8 + kg) * 32 + n;
-                const float4 b00 = wt[0], b01 = wt[16], b10 = wt[4 * 32], b11 = wt[4 * 32 + 16];
+                const BFrag cur = load_b(wp, kt, p == 0 ? 2 * m + 1 : 2 * m, kg, n);
                 const int tap_off = ((10 - kt) * CV_PF + 9 + p - m) * CV_PITCH;
 #pragma unroll
                 for (int ti = 0; ti < 5; ++ti) {
                     const float4 a0 = *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off);
                     const float4 a1 =
                         *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off + 16);
-                    mma4(acc[p][ti][0], a0, b00);
-                    mma4(acc[p][ti][1], a0, b01);
-                    mma4(acc[p][ti][0], a1, b10);
-                    mma4(acc[p][ti][1], a1, b11);
+                    mma4(acc[p][ti][0], a0, cur.b00);
+                    mma4(acc[p][ti][1], a0, cur.b01);
+                    mma4(acc[p][ti][0], a1, cur.b10);
+                    mma4(acc[p][ti][1], a1, cur.b11);
                 }
             }
         }
@@ -131,12 +231,30 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
 
 }  // namespace
 
-// Fragment-ordered copy of the layer's kernel for ctcasr_conv_s12_bwd_data (946 KB; the weights
-// change every step).  w: [32, 32, 11, 21] = [Cout, Cin, kt, kf].
+// Fragment-ordered copies of the layer's kernel for ctcasr_conv_s12_bwd_data and _fwd (2 x 946 KB;
+// the weights change every step).  w: [32, 32, 11, 21] = [Cout, Cin, kt, kf].
 extern "C" int ctcasr_conv_s12_pack_weights(const float *w, float *packed, ctcasr_stream_t stream) {
     if (!w || !packed) return CTCASR_ERR_BAD_ARGUMENT;
     const int n = CV_KT * CV_KF * CV_C * CV_C;
     conv_pack_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, packed);
+    conv_pack_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, packed + n);
+    return ctcasr_launch_status();
+}
+
+// x [B, T, 40, 32] (NHWC) -> y [B, T, 20, 32] = conv(x) + bias (bias may be NULL).  `packed` holds
+// 2 x 11*21*32*32 floats: ctcasr_conv_s12_pack_weights fills the backward order first, then the
+// forward order.
+extern "C" int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y,
+                                   int B, int T, ctcasr_stream_t stream) {
+    if (!x || !packed || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)CV_PT * CV_PF * CV_PITCH * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    dim3 grid((T + CV_TT - 1) / CV_TT, B);
+    conv_fwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(
+        x, reinterpret_cast<const float4 *>(packed + CV_KT * CV_KF * CV_C * CV_C), bias, y, T);
     return ctcasr_launch_status();
 }
 

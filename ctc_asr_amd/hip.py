@@ -48,6 +48,7 @@ SIGNATURES = {
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
     'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_p]),
+    'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
@@ -361,19 +362,43 @@ def colsum_accumulate(dz, dbias):
     return dbias
 
 
-def conv_s12_bwd_data(dz, weight, packed=None, out=None):
-    """Data gradient of the 11x21 / stride (1,2) / 32->32 convolution: dz f32[B,T,20,32] (NHWC),
-    weight f32[32,32,11,21] ([Cout,Cin,kt,kf]) -> dx f32[B,T,40,32]."""
-    batch, frames = dz.shape[0], dz.shape[1]
-    if tuple(dz.shape[2:]) != (20, 32) or tuple(weight.shape) != (32, 32, 11, 21):
-        raise CtcAsrError('conv_s12_bwd_data covers dz [B,T,20,32] and w [32,32,11,21] only.')
-    packed = torch.empty(11 * 21 * 32 * 32, dtype=torch.float32, device=dz.device) \
+CONV_S12_PACKED_FLOATS = 2 * 11 * 21 * 32 * 32
+
+
+def conv_s12_pack_weights(weight, packed=None):
+    """Fragment-ordered copies (backward, forward) of w f32[32,32,11,21] ([Cout,Cin,kt,kf])."""
+    if tuple(weight.shape) != (32, 32, 11, 21):
+        raise CtcAsrError('the conv_s12 kernels cover w [32,32,11,21] only.')
+    packed = torch.empty(CONV_S12_PACKED_FLOATS, dtype=torch.float32, device=weight.device) \
         if packed is None else packed
-    out = torch.empty((batch, frames, 40, 32), dtype=torch.float32, device=dz.device) \
-        if out is None else out
     _check(load().ctcasr_conv_s12_pack_weights(_dev(weight, name='weight'),
                                                _dev(packed, name='packed'), _stream()),
            'conv_s12_pack_weights')
+    return packed
+
+
+def conv_s12_fwd(x, packed, bias=None, out=None):
+    """x f32[B,T,40,32] (NHWC) -> conv(x) + bias, f32[B,T,20,32]; 11x21 taps, stride (1,2),
+    TensorFlow SAME padding.  ``packed`` from `conv_s12_pack_weights`."""
+    batch, frames = x.shape[0], x.shape[1]
+    if tuple(x.shape[2:]) != (40, 32):
+        raise CtcAsrError('conv_s12_fwd covers x [B,T,40,32] only.')
+    out = torch.empty((batch, frames, 20, 32), dtype=torch.float32, device=x.device) \
+        if out is None else out
+    with _Timed('conv_s12_fwd'):
+        _check(load().ctcasr_conv_s12_fwd(_dev(x, name='x'), _dev(packed, name='packed'),
+                                          _dev(bias, name='bias'), _dev(out, name='y'), batch,
+                                          frames, _stream()), 'conv_s12_fwd')
+    return out
+
+
+def conv_s12_bwd_data(dz, packed, out=None):
+    """dz f32[B,T,20,32] (NHWC) -> dx f32[B,T,40,32] of the same layer."""
+    batch, frames = dz.shape[0], dz.shape[1]
+    if tuple(dz.shape[2:]) != (20, 32):
+        raise CtcAsrError('conv_s12_bwd_data covers dz [B,T,20,32] only.')
+    out = torch.empty((batch, frames, 40, 32), dtype=torch.float32, device=dz.device) \
+        if out is None else out
     with _Timed('conv_s12_bwd_data'):
         _check(load().ctcasr_conv_s12_bwd_data(_dev(dz, name='dz'), _dev(packed, name='packed'),
                                                _dev(out, name='dx'), batch, frames, _stream()),

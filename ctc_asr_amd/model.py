@@ -298,8 +298,10 @@ class CTCModel:
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
         self.fuse_xw_bias = os.environ.get('CTCASR_FUSE_XW_BIAS', '1') == '1'
-        self.own_conv_bwd_data = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
-        self._conv_packed = torch.empty(11 * 21 * 32 * 32, dtype=torch.float32,
+        # the 11x21 / stride (1,2) / 32->32 convolution runs on this package's own implicit-GEMM
+        # kernels (forward and data gradient; any T, no padded intermediates)
+        self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
+        self._conv_packed = torch.empty(hip.CONV_S12_PACKED_FLOATS, dtype=torch.float32,
                                         device=self.device)
         self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
@@ -346,7 +348,14 @@ class CTCModel:
                 s_t, s_f = CONV_STRIDES[i]
                 _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
-                if self.conv_mode == 'tiled':
+                if self._own_conv_layer(i, x.shape[3]):
+                    # weights change every step: re-pack (2 x 946 KB), then one launch
+                    hip.conv_s12_pack_weights(p['conv{}/kernel'.format(i)], self._conv_packed)
+                    x_phys = x.permute(0, 2, 3, 1)
+                    y = hip.conv_s12_fwd(x_phys, self._conv_packed,
+                                         p['conv{}/bias'.format(i)]).permute(0, 3, 1, 2)
+                    conv_in.append(x)      # padded / tiled for the kernel gradient on demand
+                elif self.conv_mode == 'tiled':
                     y, ctx = self._conv_fwd_tiled(i, x, (pt0, pt1, pf0, pf1))
                     conv_in.append(ctx)
                 else:
@@ -426,6 +435,20 @@ class CTCModel:
         self._acts = acts
         return logits.view(t_out, batch, cfg.num_classes), seq_length
 
+    def _own_conv_layer(self, layer, freq_in):
+        kernel = self.arena.p['conv{}/kernel'.format(layer)]
+        return (self.own_conv and tuple(kernel.shape) == (32, 32, 11, 21) and
+                CONV_STRIDES[layer] == (1, 2) and freq_in == 40)
+
+    def _conv_wrw_input(self, layer, x, pads):
+        """What the (library) kernel-gradient pass of a layer that ran on the own forward kernel
+        needs to keep: the padded input (direct mode) or its tiles (tiled mode)."""
+        pt0, pt1, pf0, pf1 = pads
+        if self.conv_mode == 'tiled':
+            return self._conv_tiles(layer, x, pads)
+        return torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1)) \
+            .contiguous(memory_format=torch.channels_last)
+
     def _conv_tiling(self, layer, frames_in, pad_t):
         """Tile geometry of conv ``layer`` for ``frames_in`` input frames: output frames,
         tiles per utterance, input frames per tile (window), tile step, padded input length."""
@@ -439,10 +462,9 @@ class CTCModel:
         need = (n_tiles * tile - 1) * s_t + k_t
         return t_out, n_tiles, window, step, need
 
-    def _conv_fwd_tiled(self, layer, x, pads):
-        """SAME convolution + bias of one layer as fixed-shape calls (see ``conv_mode``).
-        ``x`` logical NCHW / physical NHWC.  Returns (y like the direct path, context)."""
-        p = self.arena.p
+    def _conv_tiles(self, layer, x, pads):
+        """The zero-padded input of a layer cut into fixed-shape tiles (context of the tiled
+        convolution calls)."""
         pt0, pt1, pf0, pf1 = pads
         s_t, s_f = CONV_STRIDES[layer]
         batch, c_in, frames, freq = x.shape
@@ -459,6 +481,18 @@ class CTCModel:
         tiles[:total].view(batch, n_tiles, window, fp, c_in).copy_(
             xp.as_strided((batch, n_tiles, window, fp, c_in),
                           (need * fp * c_in, step * fp * c_in, fp * c_in, c_in, 1)))
+        return {'tiles': tiles, 'geometry': (batch, c_in, frames, freq, t_out, n_tiles, window,
+                                             step, need, fp, calls)}
+
+    def _conv_fwd_tiled(self, layer, x, pads):
+        """SAME convolution + bias of one layer as fixed-shape calls (see ``conv_mode``).
+        ``x`` logical NCHW / physical NHWC.  Returns (y like the direct path, context)."""
+        p = self.arena.p
+        s_t, s_f = CONV_STRIDES[layer]
+        ctx = self._conv_tiles(layer, x, pads)
+        tiles, nfix = ctx['tiles'], self.conv_tile_batch
+        batch, _, _, _, t_out, n_tiles, _, _, _, _, calls = ctx['geometry']
+        total = batch * n_tiles
         weight, bias = self._conv_kernel_cl(layer), p['conv{}/bias'.format(layer)]
         out = None
         for call in range(calls):
@@ -472,8 +506,6 @@ class CTCModel:
         f_out, c_out = out.shape[2], out.shape[3]
         y = out[:total].view(batch, n_tiles * self.conv_tile_frames, f_out, c_out)[:, :t_out] \
             .contiguous().permute(0, 3, 1, 2)
-        ctx = {'tiles': tiles, 'geometry': (batch, c_in, frames, freq, t_out, n_tiles, window,
-                                            step, need, fp, calls, f_out, c_out)}
         return y, ctx
 
     def _conv_bwd_tiled(self, layer, dz_phys, ctx, pads, need_dx):
@@ -481,8 +513,8 @@ class CTCModel:
         the layer input, physical NHWC, or None; kernel gradient [Cout, Cin, kt, kf])."""
         pt0, _, pf0, _ = pads
         s_t, s_f = CONV_STRIDES[layer]
-        (batch, c_in, frames, freq, t_out, n_tiles, window, step, need, fp, calls, f_out,
-         c_out) = ctx['geometry']
+        batch, c_in, frames, freq, t_out, n_tiles, window, step, need, fp, calls = ctx['geometry']
+        f_out, c_out = dz_phys.shape[2], dz_phys.shape[3]
         tiles, nfix, tile = ctx['tiles'], self.conv_tile_batch, self.conv_tile_frames
         total = batch * n_tiles
         dz_tiles = torch.zeros((calls * nfix, tile, f_out, c_out), dtype=torch.float32,
@@ -756,22 +788,22 @@ class CTCModel:
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 # the 11x21 / stride (1,2) / 32->32 layer has its own data-gradient kernel
                 # (implicit GEMM, any T, no padded intermediates: 0.62 ms vs 1.6 ms at C2)
-                own_dx = (i > 0 and self.own_conv_bwd_data and
-                          tuple(p[name + '/kernel'].shape) == (32, 32, 11, 21) and
-                          CONV_STRIDES[i] == (1, 2) and dz.shape[3] == 20)
+                own = self._own_conv_layer(i, 2 * dz.shape[3])
+                own_dx = i > 0 and own
                 need_dx = i > 0 and not own_dx
-                if own_dx:
-                    dact = hip.conv_s12_bwd_data(dz.permute(0, 2, 3, 1), p[name + '/kernel'],
-                                                 self._conv_packed)
+                conv_in = acts['conv_in'][i]
+                if own:         # forward kept the plain input only
+                    conv_in = self._conv_wrw_input(i, conv_in, acts['pads'][i])
+                if own_dx:      # (packed by the forward pass of this step)
+                    dact = hip.conv_s12_bwd_data(dz.permute(0, 2, 3, 1), self._conv_packed)
                 if self.conv_mode == 'tiled':
-                    dx_phys, dw = self._conv_bwd_tiled(i, dz.permute(0, 2, 3, 1),
-                                                       acts['conv_in'][i], acts['pads'][i],
-                                                       need_dx)
+                    dx_phys, dw = self._conv_bwd_tiled(i, dz.permute(0, 2, 3, 1), conv_in,
+                                                       acts['pads'][i], need_dx)
                     g[name + '/kernel'].copy_(dw)
                     if need_dx:
                         dact = dx_phys
                 else:
-                    xp = acts['conv_in'][i]
+                    xp = conv_in
                     dxp, dw, _ = torch.ops.aten.convolution_backward(
                         dz, xp, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
                         list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,

@@ -180,13 +180,16 @@ int ctcasr_dropout(const float *in, float *out, int64_t n, float dropout_rate, u
 int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t rows, int cols,
                              ctcasr_stream_t stream);
 
-/* ---- data gradient of the second DS2 convolution (11 x 21 taps, stride (1, 2), 32 -> 32
- * channels, TensorFlow SAME padding; asr/util/tf_contrib.py:64-146) ---------------------------
- * Implicit GEMM on the fp32 MFMA units, NHWC, no padded intermediates:
- *   dz [B, T, 20, 32] -> dx [B, T, 40, 32].
- * `packed` is a fragment-ordered copy of the kernel w [Cout=32, Cin=32, 11, 21] made by
- * ctcasr_conv_s12_pack_weights (11*21*32*32 floats). */
+/* ---- the second DS2 convolution (11 x 21 taps, stride (1, 2), 32 -> 32 channels, TensorFlow
+ * SAME padding; asr/util/tf_contrib.py:64-146): forward and data gradient ------------------------
+ * Implicit GEMM on the fp32 MFMA units, NHWC, any number of frames, no padded intermediates:
+ *   fwd:       x  [B, T, 40, 32] -> y  [B, T, 20, 32] = conv(x) + bias  (bias may be NULL)
+ *   bwd_data:  dz [B, T, 20, 32] -> dx [B, T, 40, 32]
+ * `packed` holds fragment-ordered copies of the kernel w [Cout=32, Cin=32, 11, 21] made by
+ * ctcasr_conv_s12_pack_weights: 2 * 11*21*32*32 floats (backward order, then forward order). */
 int ctcasr_conv_s12_pack_weights(const float *w, float *packed, ctcasr_stream_t stream);
+int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
+                        int T, ctcasr_stream_t stream);
 int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B, int T,
                              ctcasr_stream_t stream);
 

@@ -328,18 +328,29 @@ def test_dropout_kernel(hip):
 
 
 @pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (1, 500)])
-def test_conv_s12_bwd_data_matches_the_library_convolution(hip, shape):
-    """Implicit-GEMM data gradient of the 11x21 / stride (1,2) / 32->32 layer against torch's
-    convolution backward on the explicitly SAME-padded input (pad 5/5 in time, 9/10 in
+def test_conv_s12_kernels_match_the_library_convolution(hip, shape):
+    """Implicit-GEMM forward and data gradient of the 11x21 / stride (1,2) / 32->32 layer against
+    torch's convolution on the explicitly SAME-padded input (pad 5/5 in time, 9/10 in
     frequency), fp64 on the CPU."""
     batch, frames = shape
     rng = np.random.default_rng(frames)
+    x_np = rng.normal(size=(batch, frames, 40, 32)).astype(np.float32)
     dz = rng.normal(size=(batch, frames, 20, 32)).astype(np.float32)
     weight = (rng.normal(size=(32, 32, 11, 21)) * 0.05).astype(np.float32)
-    dx = hip.conv_s12_bwd_data(_t(dz), _t(weight)).cpu().numpy()
-    x = torch.zeros(batch, 32, frames + 10, 40 + 19, dtype=torch.float64, requires_grad=True)
-    y = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64), stride=(1, 2))
+    bias = rng.normal(size=32).astype(np.float32)
+    packed = hip.conv_s12_pack_weights(_t(weight))
+    y_gpu = hip.conv_s12_fwd(_t(x_np), packed, _t(bias)).cpu().numpy()
+    y_nobias = hip.conv_s12_fwd(_t(x_np), packed).cpu().numpy()
+    dx = hip.conv_s12_bwd_data(_t(dz), packed).cpu().numpy()
+    x = torch.zeros(batch, 32, frames + 10, 40 + 19, dtype=torch.float64)
+    x[:, :, 5:5 + frames, 9:9 + 40] = torch.tensor(x_np, dtype=torch.float64).permute(0, 3, 1, 2)
+    x.requires_grad_(True)
+    y = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64),
+                                   torch.tensor(bias, dtype=torch.float64), stride=(1, 2))
     assert tuple(y.shape) == (batch, 32, frames, 20)
+    ref_y = y.detach().permute(0, 2, 3, 1).numpy()
+    assert np.abs(y_gpu - ref_y).max() < 2e-4 * max(1.0, np.abs(ref_y).max())
+    assert np.abs(y_nobias + bias - ref_y).max() < 2e-4 * max(1.0, np.abs(ref_y).max())
     y.backward(torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
     ref = x.grad[:, :, 5:5 + frames, 9:9 + 40].permute(0, 2, 3, 1).numpy()
     assert dx.shape == ref.shape

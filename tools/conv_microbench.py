@@ -30,10 +30,17 @@ def main():
     gen = torch.Generator(device='cuda').manual_seed(0)
     dz = torch.randn(batch, frames, 20, 32, device='cuda', generator=gen)
     weight = torch.randn(32, 32, 11, 21, device='cuda', generator=gen) * 0.05
-    packed = torch.empty(11 * 21 * 32 * 32, device='cuda')
+    packed = hip.conv_s12_pack_weights(weight)
     out = torch.empty(batch, frames, 40, 32, device='cuda')
+    x = torch.randn(batch, frames, 40, 32, device='cuda', generator=gen)
+    y = torch.empty(batch, frames, 20, 32, device='cuda')
+    bias = torch.randn(32, device='cuda', generator=gen)
     flops = 2.0 * batch * frames * 20 * 32 * 32 * 11 * 21
-    ms = timed(lambda: hip.conv_s12_bwd_data(dz, weight, packed, out))
+    ms = timed(lambda: hip.conv_s12_pack_weights(weight, packed))
+    print('pack weights: {:.3f} ms'.format(ms))
+    ms = timed(lambda: hip.conv_s12_fwd(x, packed, bias, y))
+    print('conv_s12_fwd: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    ms = timed(lambda: hip.conv_s12_bwd_data(dz, packed, out))
     print('conv_s12_bwd_data: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     xp = torch.zeros(batch, 32, frames + 10, 59, device='cuda') \
         .contiguous(memory_format=torch.channels_last)
@@ -47,7 +54,20 @@ def main():
         return dxp[:, :, 5:5 + frames, 9:49].permute(0, 2, 3, 1).contiguous()
     ms = timed(library)
     print('MIOpen bwd-data + interior copy: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
-    print('max |diff| {:.2e}'.format(float((library() - out).abs().max())))
+    print('bwd-data max |diff| {:.2e}'.format(float((library() - out).abs().max())))
+    xpad = torch.zeros(batch, 32, frames + 10, 59, device='cuda') \
+        .contiguous(memory_format=torch.channels_last)
+    xpad[:, :, 5:5 + frames, 9:49] = x.permute(0, 3, 1, 2)
+
+    def library_fwd():
+        padded = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (9, 10, 5, 5)) \
+            .contiguous(memory_format=torch.channels_last)
+        return torch.ops.aten.convolution(padded, w_cl, bias, [1, 2], [0, 0], [1, 1], False,
+                                          [0, 0], 1)
+    ms = timed(library_fwd)
+    print('MIOpen fwd incl. padding copy: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    print('fwd max |diff| {:.2e}'.format(
+        float((library_fwd().permute(0, 2, 3, 1) - y).abs().max())))
 
 
 if __name__ == '__main__':

@@ -1,33 +1,38 @@
-// Data gradient of the DS2 stack's 11 x 21, stride (1, 2), 32 -> 32 channel convolution (the second
-// conv layer, asr/util/tf_contrib.py:64-146) as an implicit GEMM on the fp32 MFMA units.
+// The 11 x 21, stride (1, 2) convolutions over 32 input channels of the DS2 stack (layers 2 and 3 of
+// tf_contrib.conv_layers, asr/util/tf_contrib.py:64-146: 32 -> 32 channels on 40 input frequencies,
+// 32 -> 96 on 20) as implicit GEMMs on the fp32 MFMA units: forward pass and data gradient.
 //
-// MIOpen's best kernel for this layer's backward-data runs at ~60 TFLOP/s and needs a zero-fill of
-// its padded output plus a strided copy of the interior afterwards (1.6 ms of the 25 ms C2 step).
-// Here the padding never exists: out-of-range taps read zeros from the LDS patch and the result is
-// written straight into the unpadded NHWC tensor the layer below consumes.
+// MIOpen's best kernels for the 32 -> 32 layer reach 81 TFLOP/s forward and ~60 TFLOP/s
+// backward-data, the latter plus a zero-fill of its padded output and a strided copy of the
+// interior afterwards (2.5 ms of the 25 ms C2 step together).  Here the padding never exists:
+// out-of-range taps read zeros from the LDS patch and results go straight to the unpadded NHWC
+// tensor.  Any number of frames (grid = ceil(T / TT) x B), so variable-length batches need no
+// fixed-shape tiling for these layers.
 //
-//   dx[b, t, f, ci] = sum_{kt, kf, co} dz[b, t + 5 - kt, (f + 9 - kf) / 2, co] * w[co, ci, kt, kf]
-//                     (terms with f + 9 - kf odd or indices out of range vanish)
+//   forward   y[b, t, fo, co] = bias[co] + sum_{kt,kf,ci} x[b, t+kt-5, 2fo+kf-9, ci] w[co,ci,kt,kf]
+//   backward  dx[b, t, f, ci] = sum_{kt,kf,co} dz[b, t+5-kt, (f+9-kf)/2, co] w[co,ci,kt,kf]
+//             (terms with f + 9 - kf odd or indices out of range vanish)
 //
-// One workgroup = one utterance x 16 output frames x all 40 frequencies x all 32 channels.  Its
-// slice of dz (26 frames x 20 frequencies x 32 channels, zero border of 5 frequencies each side)
-// sits in LDS with a row pitch of 36 floats (conflict-free 16-byte fragment reads).  Output rows
-// of equal frequency parity see the same set of kf taps, so the M tiles are built per parity:
-// 4 frames x 20 positions = 80 rows = 5 tiles; a wave owns 4 frames = 10 M tiles x 2 N tiles.
-// Per tap the B fragments (weights, pre-packed in fragment order, L2-resident) are shared by a
-// wave's 5 tiles; the A fragment of a row is the patch shifted by a tap-uniform offset.
+// One workgroup = one utterance x TT output frames x all frequencies x all channels; its input
+// slice sits in LDS as [TT + 10 frames][FO + 10 positions][36-float pitch] (32 channels per cell;
+// the pitch makes the 16-byte fragment reads of 16 neighbouring rows conflict-free).  The stride-2
+// frequency axis is handled by parity.  In padded coordinates fp = 2 fo + kf, so
+//   forward:  a tap of parity par = kf & 1 only reads input frequencies of that parity - the patch
+//             holds one parity plane at a time, position = fo + kf / 2;
+//   backward: output rows of equal frequency parity see the same kf taps - M tiles are built per
+//             parity, dz position = j + 4 + p - kf / 2 for output frequency f = 2 j + p;
+// either way the A fragment of a row is "lane base address + tap-uniform offset".  A wave owns
+// TT / 4 frames = 80 rows = 5 M tiles.  The weights are re-packed once per step into fragment
+// order (L2 resident); the B fragments of a tap are shared by the wave's 5 M tiles.  With 96
+// output channels the backward pass stages dz in three 32-channel passes (the patch would not
+// fit otherwise) and keeps accumulating.
 #include "common.h"
 
 namespace {
 
-constexpr int CV_C = 32;           // channels in and out
-constexpr int CV_FO = 20;          // frequencies of dz (conv output)
-constexpr int CV_FI = 40;          // frequencies of dx (conv input)
+constexpr int CV_CIN = 32;
 constexpr int CV_KT = 11, CV_KF = 21;
-constexpr int CV_TT = 16;          // output frames per workgroup
-constexpr int CV_PF = CV_FO + 10;  // patch frequencies: 5 zero columns each side
-constexpr int CV_PITCH = 36;       // floats per (frame, frequency) cell of the patch
-constexpr int CV_PT = CV_TT + CV_KT - 1;
+constexpr int CV_PITCH = 36;       // floats per (frame, position) cell of the patch
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,145 +43,156 @@ __device__ __forceinline__ void mma4(f32x4 &acc, const float4 &a, const float4 &
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
 }
 
-// The four B fragments of a tap: K chunks q = 0, 1 x N tiles 0, 1 (packed order, see below).
-struct BFrag { float4 b00, b01, b10, b11; };
-__device__ __forceinline__ BFrag load_b(const float4 *__restrict__ wp, int kt, int kf, int kg,
-                                        int n) {
-    const float4 *wt = wp + (size_t)((kt * CV_KF + kf) * 8 + kg) * 32 + n;
-    return BFrag{wt[0], wt[16], wt[4 * 32], wt[4 * 32 + 16]};
-}
+template <int COUT, int FI>
+struct Geometry {
+    static constexpr int FO = FI / 2;            // output frequencies
+    static constexpr int TT = FO == 20 ? 16 : 32;   // output frames per workgroup: 80 rows per wave
+    static constexpr int PF = FO + 10;           // patch positions per frame
+    static constexpr int PT = TT + CV_KT - 1;    // patch frames
+    static constexpr int NT = COUT / 16;         // N tiles forward, K chunks backward
+    static constexpr size_t LDS = (size_t)PT * PF * CV_PITCH * sizeof(float);
+    static_assert((TT / 4) * FO == 80, "a wave owns 5 M tiles");
+};
 
-// w [Cout, Cin, kt, kf] (the arena's compute layout) -> packed[kt][kf][q][kg][ci][r] with
-// co = 16 q + 4 kg + r: lane (ci & 15, kg) of N tile ci / 16 reads one float4.
-__global__ void conv_pack_bwd_kernel(const float *__restrict__ w, float *__restrict__ packed) {
+// Packed weights, forward order: [kt][kf][q (2)][kg (4)][co (COUT)][r (4)], ci = 16 q + 4 kg + r:
+// lane (n = co & 15, kg) of N tile co / 16 reads one float4 per K chunk q.
+// Backward order: [kt][kf][qc (COUT / 16)][kg (4)][ci (32)][r (4)], co = 16 qc + 4 kg + r.
+// w is [COUT, 32, kt, kf] (the arena's compute layout).
+__global__ void conv_pack_kernel(const float *__restrict__ w, float *__restrict__ bwd,
+                                 float *__restrict__ fwd, int cout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= CV_KT * CV_KF * CV_C * CV_C) return;
-    const int r = i & 3, ci = (i >> 2) & 31, kg = (i >> 7) & 3, q = (i >> 9) & 1;
-    const int tap = i >> 10, kf = tap % CV_KF, kt = tap / CV_KF;
-    const int co = 16 * q + 4 * kg + r;
-    packed[i] = w[((co * CV_C + ci) * CV_KT + kt) * CV_KF + kf];
+    const int per_tap = CV_CIN * cout;
+    if (i >= CV_KT * CV_KF * per_tap) return;
+    const int tap = i / per_tap, rest = i % per_tap, kf = tap % CV_KF, kt = tap / CV_KF;
+    const int r = rest & 3;
+    {   // backward order
+        const int ci = (rest >> 2) & 31, kg = (rest >> 7) & 3, qc = rest >> 9;
+        const int co = 16 * qc + 4 * kg + r;
+        bwd[i] = w[((co * CV_CIN + ci) * CV_KT + kt) * CV_KF + kf];
+    }
+    {   // forward order
+        const int co = (rest >> 2) % cout, kg = ((rest >> 2) / cout) & 3, q = (rest >> 2) / (4 * cout);
+        const int ci = 16 * q + 4 * kg + r;
+        fwd[i] = w[((co * CV_CIN + ci) * CV_KT + kt) * CV_KF + kf];
+    }
 }
 
-// Forward pass of the same layer, same machinery:
-//   y[b, t, fo, co] = bias[co] + sum_{kt, kf, ci} x[b, t + kt - 5, 2 fo + kf - 9, ci] * w[co, ci, kt, kf]
-// In padded coordinates fp = 2 fo + kf, so a tap of parity par = kf & 1 only ever reads input
-// frequencies of that parity: the patch is staged twice, once per parity plane
-// (26 frames x 30 positions x 32 channels), position = fo + kf / 2 - which makes the A fragment
-// of a row, again, the lane's base address plus a tap-uniform offset.
-// packed (forward): [kt][kf][q][kg][co][r] with ci = 16 q + 4 kg + r.
-__global__ void conv_pack_fwd_kernel(const float *__restrict__ w, float *__restrict__ packed) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= CV_KT * CV_KF * CV_C * CV_C) return;
-    const int r = i & 3, co = (i >> 2) & 31, kg = (i >> 7) & 3, q = (i >> 9) & 1;
-    const int tap = i >> 10, kf = tap % CV_KF, kt = tap / CV_KF;
-    const int ci = 16 * q + 4 * kg + r;
-    packed[i] = w[((co * CV_C + ci) * CV_KT + kt) * CV_KF + kf];
-}
-
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int COUT, int FI>
 __global__ void __launch_bounds__(256)
 conv_fwd_kernel(const float *__restrict__ x, const float4 *__restrict__ wp,
                 const float *__restrict__ bias, float *__restrict__ y, int T) {
-    extern __shared__ __attribute__((aligned(16))) float patch[];   // [CV_PT][CV_PF][CV_PITCH]
+    using G = Geometry<COUT, FI>;
+    constexpr int NT = G::NT;
+    extern __shared__ __attribute__((aligned(16))) float patch[];   // [PT][PF][CV_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * CV_TT, b = blockIdx.y;
+    const int t0 = blockIdx.x * G::TT, b = blockIdx.y;
+    const int kg = lane >> 4, n = lane & 15;
+    float4 *patch4 = reinterpret_cast<float4 *>(patch);
+
+    int base_a[5];                      // float index of (frame, position) of this lane's row
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti) {
+        const int row = ti * 16 + n, tt = row / G::FO, fo = row % G::FO;
+        base_a[ti] = (((G::TT / 4) * wave + tt) * G::PF + fo) * CV_PITCH + 4 * kg;
+    }
+    f32x4 acc[5][NT];
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the 2 * NT B fragments of tap (kt, kf): K chunk q, N tile nt
+    auto load_b = [&](int kt, int kf, float4 (&dst)[2][NT]) {
+        const float4 *wt = wp + (size_t)((kt * CV_KF + kf) * 8 + kg) * COUT + n;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dst[q][nt] = wt[q * 4 * COUT + nt * 16];
+    };
+
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {    // unrolled: compile-time tap counts in both copies
+        if (par) __syncthreads();          // everyone is done reading the other plane
+        for (int i = tid; i < G::PT * G::PF * 8; i += 256) {
+            const int c4 = i & 7, pos = (i >> 3) % G::PF, pr = i / (8 * G::PF);
+            const int ts = t0 - 5 + pr, fi = 2 * pos + par - 9;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ts >= 0 && ts < T && fi >= 0 && fi < FI)
+                v = reinterpret_cast<const float4 *>(x)[((size_t)(b * T + ts) * FI + fi) * 8 + c4];
+            patch4[((pr * G::PF + pos) * CV_PITCH) / 4 + c4] = v;
+        }
+        __syncthreads();
+        const int taps = par == 0 ? 11 : 10;
+        // B fragments (weights, from L2) run one tap ahead of the MFMAs that use them; the
+        // scheduling barriers keep hipcc from sinking the loads next to their first use
+        float4 cur[2][NT], nxt[2][NT];
+        load_b(0, par, cur);
+        for (int kt = 0; kt < CV_KT; ++kt) {
+#pragma unroll
+            for (int m = 0; m < taps; ++m) {
+                const bool wrap = m + 1 == taps;
+                load_b(wrap ? min(kt + 1, CV_KT - 1) : kt, wrap ? par : 2 * (m + 1) + par, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                const int tap_off = (kt * G::PF + m) * CV_PITCH;
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off);
+                    const float4 a1 =
+                        *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off + 16);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma4(acc[ti][nt], a0, cur[0][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma4(acc[ti][nt], a1, cur[1][nt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) cur[q][nt] = nxt[q][nt];
+            }
+        }
+    }
+
+    float bias_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias_v[nt] = bias ? bias[nt * 16 + n] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + 4 * kg + r, tt = row / G::FO, fo = row % G::FO;
+            const int t = t0 + (G::TT / 4) * wave + tt;
+            if (t < T) {
+                float *out = y + ((size_t)(b * T + t) * G::FO + fo) * COUT + n;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) out[nt * 16] = acc[ti][nt][r] + bias_v[nt];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward data
+// ---------------------------------------------------------------------------------------------
+template <int COUT, int FI>
+__global__ void __launch_bounds__(256)
+conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp,
+                     float *__restrict__ dx, int T) {
+    using G = Geometry<COUT, FI>;
+    constexpr int PASSES = COUT / 32;           // 32 dz channels staged at a time
+    extern __shared__ __attribute__((aligned(16))) float patch[];   // [PT][PF][CV_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * G::TT, b = blockIdx.y;
     const int kg = lane >> 4, n = lane & 15;
     float4 *patch4 = reinterpret_cast<float4 *>(patch);
 
     int base_a[5];
 #pragma unroll
     for (int ti = 0; ti < 5; ++ti) {
-        const int row = ti * 16 + n, tt = row / CV_FO, fo = row % CV_FO;
-        base_a[ti] = ((4 * wave + tt) * CV_PF + fo) * CV_PITCH + 4 * kg;
-    }
-    f32x4 acc[5][2];
-#pragma unroll
-    for (int ti = 0; ti < 5; ++ti)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {    // unrolled: compile-time tap counts in both copies
-        if (par) __syncthreads();          // everyone is done reading the other plane
-        for (int i = tid; i < CV_PT * CV_PF * 8; i += 256) {
-            const int c4 = i & 7, pos = (i >> 3) % CV_PF, pr = i / (8 * CV_PF);
-            const int ts = t0 - 5 + pr, fi = 2 * pos + par - 9;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ts >= 0 && ts < T && fi >= 0 && fi < CV_FI)
-                v = reinterpret_cast<const float4 *>(x)[((size_t)(b * T + ts) * CV_FI + fi) * 8 + c4];
-            patch4[((pr * CV_PF + pos) * CV_PITCH) / 4 + c4] = v;
-        }
-        __syncthreads();
-        const int taps = par == 0 ? 11 : 10;
-        // B fragments (weights, from L2) run one tap ahead of the MFMAs that use them; the
-        // scheduling barriers keep hipcc from sinking the loads next to their first use
-        BFrag cur = load_b(wp, 0, par, kg, n);
-        for (int kt = 0; kt < CV_KT; ++kt) {
-#pragma unroll
-            for (int m = 0; m < taps; ++m) {
-                const bool wrap = m + 1 == taps;
-                const BFrag nxt = load_b(wp, wrap ? min(kt + 1, CV_KT - 1) : kt,
-                                         wrap ? par : 2 * (m + 1) + par, kg, n);
-                __builtin_amdgcn_sched_barrier(0);
-                const int tap_off = (kt * CV_PF + m) * CV_PITCH;
-#pragma unroll
-                for (int ti = 0; ti < 5; ++ti) {
-                    const float4 a0 = *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off);
-                    const float4 a1 =
-                        *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off + 16);
-                    mma4(acc[ti][0], a0, cur.b00);
-                    mma4(acc[ti][1], a0, cur.b01);
-                    mma4(acc[ti][0], a1, cur.b10);
-                    mma4(acc[ti][1], a1, cur.b11);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
-            }
-        }
-    }
-
-    const float bias0 = bias ? bias[n] : 0.f, bias1 = bias ? bias[16 + n] : 0.f;
-#pragma unroll
-    for (int ti = 0; ti < 5; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + 4 * kg + r, tt = row / CV_FO, fo = row % CV_FO;
-            const int t = t0 + 4 * wave + tt;
-            if (t < T) {
-                float *out = y + ((size_t)(b * T + t) * CV_FO + fo) * CV_C + n;
-                out[0] = acc[ti][0][r] + bias0;
-                out[16] = acc[ti][1][r] + bias1;
-            }
-        }
-}
-
-__global__ void __launch_bounds__(256)
-conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp,
-                     float *__restrict__ dx, int T) {
-    extern __shared__ __attribute__((aligned(16))) float patch[];   // [CV_PT][CV_PF][CV_PITCH]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * CV_TT, b = blockIdx.y;
-
-    // ---- stage dz[b, t0-5 .. t0+20, :, :] with its zero border ------------------------------
-    float4 *patch4 = reinterpret_cast<float4 *>(patch);
-    for (int i = tid; i < CV_PT * CV_PF * (CV_PITCH / 4); i += 256)
-        patch4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    for (int i = tid; i < CV_PT * CV_FO * (CV_C / 4); i += 256) {
-        const int c4 = i & 7, fo = (i >> 3) % CV_FO, pr = i / (8 * CV_FO);
-        const int ts = t0 - 5 + pr;
-        if (ts >= 0 && ts < T)
-            patch4[((pr * CV_PF + fo + 5) * CV_PITCH) / 4 + c4] =
-                reinterpret_cast<const float4 *>(dz)[((size_t)(b * T + ts) * CV_FO + fo) * 8 + c4];
-    }
-    __syncthreads();
-
-    // ---- per-lane fragment addresses -----------------------------------------------------------
-    const int kg = lane >> 4, n = lane & 15;
-    int base_a[5];                       // float index of (frame, position) of this lane's row
-#pragma unroll
-    for (int ti = 0; ti < 5; ++ti) {
-        const int row = ti * 16 + n, tt = row / CV_FO, j = row % CV_FO;
-        base_a[ti] = ((4 * wave + tt) * CV_PF + j) * CV_PITCH + 4 * kg;
+        const int row = ti * 16 + n, tt = row / G::FO, j = row % G::FO;
+        base_a[ti] = (((G::TT / 4) * wave + tt) * G::PF + j) * CV_PITCH + 4 * kg;
     }
     f32x4 acc[2][5][2];
 #pragma unroll
@@ -186,27 +202,47 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[p][ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- taps -----------------------------------------------------------------------------------
-    for (int kt = 0; kt < CV_KT; ++kt) {
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        // ---- stage dz[b, t0-5 .. , :, 32 pass .. 32 pass + 31] with 5 zero positions each side ----
+        if (pass) __syncthreads();
+        for (int i = tid; i < G::PT * G::PF * 8; i += 256) {
+            const int c4 = i & 7, pos = (i >> 3) % G::PF, pr = i / (8 * G::PF);
+            const int ts = t0 - 5 + pr, fo = pos - 5;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ts >= 0 && ts < T && fo >= 0 && fo < G::FO)
+                v = reinterpret_cast<const float4 *>(dz)[((size_t)(b * T + ts) * G::FO + fo) *
+                                                             (COUT / 4) + pass * 8 + c4];
+            patch4[((pr * G::PF + pos) * CV_PITCH) / 4 + c4] = v;
+        }
+        __syncthreads();
+
+        // ---- taps (no explicit weight prefetch: hipcc's own schedule of this loop nest reaches
+        // 138 TFLOP/s on the 32 -> 32 layer, the pinned one-tap-ahead variant 131) -------------
+        for (int kt = 0; kt < CV_KT; ++kt) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            // even output frequencies (f = 2j) meet the odd kf, odd ones (f = 2j+1) the even kf;
-            // dz frequency = j + 4 + p - m with m = kf / 2
-            const int taps = p == 0 ? 10 : 11;
-            // (no explicit weight prefetch here: hipcc's own schedule of this loop nest reaches
-            // 138 TFLOP/s, the pinned one-tap-ahead variant of the forward kernel 131)
-            for (int m = 0; m < taps; ++m) {
-                const BFrag cur = load_b(wp, kt, p == 0 ? 2 * m + 1 : 2 * m, kg, n);
-                const int tap_off = ((10 - kt) * CV_PF + 9 + p - m) * CV_PITCH;
+            for (int p = 0; p < 2; ++p) {
+                // even output frequencies (f = 2j) meet the odd kf, odd ones (f = 2j+1) the even
+                // kf; dz position = j + 4 + p - m (+5 for the zero border) with m = kf / 2
+                const int taps = p == 0 ? 10 : 11;
+                for (int m = 0; m < taps; ++m) {
+                    const int kf = p == 0 ? 2 * m + 1 : 2 * m;
+                    // K chunks 2 pass, 2 pass + 1 of this tap; N tiles ci 0..15, 16..31
+                    const float4 *wt =
+                        wp + (size_t)(((kt * CV_KF + kf) * (COUT / 16) + 2 * pass) * 4 + kg) * 32 + n;
+                    const float4 b00 = wt[0], b01 = wt[16], b10 = wt[4 * 32], b11 = wt[4 * 32 + 16];
+                    const int tap_off = ((10 - kt) * G::PF + 9 + p - m) * CV_PITCH;
 #pragma unroll
-                for (int ti = 0; ti < 5; ++ti) {
-                    const float4 a0 = *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off);
-                    const float4 a1 =
-                        *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off + 16);
-                    mma4(acc[p][ti][0], a0, cur.b00);
-                    mma4(acc[p][ti][1], a0, cur.b01);
-                    mma4(acc[p][ti][0], a1, cur.b10);
-                    mma4(acc[p][ti][1], a1, cur.b11);
+                    for (int ti = 0; ti < 5; ++ti) {
+                        const float4 a0 =
+                            *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off);
+                        const float4 a1 =
+                            *reinterpret_cast<const float4 *>(patch + base_a[ti] + tap_off + 16);
+                        mma4(acc[p][ti][0], a0, b00);
+                        mma4(acc[p][ti][1], a0, b01);
+                        mma4(acc[p][ti][0], a1, b10);
+                        mma4(acc[p][ti][1], a1, b11);
+                    }
                 }
             }
         }
@@ -219,56 +255,79 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
         for (int ti = 0; ti < 5; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + 4 * kg + r, tt = row / CV_FO, j = row % CV_FO;
-                const int t = t0 + 4 * wave + tt;
+                const int row = ti * 16 + 4 * kg + r, tt = row / G::FO, j = row % G::FO;
+                const int t = t0 + (G::TT / 4) * wave + tt;
                 if (t < T) {
-                    float *out = dx + ((size_t)(b * T + t) * CV_FI + 2 * j + p) * CV_C + n;
+                    float *out = dx + ((size_t)(b * T + t) * FI + 2 * j + p) * CV_CIN + n;
                     out[0] = acc[p][ti][0][r];
                     out[16] = acc[p][ti][1][r];
                 }
             }
 }
 
-}  // namespace
-
-// Fragment-ordered copies of the layer's kernel for ctcasr_conv_s12_bwd_data and _fwd (2 x 946 KB;
-// the weights change every step).  w: [32, 32, 11, 21] = [Cout, Cin, kt, kf].
-extern "C" int ctcasr_conv_s12_pack_weights(const float *w, float *packed, ctcasr_stream_t stream) {
-    if (!w || !packed) return CTCASR_ERR_BAD_ARGUMENT;
-    const int n = CV_KT * CV_KF * CV_C * CV_C;
-    conv_pack_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, packed);
-    conv_pack_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, packed + n);
+template <int COUT, int FI>
+int launch_fwd(const float *x, const float *packed, const float *bias, float *y, int B, int T,
+               hipStream_t s) {
+    using G = Geometry<COUT, FI>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_kernel<COUT, FI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    dim3 grid((T + G::TT - 1) / G::TT, B);
+    const size_t per_order = (size_t)CV_KT * CV_KF * CV_CIN * COUT;
+    conv_fwd_kernel<COUT, FI><<<grid, 256, G::LDS, s>>>(
+        x, reinterpret_cast<const float4 *>(packed + per_order), bias, y, T);
     return ctcasr_launch_status();
 }
 
-// x [B, T, 40, 32] (NHWC) -> y [B, T, 20, 32] = conv(x) + bias (bias may be NULL).  `packed` holds
-// 2 x 11*21*32*32 floats: ctcasr_conv_s12_pack_weights fills the backward order first, then the
-// forward order.
-extern "C" int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y,
-                                   int B, int T, ctcasr_stream_t stream) {
-    if (!x || !packed || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
-    if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)CV_PT * CV_PF * CV_PITCH * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+template <int COUT, int FI>
+int launch_bwd(const float *dz, const float *packed, float *dx, int B, int T, hipStream_t s) {
+    using G = Geometry<COUT, FI>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bwd_data_kernel<COUT, FI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    dim3 grid((T + CV_TT - 1) / CV_TT, B);
-    conv_fwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(
-        x, reinterpret_cast<const float4 *>(packed + CV_KT * CV_KF * CV_C * CV_C), bias, y, T);
-    return ctcasr_launch_status();
-}
-
-// dz [B, T, 20, 32] (NHWC, gradient w.r.t. the layer's pre-activation output) -> dx [B, T, 40, 32].
-extern "C" int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B,
-                                        int T, ctcasr_stream_t stream) {
-    if (!dz || !packed || !dx || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
-    if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)CV_PT * CV_PF * CV_PITCH * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bwd_data_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
-    dim3 grid((T + CV_TT - 1) / CV_TT, B);
-    conv_bwd_data_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(
+    dim3 grid((T + G::TT - 1) / G::TT, B);
+    conv_bwd_data_kernel<COUT, FI><<<grid, 256, G::LDS, s>>>(
         dz, reinterpret_cast<const float4 *>(packed), dx, T);
     return ctcasr_launch_status();
+}
+
+bool covered(int freq_in, int cout) {
+    return (freq_in == 40 && cout == 32) || (freq_in == 20 && cout == 96);
+}
+
+}  // namespace
+
+// 1 for the (input frequencies, output channels) pairs the kernels are instantiated for: the
+// second (40, 32) and third (20, 96) convolution of the reference's stack.
+extern "C" int ctcasr_conv_s12_supported(int freq_in, int cout) { return covered(freq_in, cout); }
+
+// Fragment-ordered copies of a layer's kernel w [cout, 32, 11, 21]: `packed` holds
+// 2 * 11*21*32*cout floats (backward order, then forward order).  The weights change every step.
+extern "C" int ctcasr_conv_s12_pack_weights(const float *w, float *packed, int cout,
+                                            ctcasr_stream_t stream) {
+    if (!w || !packed || (cout != 32 && cout != 96)) return CTCASR_ERR_BAD_ARGUMENT;
+    const int n = CV_KT * CV_KF * CV_CIN * cout;
+    conv_pack_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, packed, packed + n, cout);
+    return ctcasr_launch_status();
+}
+
+// x [B, T, freq_in, 32] (NHWC) -> y [B, T, freq_in / 2, cout] = conv(x) + bias (bias may be NULL).
+extern "C" int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y,
+                                   int B, int T, int freq_in, int cout, ctcasr_stream_t stream) {
+    if (!x || !packed || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!covered(freq_in, cout) || B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (cout == 32) return launch_fwd<32, 40>(x, packed, bias, y, B, T, s);
+    return launch_fwd<96, 20>(x, packed, bias, y, B, T, s);
+}
+
+// dz [B, T, freq_in / 2, cout] (NHWC, gradient w.r.t. the layer's pre-activation output)
+// -> dx [B, T, freq_in, 32].
+extern "C" int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B,
+                                        int T, int freq_in, int cout, ctcasr_stream_t stream) {
+    if (!dz || !packed || !dx || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!covered(freq_in, cout) || B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (cout == 32) return launch_bwd<32, 40>(dz, packed, dx, B, T, s);
+    return launch_bwd<96, 20>(dz, packed, dx, B, T, s);
 }

@@ -47,9 +47,10 @@ SIGNATURES = {
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
-    'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_p]),
-    'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
-    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    'ctcasr_conv_s12_supported': (_c_int, [_c_int, _c_int]),
+    'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
+    'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
+    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
     'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
@@ -362,47 +363,55 @@ def colsum_accumulate(dz, dbias):
     return dbias
 
 
-CONV_S12_PACKED_FLOATS = 2 * 11 * 21 * 32 * 32
+def conv_s12_supported(freq_in, cout):
+    """Whether the own 11x21 / stride (1,2) convolution kernels cover this layer shape."""
+    return bool(load().ctcasr_conv_s12_supported(int(freq_in), int(cout)))
+
+
+def conv_s12_packed_floats(cout):
+    return 2 * 11 * 21 * 32 * cout
 
 
 def conv_s12_pack_weights(weight, packed=None):
-    """Fragment-ordered copies (backward, forward) of w f32[32,32,11,21] ([Cout,Cin,kt,kf])."""
-    if tuple(weight.shape) != (32, 32, 11, 21):
-        raise CtcAsrError('the conv_s12 kernels cover w [32,32,11,21] only.')
-    packed = torch.empty(CONV_S12_PACKED_FLOATS, dtype=torch.float32, device=weight.device) \
-        if packed is None else packed
+    """Fragment-ordered copies (backward, forward) of w f32[cout,32,11,21] ([Cout,Cin,kt,kf])."""
+    cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (32, 11, 21) or cout not in (32, 96):
+        raise CtcAsrError('the conv_s12 kernels cover w [32|96, 32, 11, 21] only.')
+    packed = torch.empty(conv_s12_packed_floats(cout), dtype=torch.float32,
+                         device=weight.device) if packed is None else packed
     _check(load().ctcasr_conv_s12_pack_weights(_dev(weight, name='weight'),
-                                               _dev(packed, name='packed'), _stream()),
+                                               _dev(packed, name='packed'), cout, _stream()),
            'conv_s12_pack_weights')
     return packed
 
 
-def conv_s12_fwd(x, packed, bias=None, out=None):
-    """x f32[B,T,40,32] (NHWC) -> conv(x) + bias, f32[B,T,20,32]; 11x21 taps, stride (1,2),
+def conv_s12_fwd(x, packed, cout, bias=None, out=None):
+    """x f32[B,T,F,32] (NHWC) -> conv(x) + bias, f32[B,T,F/2,cout]; 11x21 taps, stride (1,2),
     TensorFlow SAME padding.  ``packed`` from `conv_s12_pack_weights`."""
-    batch, frames = x.shape[0], x.shape[1]
-    if tuple(x.shape[2:]) != (40, 32):
-        raise CtcAsrError('conv_s12_fwd covers x [B,T,40,32] only.')
-    out = torch.empty((batch, frames, 20, 32), dtype=torch.float32, device=x.device) \
+    batch, frames, freq = x.shape[0], x.shape[1], x.shape[2]
+    if x.shape[3] != 32 or not conv_s12_supported(freq, cout):
+        raise CtcAsrError('conv_s12_fwd: unsupported layer shape {} -> {} channels'.format(
+            tuple(x.shape), cout))
+    out = torch.empty((batch, frames, freq // 2, cout), dtype=torch.float32, device=x.device) \
         if out is None else out
     with _Timed('conv_s12_fwd'):
         _check(load().ctcasr_conv_s12_fwd(_dev(x, name='x'), _dev(packed, name='packed'),
                                           _dev(bias, name='bias'), _dev(out, name='y'), batch,
-                                          frames, _stream()), 'conv_s12_fwd')
+                                          frames, freq, cout, _stream()), 'conv_s12_fwd')
     return out
 
 
 def conv_s12_bwd_data(dz, packed, out=None):
-    """dz f32[B,T,20,32] (NHWC) -> dx f32[B,T,40,32] of the same layer."""
-    batch, frames = dz.shape[0], dz.shape[1]
-    if tuple(dz.shape[2:]) != (20, 32):
-        raise CtcAsrError('conv_s12_bwd_data covers dz [B,T,20,32] only.')
-    out = torch.empty((batch, frames, 40, 32), dtype=torch.float32, device=dz.device) \
+    """dz f32[B,T,F/2,cout] (NHWC) -> dx f32[B,T,F,32] of the same layer."""
+    batch, frames, freq_out, cout = dz.shape
+    if not conv_s12_supported(2 * freq_out, cout):
+        raise CtcAsrError('conv_s12_bwd_data: unsupported layer shape {}'.format(tuple(dz.shape)))
+    out = torch.empty((batch, frames, 2 * freq_out, 32), dtype=torch.float32, device=dz.device) \
         if out is None else out
     with _Timed('conv_s12_bwd_data'):
         _check(load().ctcasr_conv_s12_bwd_data(_dev(dz, name='dz'), _dev(packed, name='packed'),
-                                               _dev(out, name='dx'), batch, frames, _stream()),
-               'conv_s12_bwd_data')
+                                               _dev(out, name='dx'), batch, frames,
+                                               2 * freq_out, cout, _stream()), 'conv_s12_bwd_data')
     return out
 
 

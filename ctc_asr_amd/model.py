@@ -298,11 +298,11 @@ class CTCModel:
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
         self.fuse_xw_bias = os.environ.get('CTCASR_FUSE_XW_BIAS', '1') == '1'
-        # the 11x21 / stride (1,2) / 32->32 convolution runs on this package's own implicit-GEMM
-        # kernels (forward and data gradient; any T, no padded intermediates)
+        # the 11x21 / stride (1,2) convolutions over 32 input channels (layers 2 and 3 of the
+        # reference's stack) run on this package's own implicit-GEMM kernels (forward and data
+        # gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
-        self._conv_packed = torch.empty(hip.CONV_S12_PACKED_FLOATS, dtype=torch.float32,
-                                        device=self.device)
+        self._conv_packed = {}          # layer -> fragment-ordered weight copies
         self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
         # launch has finished run beside the next launch instead of queueing up behind the layer
@@ -350,9 +350,11 @@ class CTCModel:
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
                 if self._own_conv_layer(i, x.shape[3]):
                     # weights change every step: re-pack (2 x 946 KB), then one launch
-                    hip.conv_s12_pack_weights(p['conv{}/kernel'.format(i)], self._conv_packed)
+                    kernel = p['conv{}/kernel'.format(i)]
+                    self._conv_packed[i] = hip.conv_s12_pack_weights(kernel,
+                                                                     self._conv_packed.get(i))
                     x_phys = x.permute(0, 2, 3, 1)
-                    y = hip.conv_s12_fwd(x_phys, self._conv_packed,
+                    y = hip.conv_s12_fwd(x_phys, self._conv_packed[i], kernel.shape[0],
                                          p['conv{}/bias'.format(i)]).permute(0, 3, 1, 2)
                     conv_in.append(x)      # padded / tiled for the kernel gradient on demand
                 elif self.conv_mode == 'tiled':
@@ -437,8 +439,9 @@ class CTCModel:
 
     def _own_conv_layer(self, layer, freq_in):
         kernel = self.arena.p['conv{}/kernel'.format(layer)]
-        return (self.own_conv and tuple(kernel.shape) == (32, 32, 11, 21) and
-                CONV_STRIDES[layer] == (1, 2) and freq_in == 40)
+        return (self.own_conv and tuple(kernel.shape[1:]) == (32, 11, 21) and
+                CONV_STRIDES[layer] == (1, 2) and
+                hip.conv_s12_supported(freq_in, kernel.shape[0]))
 
     def _conv_wrw_input(self, layer, x, pads):
         """What the (library) kernel-gradient pass of a layer that ran on the own forward kernel
@@ -547,9 +550,18 @@ class CTCModel:
         return dxp[:, pt0:pt0 + frames, pf0:pf0 + freq, :].contiguous(), dw_sum
 
     def _conv_kernel_cl(self, layer):
-        """Conv kernel [Cout, Cin, kt, kf] in channels_last memory (scratch copy per call)."""
-        return self.arena.p['conv{}/kernel'.format(layer)] \
-            .contiguous(memory_format=torch.channels_last)
+        """Conv kernel [Cout, Cin, kt, kf] in channels_last memory (scratch copy per call).  The
+        copy lives in a buffer with 1 KB of slack behind it: MIOpen's immediate-mode kernels for
+        very small channel counts (the 4-channel test models) read a little past the end of the
+        weight tensor, which is a GPU memory fault when that tensor happens to be the last one
+        of an allocator segment."""
+        weight = self.arena.p['conv{}/kernel'.format(layer)]
+        c_out, c_in, k_t, k_f = weight.shape
+        flat = torch.empty(weight.numel() + 256, dtype=torch.float32, device=weight.device)
+        scratch = flat.as_strided((c_out, c_in, k_t, k_f),
+                                  (k_t * k_f * c_in, 1, k_f * c_in, c_in))
+        scratch.copy_(weight)
+        return scratch
 
     def _rnn_bias(self, layer):
         """The bias folded into the input projection, one [2*G*H] vector (scratch): b_ih + b_hh,
@@ -795,7 +807,7 @@ class CTCModel:
                 if own:         # forward kept the plain input only
                     conv_in = self._conv_wrw_input(i, conv_in, acts['pads'][i])
                 if own_dx:      # (packed by the forward pass of this step)
-                    dact = hip.conv_s12_bwd_data(dz.permute(0, 2, 3, 1), self._conv_packed)
+                    dact = hip.conv_s12_bwd_data(dz.permute(0, 2, 3, 1), self._conv_packed[i])
                 if self.conv_mode == 'tiled':
                     dx_phys, dw = self._conv_bwd_tiled(i, dz.permute(0, 2, 3, 1), conv_in,
                                                        acts['pads'][i], need_dx)

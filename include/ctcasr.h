@@ -180,18 +180,21 @@ int ctcasr_dropout(const float *in, float *out, int64_t n, float dropout_rate, u
 int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t rows, int cols,
                              ctcasr_stream_t stream);
 
-/* ---- the second DS2 convolution (11 x 21 taps, stride (1, 2), 32 -> 32 channels, TensorFlow
- * SAME padding; asr/util/tf_contrib.py:64-146): forward and data gradient ------------------------
- * Implicit GEMM on the fp32 MFMA units, NHWC, any number of frames, no padded intermediates:
- *   fwd:       x  [B, T, 40, 32] -> y  [B, T, 20, 32] = conv(x) + bias  (bias may be NULL)
- *   bwd_data:  dz [B, T, 20, 32] -> dx [B, T, 40, 32]
- * `packed` holds fragment-ordered copies of the kernel w [Cout=32, Cin=32, 11, 21] made by
- * ctcasr_conv_s12_pack_weights: 2 * 11*21*32*32 floats (backward order, then forward order). */
-int ctcasr_conv_s12_pack_weights(const float *w, float *packed, ctcasr_stream_t stream);
+/* ---- the 11 x 21, stride (1, 2) convolutions over 32 input channels of the DS2 stack (layers 2
+ * and 3 of conv_layers, asr/util/tf_contrib.py:64-146; TensorFlow SAME padding): forward pass and
+ * data gradient as implicit GEMMs on the fp32 MFMA units, NHWC, any number of frames, no padded
+ * intermediates.  Covered (ctcasr_conv_s12_supported): freq_in = 40, cout = 32 and freq_in = 20,
+ * cout = 96.
+ *   fwd:       x  [B, T, freq_in, 32]       -> y  [B, T, freq_in/2, cout] = conv(x) + bias|NULL
+ *   bwd_data:  dz [B, T, freq_in/2, cout]   -> dx [B, T, freq_in, 32]
+ * `packed`: fragment-ordered copies of the kernel w [cout, 32, 11, 21] made by
+ * ctcasr_conv_s12_pack_weights, 2 * 11*21*32*cout floats (backward order, then forward order). */
+int ctcasr_conv_s12_supported(int freq_in, int cout);
+int ctcasr_conv_s12_pack_weights(const float *w, float *packed, int cout, ctcasr_stream_t stream);
 int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
-                        int T, ctcasr_stream_t stream);
+                        int T, int freq_in, int cout, ctcasr_stream_t stream);
 int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B, int T,
-                             ctcasr_stream_t stream);
+                             int freq_in, int cout, ctcasr_stream_t stream);
 
 /* Enqueues a one-lane kernel that idles for `microseconds` (<= 100 ms): used to let the persistent
  * recurrence of the main stream claim its half of the chip before side-stream GEMMs start. */

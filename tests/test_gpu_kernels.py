@@ -327,31 +327,34 @@ def test_dropout_kernel(hip):
     assert not torch.equal(hip.dropout(x, 0.25, seed=78) != 0, kept)
 
 
-@pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (1, 500)])
-def test_conv_s12_kernels_match_the_library_convolution(hip, shape):
-    """Implicit-GEMM forward and data gradient of the 11x21 / stride (1,2) / 32->32 layer against
-    torch's convolution on the explicitly SAME-padded input (pad 5/5 in time, 9/10 in
-    frequency), fp64 on the CPU."""
+@pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
+@pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (3, 65), (1, 500)])
+def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
+    """Implicit-GEMM forward and data gradient of the 11x21 / stride (1,2) layers (32 -> 32 channels
+    on 40 frequencies, 32 -> 96 on 20) against torch's convolution on the explicitly SAME-padded
+    input (pad 5/5 in time, 9/10 in frequency), fp64 on the CPU."""
     batch, frames = shape
-    rng = np.random.default_rng(frames)
-    x_np = rng.normal(size=(batch, frames, 40, 32)).astype(np.float32)
-    dz = rng.normal(size=(batch, frames, 20, 32)).astype(np.float32)
-    weight = (rng.normal(size=(32, 32, 11, 21)) * 0.05).astype(np.float32)
-    bias = rng.normal(size=32).astype(np.float32)
+    freq, cout = layer
+    assert hip.conv_s12_supported(freq, cout) and not hip.conv_s12_supported(freq, 48)
+    rng = np.random.default_rng(frames + cout)
+    x_np = rng.normal(size=(batch, frames, freq, 32)).astype(np.float32)
+    dz = rng.normal(size=(batch, frames, freq // 2, cout)).astype(np.float32)
+    weight = (rng.normal(size=(cout, 32, 11, 21)) * 0.05).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
     packed = hip.conv_s12_pack_weights(_t(weight))
-    y_gpu = hip.conv_s12_fwd(_t(x_np), packed, _t(bias)).cpu().numpy()
-    y_nobias = hip.conv_s12_fwd(_t(x_np), packed).cpu().numpy()
+    y_gpu = hip.conv_s12_fwd(_t(x_np), packed, cout, _t(bias)).cpu().numpy()
+    y_nobias = hip.conv_s12_fwd(_t(x_np), packed, cout).cpu().numpy()
     dx = hip.conv_s12_bwd_data(_t(dz), packed).cpu().numpy()
-    x = torch.zeros(batch, 32, frames + 10, 40 + 19, dtype=torch.float64)
-    x[:, :, 5:5 + frames, 9:9 + 40] = torch.tensor(x_np, dtype=torch.float64).permute(0, 3, 1, 2)
+    x = torch.zeros(batch, 32, frames + 10, freq + 19, dtype=torch.float64)
+    x[:, :, 5:5 + frames, 9:9 + freq] = torch.tensor(x_np, dtype=torch.float64).permute(0, 3, 1, 2)
     x.requires_grad_(True)
     y = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64),
                                    torch.tensor(bias, dtype=torch.float64), stride=(1, 2))
-    assert tuple(y.shape) == (batch, 32, frames, 20)
+    assert tuple(y.shape) == (batch, cout, frames, freq // 2)
     ref_y = y.detach().permute(0, 2, 3, 1).numpy()
     assert np.abs(y_gpu - ref_y).max() < 2e-4 * max(1.0, np.abs(ref_y).max())
     assert np.abs(y_nobias + bias - ref_y).max() < 2e-4 * max(1.0, np.abs(ref_y).max())
     y.backward(torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
-    ref = x.grad[:, :, 5:5 + frames, 9:9 + 40].permute(0, 2, 3, 1).numpy()
+    ref = x.grad[:, :, 5:5 + frames, 9:9 + freq].permute(0, 2, 3, 1).numpy()
     assert dx.shape == ref.shape
     assert np.abs(dx - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())

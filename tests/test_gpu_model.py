@@ -19,6 +19,9 @@ CASES = {
     'ds2_lstm_32ch': dict(used_model='ds2', conv_filters=(32, 32), rnn_cell='lstm', cudnn=True),
     'ds2_lstm_32ch_3conv': dict(used_model='ds2', conv_filters=(32, 32, 8), rnn_cell='lstm',
                                 cudnn=True),
+    # the reference's own filter counts: layers 2 and 3 both on the own kernels
+    'ds2_lstm_ref_convs': dict(used_model='ds2', conv_filters=(32, 32, 96), rnn_cell='lstm',
+                               cudnn=True),
     'ds2_gru': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='gru', cudnn=True),
     'ds2_relu': dict(used_model='ds2', conv_filters=(4, 4, 6), rnn_cell='rnn_relu', cudnn=True),
     'ds1_tanh_cudnn': dict(used_model='ds1', rnn_cell='rnn_tanh', cudnn=True),

@@ -38,7 +38,7 @@ def main():
     flops = 2.0 * batch * frames * 20 * 32 * 32 * 11 * 21
     ms = timed(lambda: hip.conv_s12_pack_weights(weight, packed))
     print('pack weights: {:.3f} ms'.format(ms))
-    ms = timed(lambda: hip.conv_s12_fwd(x, packed, bias, y))
+    ms = timed(lambda: hip.conv_s12_fwd(x, packed, 32, bias, y))
     print('conv_s12_fwd: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     ms = timed(lambda: hip.conv_s12_bwd_data(dz, packed, out))
     print('conv_s12_bwd_data: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
@@ -68,6 +68,16 @@ def main():
     print('MIOpen fwd incl. padding copy: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     print('fwd max |diff| {:.2e}'.format(
         float((library_fwd().permute(0, 2, 3, 1) - y).abs().max())))
+    # the reference stack's third layer: 32 -> 96 channels on 20 frequencies
+    w3 = torch.randn(96, 32, 11, 21, device='cuda', generator=gen) * 0.05
+    packed3 = hip.conv_s12_pack_weights(w3)
+    x3 = torch.randn(batch, frames, 20, 32, device='cuda', generator=gen)
+    dz3 = torch.randn(batch, frames, 10, 96, device='cuda', generator=gen)
+    flops3 = 2.0 * batch * frames * 10 * 96 * 32 * 11 * 21
+    ms = timed(lambda: hip.conv_s12_fwd(x3, packed3, 96))
+    print('layer 3 fwd: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops3 / ms / 1e9))
+    ms = timed(lambda: hip.conv_s12_bwd_data(dz3, packed3))
+    print('layer 3 bwd-data: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops3 / ms / 1e9))
 
 
 if __name__ == '__main__':

@@ -331,3 +331,104 @@ extern "C" int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, fl
     if (cout == 32) return launch_bwd<32, 40>(dz, packed, dx, B, T, s);
     return launch_bwd<96, 20>(dz, packed, dx, B, T, s);
 }
+
+// =============================================================================================
+// First convolution of the stack: 1 -> 32 channels, 11 x 41 taps, stride (2, 2), SAME padding
+// (asr/util/tf_contrib.py:64-146, layer 1).  K = 451 taps only, so the operands are fed with
+// scalar LDS reads (one float per lane and MFMA) instead of 16-byte fragments: per (kt, group of
+// four kf) a wave reads its B values (weights) once and one A value per M tile.
+//   y[b, t, fo, co] = bias[co] + sum_{kt,kf} x[b, 2t + kt - pt0, 2fo + kf - 19] w[co, 0, kt, kf]
+// pt0 = 5 for an odd number of input frames, 4 for an even one (TensorFlow puts the odd padding
+// element at the end).  One workgroup = one utterance x 16 output frames x 40 frequencies.
+// =============================================================================================
+namespace {
+
+constexpr int C0_CO = 32, C0_KT = 11, C0_KF = 41, C0_KFP = 44;   // kf padded to a multiple of 4
+constexpr int C0_FI = 80, C0_FO = 40, C0_TT = 16;
+constexpr int C0_PW = 124;                       // patch width: 19 + 80 + 20 (+ reach of the kf pad)
+constexpr int C0_PT = 2 * C0_TT + C0_KT - 2;     // patch frames: 2 (TT - 1) + 11
+constexpr size_t C0_LDS = ((size_t)C0_PT * C0_PW + (size_t)C0_KT * C0_KFP * C0_CO) * sizeof(float);
+
+__global__ void __launch_bounds__(256)
+conv0_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                 const float *__restrict__ bias, float *__restrict__ y, int T, int t_out, int pt0) {
+    extern __shared__ __attribute__((aligned(16))) float smem0[];
+    float *patch = smem0;                               // [C0_PT][C0_PW]
+    float *wl = smem0 + C0_PT * C0_PW;                  // [kt][kf padded][co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * C0_TT, b = blockIdx.y;
+    const int kg = lane >> 4, n = lane & 15;
+
+    for (int i = tid; i < C0_PT * C0_PW; i += 256) {
+        const int col = i % C0_PW, pr = i / C0_PW;
+        const int ts = 2 * t0 - pt0 + pr, fi = col - 19;
+        patch[i] = (ts >= 0 && ts < T && fi >= 0 && fi < C0_FI)
+                       ? x[((size_t)b * T + ts) * C0_FI + fi] : 0.f;
+    }
+    for (int i = tid; i < C0_KT * C0_KFP * C0_CO; i += 256) {
+        const int co = i & 31, kf = (i >> 5) % C0_KFP, kt = i / (32 * C0_KFP);
+        wl[i] = kf < C0_KF ? w[(co * C0_KT + kt) * C0_KF + kf] : 0.f;
+    }
+    __syncthreads();
+
+    // a wave owns 4 output frames x 40 frequencies = 160 rows = 10 M tiles
+    int base_a[10];
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti) {
+        const int row = ti * 16 + n, tt = row / C0_FO, fo = row % C0_FO;
+        base_a[ti] = 2 * (4 * wave + tt) * C0_PW + 2 * fo + kg;
+    }
+    f32x4 acc[10][2];
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < C0_KT; ++kt) {
+#pragma unroll
+        for (int j = 0; j < C0_KFP / 4; ++j) {
+            const float *wrow = wl + ((kt * C0_KFP + 4 * j + kg) * C0_CO) + n;
+            const float b0 = wrow[0], b1 = wrow[16];
+            const int off = kt * C0_PW + 4 * j;
+#pragma unroll
+            for (int ti = 0; ti < 10; ++ti) {
+                const float a = patch[base_a[ti] + off];
+                acc[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[ti][0], 0, 0, 0);
+                acc[ti][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[ti][1], 0, 0, 0);
+            }
+        }
+    }
+
+    const float bias0 = bias ? bias[n] : 0.f, bias1 = bias ? bias[16 + n] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + 4 * kg + r, tt = row / C0_FO, fo = row % C0_FO;
+            const int t = t0 + 4 * wave + tt;
+            if (t < t_out) {
+                float *out = y + ((size_t)(b * t_out + t) * C0_FO + fo) * C0_CO + n;
+                out[0] = acc[ti][0][r] + bias0;
+                out[16] = acc[ti][1][r] + bias1;
+            }
+        }
+}
+
+}  // namespace
+
+// x [B, T, 80] (one channel) -> y [B, ceil(T / 2), 40, 32] (NHWC) = conv(x) + bias (bias may be
+// NULL); w [32, 1, 11, 41].
+extern "C" int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y, int B,
+                                int T, ctcasr_stream_t stream) {
+    if (!x || !w || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    const int t_out = (T + 1) / 2;
+    const int total = (t_out - 1) * 2 + C0_KT - T;          // TensorFlow SAME padding
+    const int pt0 = total > 0 ? total / 2 : 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_fwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0_LDS) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    dim3 grid((t_out + C0_TT - 1) / C0_TT, B);
+    conv0_fwd_kernel<<<grid, 256, C0_LDS, (hipStream_t)stream>>>(x, w, bias, y, T, t_out, pt0);
+    return ctcasr_launch_status();
+}

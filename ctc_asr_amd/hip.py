@@ -51,6 +51,7 @@ SIGNATURES = {
     'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
     'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
     'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
+    'ctcasr_conv0_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
@@ -412,6 +413,21 @@ def conv_s12_bwd_data(dz, packed, out=None):
         _check(load().ctcasr_conv_s12_bwd_data(_dev(dz, name='dz'), _dev(packed, name='packed'),
                                                _dev(out, name='dx'), batch, frames,
                                                2 * freq_out, cout, _stream()), 'conv_s12_bwd_data')
+    return out
+
+
+def conv0_fwd(x, weight, bias=None, out=None):
+    """First DS2 convolution: x f32[B,T,80] -> f32[B,ceil(T/2),40,32] (NHWC); weight
+    f32[32,1,11,41], stride (2,2), TensorFlow SAME padding."""
+    batch, frames = x.shape[0], x.shape[1]
+    if x.shape[2] != 80 or tuple(weight.shape) != (32, 1, 11, 41):
+        raise CtcAsrError('conv0_fwd covers x [B,T,80] and w [32,1,11,41] only.')
+    out = torch.empty((batch, (frames + 1) // 2, 40, 32), dtype=torch.float32,
+                      device=x.device) if out is None else out
+    with _Timed('conv0_fwd'):
+        _check(load().ctcasr_conv0_fwd(_dev(x, name='x'), _dev(weight, name='weight'),
+                                       _dev(bias, name='bias'), _dev(out, name='y'), batch,
+                                       frames, _stream()), 'conv0_fwd')
     return out
 
 

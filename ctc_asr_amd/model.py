@@ -348,7 +348,12 @@ class CTCModel:
                 s_t, s_f = CONV_STRIDES[i]
                 _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
-                if self._own_conv_layer(i, x.shape[3]):
+                if self._own_conv0_layer(i, x.shape[3]):
+                    # first layer: straight from the [B, T, 80] features, no padded copy
+                    y = hip.conv0_fwd(sequences, p['conv0/kernel'],
+                                      p['conv0/bias']).permute(0, 3, 1, 2)
+                    conv_in.append(x)
+                elif self._own_conv_layer(i, x.shape[3]):
                     # weights change every step: re-pack (2 x 946 KB), then one launch
                     kernel = p['conv{}/kernel'.format(i)]
                     self._conv_packed[i] = hip.conv_s12_pack_weights(kernel,
@@ -436,6 +441,10 @@ class CTCModel:
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
         self._acts = acts
         return logits.view(t_out, batch, cfg.num_classes), seq_length
+
+    def _own_conv0_layer(self, layer, freq_in):
+        return (self.own_conv and layer == 0 and freq_in == 80 and
+                tuple(self.arena.p['conv0/kernel'].shape) == (32, 1, 11, 41))
 
     def _own_conv_layer(self, layer, freq_in):
         kernel = self.arena.p['conv{}/kernel'.format(layer)]
@@ -800,7 +809,8 @@ class CTCModel:
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 # the 11x21 / stride (1,2) / 32->32 layer has its own data-gradient kernel
                 # (implicit GEMM, any T, no padded intermediates: 0.62 ms vs 1.6 ms at C2)
-                own = self._own_conv_layer(i, 2 * dz.shape[3])
+                own = self._own_conv_layer(i, 2 * dz.shape[3]) or \
+                    self._own_conv0_layer(i, 2 * dz.shape[3])
                 own_dx = i > 0 and own
                 need_dx = i > 0 and not own_dx
                 conv_in = acts['conv_in'][i]

@@ -196,6 +196,11 @@ int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, 
 int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B, int T,
                              int freq_in, int cout, ctcasr_stream_t stream);
 
+/* ---- the first DS2 convolution: 1 -> 32 channels, 11 x 41 taps, stride (2, 2), SAME padding ----
+ *   fwd: x [B, T, 80] -> y [B, ceil(T/2), 40, 32] (NHWC) = conv(x) + bias|NULL; w [32, 1, 11, 41] */
+int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y, int B, int T,
+                     ctcasr_stream_t stream);
+
 /* Enqueues a one-lane kernel that idles for `microseconds` (<= 100 ms): used to let the persistent
  * recurrence of the main stream claim its half of the chip before side-stream GEMMs start. */
 int ctcasr_stream_delay(int microseconds, ctcasr_stream_t stream);

@@ -358,3 +358,26 @@ def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
     ref = x.grad[:, :, 5:5 + frames, 9:9 + freq].permute(0, 2, 3, 1).numpy()
     assert dx.shape == ref.shape
     assert np.abs(dx - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (2, 9), (2, 10), (3, 64), (2, 131), (1, 999), (1, 1000)])
+def test_conv0_fwd_matches_the_library_convolution(hip, shape):
+    """First DS2 convolution (1 -> 32 channels, 11x41, stride (2,2), TensorFlow SAME padding: 5/5
+    or 4/5 frames depending on the parity of T, 19/20 frequencies) against torch's conv2d, fp64."""
+    from ctc_asr_amd.model import same_padding
+    batch, frames = shape
+    rng = np.random.default_rng(frames)
+    x_np = rng.normal(size=(batch, frames, 80)).astype(np.float32)
+    weight = (rng.normal(size=(32, 1, 11, 41)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=32).astype(np.float32)
+    y_gpu = hip.conv0_fwd(_t(x_np), _t(weight), _t(bias)).cpu().numpy()
+    t_out, pt0, pt1 = same_padding(frames, 11, 2)
+    f_out, pf0, pf1 = same_padding(80, 41, 2)
+    assert (f_out, pf0, pf1) == (40, 19, 20)
+    x = torch.nn.functional.pad(torch.tensor(x_np, dtype=torch.float64).unsqueeze(1),
+                                (pf0, pf1, pt0, pt1))
+    y = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64),
+                                   torch.tensor(bias, dtype=torch.float64), stride=(2, 2))
+    ref = y.permute(0, 2, 3, 1).numpy()
+    assert y_gpu.shape == ref.shape == (batch, t_out, 40, 32)
+    assert np.abs(y_gpu - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())

@@ -68,6 +68,23 @@ def main():
     print('MIOpen fwd incl. padding copy: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     print('fwd max |diff| {:.2e}'.format(
         float((library_fwd().permute(0, 2, 3, 1) - y).abs().max())))
+    # first layer: 1 -> 32 channels, 11x41, stride (2, 2)
+    feats = torch.randn(batch, 2 * frames - 1, 80, device='cuda', generator=gen)
+    w0 = torch.randn(32, 1, 11, 41, device='cuda', generator=gen) * 0.1
+    flops0 = 2.0 * batch * frames * 40 * 32 * 11 * 41
+    ms = timed(lambda: hip.conv0_fwd(feats, w0, bias))
+    print('conv0_fwd: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops0 / ms / 1e9))
+    w0_cl = w0.contiguous(memory_format=torch.channels_last)
+
+    def library_conv0():
+        padded = torch.nn.functional.pad(feats.unsqueeze(1), (19, 20, 5, 5)) \
+            .contiguous(memory_format=torch.channels_last)
+        return torch.ops.aten.convolution(padded, w0_cl, bias, [2, 2], [0, 0], [1, 1], False,
+                                          [0, 0], 1).contiguous(memory_format=torch.channels_last)
+    ms = timed(library_conv0)
+    print('MIOpen conv0 fwd incl. padding copy: {:.3f} ms'.format(ms))
+    print('conv0 max |diff| {:.2e}'.format(float(
+        (library_conv0().permute(0, 2, 3, 1) - hip.conv0_fwd(feats, w0, bias)).abs().max())))
     # the reference stack's third layer: 32 -> 96 channels on 20 frequencies
     w3 = torch.randn(96, 32, 11, 21, device='cuda', generator=gen) * 0.05
     packed3 = hip.conv_s12_pack_weights(w3)

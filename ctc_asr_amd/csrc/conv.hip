@@ -432,3 +432,142 @@ extern "C" int ctcasr_conv0_fwd(const float *x, const float *w, const float *bia
     conv0_fwd_kernel<<<grid, 256, C0_LDS, (hipStream_t)stream>>>(x, w, bias, y, T, t_out, pt0);
     return ctcasr_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Kernel gradient of the first convolution:
+//   dw[co, 0, kt, kf] = sum_{b,t,fo} dz[b, t, fo, co] * x[b, 2t + kt - pt0, 2fo + kf - 19]
+// GEMM per kt: M = co (2 tiles), N = kf (41 -> 3 tiles), K = output positions (t, fo).  One
+// workgroup = one utterance x 16 output frames = 640 positions; its dz slice (pitch 48 floats:
+// conflict-free scalar reads of 4 consecutive positions x 16 channels) and x patch sit in LDS; a
+// wave owns the taps kt = wave, wave + 4, wave + 8 and walks all 160 groups of 4 positions.
+// Partial results go to a workspace [workgroups][32 * 11 * 41]; conv0_wrw_reduce_kernel sums them.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int C0_DZP = 48;                       // dz pitch in LDS
+constexpr int C0_PW2 = 128;                      // x patch width for kf up to 47
+constexpr size_t C0_WRW_LDS =
+    ((size_t)C0_PT * C0_PW2 + (size_t)C0_TT * C0_FO * C0_DZP) * sizeof(float);
+constexpr int C0_DW = C0_CO * C0_KT * C0_KF;     // 14432 floats
+
+__global__ void __launch_bounds__(256)
+conv0_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
+                 float *__restrict__ partial, int T, int t_out, int pt0) {
+    extern __shared__ __attribute__((aligned(16))) float smem0[];
+    float *patch = smem0;                               // [C0_PT][C0_PW2]
+    float *dzl = smem0 + C0_PT * C0_PW2;                // [640 positions][C0_DZP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * C0_TT, b = blockIdx.y;
+    const int kg = lane >> 4, n = lane & 15;
+
+    for (int i = tid; i < C0_PT * C0_PW2; i += 256) {
+        const int col = i % C0_PW2, pr = i / C0_PW2;
+        const int ts = 2 * t0 - pt0 + pr, fi = col - 19;
+        patch[i] = (ts >= 0 && ts < T && fi >= 0 && fi < C0_FI)
+                       ? x[((size_t)b * T + ts) * C0_FI + fi] : 0.f;
+    }
+    for (int i = tid; i < C0_TT * C0_FO * 8; i += 256) {
+        const int c4 = i & 7, pos = i >> 3, t = t0 + pos / C0_FO;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < t_out)
+            v = reinterpret_cast<const float4 *>(dz)[((size_t)(b * t_out + t) * C0_FO +
+                                                      pos % C0_FO) * 8 + c4];
+        *reinterpret_cast<float4 *>(dzl + pos * C0_DZP + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[3][3][2];     // [kt of this wave][kf tile][co tile]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[k][nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 4
+    for (int s = 0; s < C0_TT * C0_FO / 4; ++s) {
+        const int pos0 = 4 * s, tl = pos0 / C0_FO, fo0 = pos0 % C0_FO;
+        const float a0 = dzl[(pos0 + kg) * C0_DZP + n], a1 = dzl[(pos0 + kg) * C0_DZP + 16 + n];
+        const float *xrow = patch + 2 * tl * C0_PW2 + 2 * (fo0 + kg) + n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kt = wave + 4 * k;
+            if (kt < C0_KT) {
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    const float bv = xrow[kt * C0_PW2 + 16 * nt];
+                    acc[k][nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[k][nt][0], 0, 0, 0);
+                    acc[k][nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[k][nt][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float *out = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * C0_DW;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int kt = wave + 4 * k;
+        if (kt >= C0_KT) continue;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int kf = 16 * nt + n;
+            if (kf >= C0_KF) continue;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * mt + 4 * kg + r;
+                    out[(co * C0_KT + kt) * C0_KF + kf] = acc[k][nt][mt][r];
+                }
+        }
+    }
+}
+
+// Two deterministic stages (no atomics): grid (ceil(C0_DW / 256), C0_BANDS) sums a band of the
+// partials per workgroup row into bands[band][i]; a second launch sums the bands.  One thread per
+// element alone would walk all parts serially.
+constexpr int C0_BANDS = 16;
+__global__ void conv0_wrw_reduce_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                        int parts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C0_DW) return;
+    const int band = (parts + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * band, hi = min(parts, lo + band);
+    float sum = 0.f;
+#pragma unroll 8
+    for (int part = lo; part < hi; ++part) sum += src[(size_t)part * C0_DW + i];
+    dst[(size_t)blockIdx.y * C0_DW + i] = sum;
+}
+
+}  // namespace
+
+extern "C" size_t ctcasr_conv0_wrw_workspace_bytes(int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    const int t_out = (T + 1) / 2;
+    return ((size_t)B * ((t_out + C0_TT - 1) / C0_TT) + C0_BANDS) * C0_DW * sizeof(float);
+}
+
+// dz [B, ceil(T/2), 40, 32] (NHWC), x [B, T, 80] -> dw [32, 1, 11, 41] (overwritten).
+extern "C" int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T,
+                                void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
+    if (!dz || !x || !dw || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ctcasr_conv0_wrw_workspace_bytes(B, T))
+        return CTCASR_ERR_WORKSPACE;
+    const int t_out = (T + 1) / 2;
+    const int total = (t_out - 1) * 2 + C0_KT - T;
+    const int pt0 = total > 0 ? total / 2 : 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_wrw_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C0_WRW_LDS) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((t_out + C0_TT - 1) / C0_TT, B);
+    float *partial = reinterpret_cast<float *>(workspace);
+    conv0_wrw_kernel<<<grid, 256, C0_WRW_LDS, s>>>(dz, x, partial, T, t_out, pt0);
+    const int parts = (int)(grid.x * grid.y);
+    float *bands = partial + (size_t)parts * C0_DW;
+    conv0_wrw_reduce_kernel<<<dim3((C0_DW + 255) / 256, C0_BANDS), 256, 0, s>>>(partial, bands, parts);
+    conv0_wrw_reduce_kernel<<<dim3((C0_DW + 255) / 256, 1), 256, 0, s>>>(bands, dw, C0_BANDS);
+    return ctcasr_launch_status();
+}

@@ -52,6 +52,8 @@ SIGNATURES = {
     'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
     'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
     'ctcasr_conv0_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    'ctcasr_conv0_wrw_workspace_bytes': (_c_sz, [_c_int, _c_int]),
+    'ctcasr_conv0_wrw': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
@@ -428,6 +430,23 @@ def conv0_fwd(x, weight, bias=None, out=None):
         _check(load().ctcasr_conv0_fwd(_dev(x, name='x'), _dev(weight, name='weight'),
                                        _dev(bias, name='bias'), _dev(out, name='y'), batch,
                                        frames, _stream()), 'conv0_fwd')
+    return out
+
+
+def conv0_wrw(dz, x, out=None):
+    """Kernel gradient of the first DS2 convolution: dz f32[B,ceil(T/2),40,32] (NHWC),
+    x f32[B,T,80] -> dw f32[32,1,11,41]."""
+    batch, frames = x.shape[0], x.shape[1]
+    if x.shape[2] != 80 or tuple(dz.shape) != (batch, (frames + 1) // 2, 40, 32):
+        raise CtcAsrError('conv0_wrw covers x [B,T,80], dz [B,ceil(T/2),40,32] only.')
+    out = torch.empty((32, 1, 11, 41), dtype=torch.float32, device=x.device) if out is None \
+        else out
+    workspace = _workspace(load().ctcasr_conv0_wrw_workspace_bytes(batch, frames), x.device)
+    with _Timed('conv0_wrw'):
+        _check(load().ctcasr_conv0_wrw(_dev(dz, name='dz'), _dev(x, name='x'),
+                                       _dev(out, name='dw'), batch, frames,
+                                       _dev(workspace, torch.uint8, 'workspace'),
+                                       workspace.numel(), _stream()), 'conv0_wrw')
     return out
 
 

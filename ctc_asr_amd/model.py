@@ -352,7 +352,8 @@ class CTCModel:
                     # first layer: straight from the [B, T, 80] features, no padded copy
                     y = hip.conv0_fwd(sequences, p['conv0/kernel'],
                                       p['conv0/bias']).permute(0, 3, 1, 2)
-                    conv_in.append(x)
+                    conv_in.append(None)
+                    acts['features'] = sequences
                 elif self._own_conv_layer(i, x.shape[3]):
                     # weights change every step: re-pack (2 x 946 KB), then one launch
                     kernel = p['conv{}/kernel'.format(i)]
@@ -809,8 +810,13 @@ class CTCModel:
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 # the 11x21 / stride (1,2) / 32->32 layer has its own data-gradient kernel
                 # (implicit GEMM, any T, no padded intermediates: 0.62 ms vs 1.6 ms at C2)
-                own = self._own_conv_layer(i, 2 * dz.shape[3]) or \
-                    self._own_conv0_layer(i, 2 * dz.shape[3])
+                if self._own_conv0_layer(i, 2 * dz.shape[3]):
+                    # first layer: kernel gradient straight from the features, no padded copy
+                    hip.conv0_wrw(dz.permute(0, 2, 3, 1), acts['features'],
+                                  out=g[name + '/kernel'])
+                    done(name)
+                    continue
+                own = self._own_conv_layer(i, 2 * dz.shape[3])
                 own_dx = i > 0 and own
                 need_dx = i > 0 and not own_dx
                 conv_in = acts['conv_in'][i]

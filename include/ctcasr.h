@@ -200,6 +200,11 @@ int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, in
  *   fwd: x [B, T, 80] -> y [B, ceil(T/2), 40, 32] (NHWC) = conv(x) + bias|NULL; w [32, 1, 11, 41] */
 int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y, int B, int T,
                      ctcasr_stream_t stream);
+/*   wrw: dz [B, ceil(T/2), 40, 32] (NHWC), x [B, T, 80] -> dw [32, 1, 11, 41] (overwritten);
+ *        workspace: per-workgroup partial sums, ctcasr_conv0_wrw_workspace_bytes(B, T) */
+size_t ctcasr_conv0_wrw_workspace_bytes(int B, int T);
+int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T, void *workspace,
+                     size_t workspace_bytes, ctcasr_stream_t stream);
 
 /* Enqueues a one-lane kernel that idles for `microseconds` (<= 100 ms): used to let the persistent
  * recurrence of the main stream claim its half of the chip before side-stream GEMMs start. */

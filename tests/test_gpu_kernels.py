@@ -381,3 +381,12 @@ def test_conv0_fwd_matches_the_library_convolution(hip, shape):
     ref = y.permute(0, 2, 3, 1).numpy()
     assert y_gpu.shape == ref.shape == (batch, t_out, 40, 32)
     assert np.abs(y_gpu - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    # kernel gradient of the same layer
+    dz = rng.normal(size=(batch, t_out, 40, 32)).astype(np.float32)
+    dw = hip.conv0_wrw(_t(dz), _t(x_np)).cpu().numpy()
+    w64 = torch.tensor(weight, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x, w64, stride=(2, 2)).backward(
+        torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
+    ref_dw = w64.grad.numpy()
+    assert dw.shape == ref_dw.shape
+    assert np.abs(dw - ref_dw).max() < 2e-4 * max(1.0, np.abs(ref_dw).max())

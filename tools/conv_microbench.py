@@ -85,6 +85,22 @@ def main():
     print('MIOpen conv0 fwd incl. padding copy: {:.3f} ms'.format(ms))
     print('conv0 max |diff| {:.2e}'.format(float(
         (library_conv0().permute(0, 2, 3, 1) - hip.conv0_fwd(feats, w0, bias)).abs().max())))
+    dz0 = torch.randn(batch, frames, 40, 32, device='cuda', generator=gen)
+    dw0 = torch.empty(32, 1, 11, 41, device='cuda')
+    ms = timed(lambda: hip.conv0_wrw(dz0, feats, dw0))
+    print('conv0_wrw: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops0 / ms / 1e9))
+    padded0 = torch.nn.functional.pad(feats.unsqueeze(1), (19, 20, 5, 5)) \
+        .contiguous(memory_format=torch.channels_last)
+    dz0_nchw = dz0.permute(0, 3, 1, 2)
+
+    def library_wrw0():
+        return torch.ops.aten.convolution_backward(dz0_nchw, padded0, w0_cl, [32], [2, 2], [0, 0],
+                                                   [1, 1], False, [0, 0], 1,
+                                                   [False, True, False])[1]
+    ms = timed(library_wrw0)
+    print('MIOpen conv0 wrw: {:.3f} ms'.format(ms))
+    print('conv0 wrw max |diff| {:.2e} of {:.2e}'.format(
+        float((library_wrw0() - dw0).abs().max()), float(dw0.abs().max())))
     # the reference stack's third layer: 32 -> 96 channels on 20 frequencies
     w3 = torch.randn(96, 32, 11, 21, device='cuda', generator=gen) * 0.05
     packed3 = hip.conv_s12_pack_weights(w3)

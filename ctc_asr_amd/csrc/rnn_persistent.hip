@@ -167,16 +167,20 @@ __device__ __forceinline__ void dir_wait(SyncWords *sy, int dir, int group_size,
 // K chunks per wave (H = 64 * QW), MT = batch tiles of 16 rows.
 // LDS: fragments [NT][4*QW][64] float4, then reduction scratch [4][NT][MT*16][17], then a flag.
 // ---------------------------------------------------------------------------------------------
-template <int CELL, int NT, int QW, int MT>
+// REGW > 0: the last REGW of a wave's QW * NT B-fragment slots (slot = chunk * NT + tile) live in
+// registers instead of LDS - the variant for 64 workgroups per direction (half of the chip), whose
+// 256 KB weight slice does not fit LDS alone.
+template <int CELL, int NT, int QW, int MT, int REGW = 0>
 __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
     constexpr int COLS = 16 * NT;
     constexpr int UPB = COLS / G;
-    constexpr int Q = 4 * QW;
+    constexpr int QS = QW * NT;          // B-fragment slots per wave
+    constexpr int QL = QS - REGW;        // ... of which in LDS
     constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *frag = reinterpret_cast<float4 *>(smem);
-    float *red = reinterpret_cast<float *>(smem + (size_t)NT * Q * 64 * sizeof(float4));
+    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(float4));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = blockIdx.x / p.nwg, slice = blockIdx.x % p.nwg;
@@ -185,14 +189,18 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     const int u0 = slice * UPB;
     const int kq = 4 * (lane >> 4);
 
-    // ---- stage this workgroup's slice of R into LDS in fragment order (once) ----------------
-    for (int nt = 0; nt < NT; ++nt) {
-        const int c = nt * 16 + (lane & 15);
-        const float *wrow = p.w + ((size_t)dir * G * H + (c / UPB) * H + u0 + (c % UPB)) * H + kq;
-        for (int i = 0; i < QW; ++i) {
-            const int q = wave * QW + i;
-            frag[(nt * Q + q) * 64 + lane] = ldg4(wrow + 16 * q);
-        }
+    // ---- stage this workgroup's slice of R in fragment order (once): LDS, then registers -------
+    float4 wreg[REGW > 0 ? REGW : 1];
+    {
+        auto slot = [&](int sl) -> float4 {
+            const int i = sl / NT, c = (sl % NT) * 16 + (lane & 15);
+            const float *wrow =
+                p.w + ((size_t)dir * G * H + (c / UPB) * H + u0 + (c % UPB)) * H + kq;
+            return ldg4(wrow + 16 * (wave * QW + i));
+        };
+        for (int sl = 0; sl < QL; ++sl) frag[(wave * QL + sl) * 64 + lane] = slot(sl);
+#pragma unroll
+        for (int sl = 0; sl < REGW; ++sl) wreg[sl] = slot(QL + sl);
     }
     __syncthreads();
 
@@ -207,12 +215,21 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     const size_t x_step = (size_t)2 * B * H;          // floats per step
     // every workgroup of a direction reads the same rows: start each one at a different chunk so
     // that the 16 workgroups sharing an XCD's L2 do not all hit the same channel at once
-    const int rot = slice & (QW - 1);
+    // (register-resident fragments need a static chunk -> register map: no rotation then)
+    const int rot = REGW == 0 ? (slice & (QW - 1)) : 0;
 
     // ---- per-item state ----------------------------------------------------------------------
     float c_state[ITEMS];
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) c_state[it] = 0.f;
+    for (int it = 0; it < ITEMS; ++it) {
+        c_state[it] = 0.f;
+        if constexpr (CELL == CTCASR_CELL_LSTM) {
+            // continuing a pass that an earlier launch started: pick up its cell state
+            const int item = tid + it * PRNN_THREADS;
+            if (p.s_lo > 0 && item < 16 * MT * UPB && item / UPB < B)
+                c_state[it] = p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB];
+        }
+    }
 
     int a_steps[MT];
 #pragma unroll
@@ -223,7 +240,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
     const bool prof = p.prof && tid == 0;
-    for (int s = 0; s < T; ++s) {
+    for (int s = p.s_lo; s < p.s_hi; ++s) {
         unsigned long long c0 = prof ? wall_clock64() : 0;
         // gate pre-activations from the input projection: independent of the recurrence, so
         // they are requested before waiting for the other workgroups
@@ -255,7 +272,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         if (s > 0) {
-            dir_wait(p.sync, dir, group_size, (unsigned)(s - 1), tid);
+            // (the first step of a continued pass reads what the previous launch published)
+            if (s > p.s_lo) dir_wait(p.sync, dir, group_size, (unsigned)(s - 1 - p.s_lo), tid);
             if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
             // A fragments: h_{s-1} rows straight from y, every load issued before the first MFMA
             float4 a[MT][QW];
@@ -281,16 +299,23 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             // its first use and the step degenerates to load -> wait -> 8 MFMAs -> load ...
             __builtin_amdgcn_sched_barrier(0);
             // B fragments one chunk ahead of the MFMAs that consume them (see the backward kernel)
+            auto bfrag = [&](int i, int nt) -> float4 {     // compile-time slot when REGW > 0
+                if constexpr (REGW == 0) {
+                    return frag[(wave * QL + ((i + rot) & (QW - 1)) * NT + nt) * 64 + lane];
+                } else {
+                    const int sl = i * NT + nt;
+                    return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+                }
+            };
             float4 bf[NT], nf[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = frag[(nt * Q + wave * QW + rot) * 64 + lane];
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = bfrag(0, nt);
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     nf[nt] = bf[nt];
-                    if (i + 1 < QW)
-                        nf[nt] = frag[(nt * Q + wave * QW + ((i + 1 + rot) & (QW - 1))) * 64 + lane];
+                    if (i + 1 < QW) nf[nt] = bfrag(i + 1, nt);
                 }
                 // pin the order: next chunk's ds_reads, THEN this chunk's MFMAs (hipcc otherwise
                 // sinks each read to one or two MFMAs before its first use).  Measured: plain RNN
@@ -301,6 +326,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (NT == 2) {
                         mma4x2(acc[mt][0], acc[mt][1], a[mt][i], bf[0], a[mt][i], bf[1]);
+                    } else if constexpr (NT == 4) {
+                        mma4x2(acc[mt][0], acc[mt][1], a[mt][i], bf[0], a[mt][i], bf[1]);
+                        mma4x2(acc[mt][2], acc[mt][3], a[mt][i], bf[2], a[mt][i], bf[3]);
                     } else {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) mma4(acc[mt][nt], a[mt][i], bf[nt]);
@@ -372,7 +400,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
-        if (s + 1 < T) dir_arrive(p.sync, dir, grp, tid);
+        if (s + 1 < p.s_hi) dir_arrive(p.sync, dir, grp, tid);
         // y and the reserve for the backward pass: nobody inside this launch reads them
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -394,6 +422,16 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if constexpr (CELL == CTCASR_CELL_LSTM) {
+        if (p.s_hi < T) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * PRNN_THREADS;
+                if (item < 16 * MT * UPB && item / UPB < B)
+                    p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB] = c_state[it];
+            }
+        }
     }
     if (prof) {
         for (int i = 0; i < 4; ++i) {
@@ -716,9 +754,10 @@ int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_flo
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    if (p.s_hi < p.T) {
-        // continuing a backward pass: fresh barrier counters, but the error word, the exchange
-        // buffer and its all-zero step stay as the previous launch left them
+    const bool continued = p.dxw ? p.s_hi < p.T : p.s_lo > 0;
+    if (continued) {
+        // continuing a pass: fresh barrier counters, but the error word, the exchange buffer and
+        // its all-zero step stay as the previous launch left them
         if (hipMemsetAsync(p.sync, 0, offsetof(SyncWords, error), s) != hipSuccess)
             return CTCASR_ERR_LAUNCH;
     } else {
@@ -785,6 +824,7 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
 
 size_t prnn_sync_bytes() { return sizeof(SyncWords); }
 
+int g_fwd_half_chip = 0;
 int g_bwd_half_chip = 1;   // measured faster than the whole-chip variant even without overlap
 
 // Process-wide options.  "rnn_bwd_half_chip" (default 1): the persistent backward recurrence runs on 128
@@ -793,6 +833,7 @@ int g_bwd_half_chip = 1;   // measured faster than the whole-chip variant even w
 extern "C" int ctcasr_set_option(const char *name, int value) {
     if (!name) return CTCASR_ERR_BAD_ARGUMENT;
     if (strcmp(name, "rnn_bwd_half_chip") == 0) { g_bwd_half_chip = value ? 1 : 0; return CTCASR_OK; }
+    if (strcmp(name, "rnn_fwd_half_chip") == 0) { g_fwd_half_chip = value ? 1 : 0; return CTCASR_OK; }
     if (strcmp(name, "rnn_kernel_events") == 0) { g_kernel_events = value ? 1 : 0; return CTCASR_OK; }
     return CTCASR_ERR_BAD_ARGUMENT;
 }
@@ -802,15 +843,17 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
 }
 
 int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
-             int H, float *y, float *gates, float *cells, void *sync, hipStream_t s) {
+             int H, float *y, float *gates, float *cells, void *sync, float *carry, int step_begin,
+             int step_end, hipStream_t s) {
     PArgs p = {};
+    p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H;
-    p.s_lo = 0; p.s_hi = T;
+    p.s_lo = step_begin; p.s_hi = step_end;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
-    if (seq_len && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
+    if (seq_len && step_begin == 0 && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
     // 128 workgroups per direction, 16 * NT gate columns each, QW = H / 64 K chunks per wave
@@ -820,6 +863,14 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
                                  (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 16,                     \
                              (size_t)2 * B * H, s)
     p.nwg = 128;
+    if (cell == CTCASR_CELL_LSTM && g_fwd_half_chip && mt == 1) {
+        // 64 workgroups per direction, 16 units = 4 N tiles each; 256 KB of weights: half in LDS,
+        // half in registers
+        p.nwg = 64;
+        return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, 4, 16, 1, 32>, p,
+                                 (size_t)4 * 32 * 64 * 16 + (size_t)4 * 4 * 16 * 17 * 4 + 16,
+                                 (size_t)2 * B * H, s);
+    }
     if (cell == CTCASR_CELL_LSTM) {
         if (mt == 1) { PRNN_FWD(CTCASR_CELL_LSTM, 2, 16, 1); }
         PRNN_FWD(CTCASR_CELL_LSTM, 2, 16, 2);

@@ -272,7 +272,8 @@ size_t prnn_sync_bytes();
 size_t prnn_error_offset();
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
-             int H, float *y, float *gates, float *cells, void *sync, hipStream_t s);
+             int H, float *y, float *gates, float *cells, void *sync, float *carry, int step_begin,
+             int step_end, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
              float *dxw, void *sync, float *carry, int step_begin, int step_end, hipStream_t s);
@@ -305,12 +306,20 @@ static int rnn_check(int cell, int T, int B, int H) {
     return CTCASR_OK;
 }
 
-extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
-                              const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
-                              void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
+// Steps [step_begin, step_end) of the forward recurrence.  A whole pass is (0, T); a pass may be
+// cut into launches that cover 0..T in ascending order with the same workspace and reserve - the
+// state between them (h through the exchange buffer / state ping-pong, c in the carry) stays in
+// the workspace.  After a launch, y of the steps it covered is final: their share of the NEXT
+// layer's input projection can run on another stream beside the following launch.
+extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh,
+                                    const float *b_hh_n, const int32_t *seq_len, int T, int B,
+                                    int H, float *y, void *reserve, void *workspace,
+                                    size_t workspace_bytes, int step_begin, int step_end,
+                                    ctcasr_stream_t stream) {
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
+    if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
     if (cell == CTCASR_CELL_GRU && !b_hh_n) return CTCASR_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
         return CTCASR_ERR_WORKSPACE;
@@ -324,13 +333,14 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, cons
     p.T = T; p.B = B; p.H = H; p.b_hh = b_hh_n;
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
         return prnn_fwd(cell, xw, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
-                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), s);
-    if (seq_len &&
+                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
+                        step_begin, step_end, s);
+    if (seq_len && step_begin == 0 &&
         hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int upb = cell == CTCASR_CELL_LSTM ? 8 : (cell == CTCASR_CELL_GRU ? 16 : 32);
     dim3 grid(H / upb, 2, (B + 15) / 16);
-    for (int step = 0; step < T; ++step) {
+    for (int step = step_begin; step < step_end; ++step) {
         p.step = step;
         if (cell == CTCASR_CELL_LSTM)
             rnn_fwd_step_kernel<CTCASR_CELL_LSTM><<<grid, RNN_THREADS, 0, s>>>(p);
@@ -342,6 +352,13 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, cons
             rnn_fwd_step_kernel<CTCASR_CELL_RNN_TANH><<<grid, RNN_THREADS, 0, s>>>(p);
     }
     return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
+                              const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
+                              void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
+    return ctcasr_rnn_fwd_steps(cell, xw, w_hh, b_hh_n, seq_len, T, B, H, y, reserve, workspace,
+                                workspace_bytes, 0, T, stream);
 }
 
 // Steps [step_begin, step_end) of the backward recurrence, walked downwards.  A whole pass is

@@ -41,6 +41,8 @@ SIGNATURES = {
     'ctcasr_rnn_gru_drec_offset': (_c_sz, [_c_int] * 3),
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
+    'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 +
+                             [_c_sz, _c_int, _c_int, _c_p]),
     'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 +
                              [_c_sz, _c_int, _c_int, _c_p]),
     'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
@@ -281,11 +283,20 @@ def rnn_gru_drec(reserve, num_steps, batch, hidden):
                                                                       3 * hidden)
 
 
-def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None):
-    """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace)."""
+def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None,
+            steps=None):
+    """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace).
+
+    ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_fwd_steps`): cut
+    a pass into calls covering 0..T in ascending order, passing the same ``y``, ``reserve`` and
+    ``workspace`` to each."""
     num_steps, batch = xw.shape[0], xw.shape[1]
     hidden = w_hh.shape[2]
     dev = xw.device
+    begin, end = (0, num_steps) if steps is None else steps
+    if (begin, end) != (0, num_steps) and (y is None or reserve is None or workspace is None):
+        raise ValueError('rnn_fwd: a partial step range needs the caller\'s y, reserve and '
+                         'workspace (they carry the pass from one call to the next).')
     y = torch.empty((num_steps, batch, 2 * hidden), dtype=torch.float32, device=dev) \
         if y is None else y
     if reserve is None:
@@ -293,11 +304,11 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
     if workspace is None:
         workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
     with _Timed('rnn_fwd'):
-      _check(load().ctcasr_rnn_fwd(
+      _check(load().ctcasr_rnn_fwd_steps(
         CELL_IDS[cell], _dev(xw, name='xw'), _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
         _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
         _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
-        workspace.numel(), _stream()), 'rnn_fwd')
+        workspace.numel(), int(begin), int(end), _stream()), 'rnn_fwd')
     return y, reserve, workspace
 
 

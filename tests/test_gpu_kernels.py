@@ -166,6 +166,27 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
                                  b_hh_n=_t(b_hh) if cell == 'gru' else None)
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert np.abs(y.cpu().numpy() - ys.detach().numpy()).max() < 2e-5
+    # the same forward pass cut into three launches (ctcasr_rnn_fwd_steps) is bit-identical, and
+    # so is the half-chip variant of the persistent LSTM kernel
+    if num_steps >= 5:
+        cuts = [0, 2, num_steps // 2 + 1, num_steps]
+        y_cut = torch.full_like(y, float('nan'))
+        reserve_cut, ws_cut = torch.zeros_like(reserve), torch.zeros_like(ws)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl, b_hh_n=_t(b_hh) if cell == 'gru' else None,
+                        y=y_cut, reserve=reserve_cut, workspace=ws_cut, steps=(lo, hi))
+        hip.rnn_poll_error(cell, ws_cut, num_steps, batch, hidden)
+        assert torch.equal(y_cut, y)
+        with pytest.raises(ValueError):
+            hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl, steps=(0, 2))
+    if cell == 'lstm' and hidden == 1024 and batch <= 16:
+        hip.set_option('rnn_fwd_half_chip', 1)
+        try:
+            y_half, _, ws_half = hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl)
+            hip.rnn_poll_error(cell, ws_half, num_steps, batch, hidden)
+        finally:
+            hip.set_option('rnn_fwd_half_chip', 0)
+        assert np.abs((y_half - y).cpu().numpy()).max() < 1e-6
     w_hh_t = hip.transpose_batched(_t(w_hh))
     assert torch.equal(w_hh_t.cpu(), torch.tensor(w_hh).transpose(1, 2).contiguous())
     dxw = hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, workspace=ws)

@@ -21,6 +21,8 @@ def main():
     hip.load(os.environ.get('CTCASR_LIB'))      # A/B builds of the library
     if os.environ.get('CTCASR_FULL'):      # backward recurrence on the whole chip (default: half)
         hip.set_option('rnn_bwd_half_chip', 0)
+    if os.environ.get('CTCASR_FWD_HALF'):  # forward recurrence on half of the chip
+        hip.set_option('rnn_fwd_half_chip', 1)
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)

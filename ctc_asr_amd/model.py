@@ -307,6 +307,9 @@ class CTCModel:
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
         # launch has finished run beside the next launch instead of queueing up behind the layer
         self.bwd_chunks = max(1, int(os.environ.get('CTCASR_BWD_CHUNKS', '3')))
+        # launches per persistent FORWARD recurrence when the next layer's input projection is
+        # pipelined with it on the other half of the chip (1 = off: whole-chip single launch)
+        self.fwd_chunks = max(1, int(os.environ.get('CTCASR_FWD_CHUNKS', '4')))
         self._side_stream = None
         self.dropout_seed = int(seed) * 0x9E3779B1 + 1
         self._acts = None
@@ -400,6 +403,7 @@ class CTCModel:
         cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
         rnn_len = None if cfg.cudnn else seq_length
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
+        pipelined_xw = None
         x = rnn_in.contiguous()
         workspace = None
         rnn_rate = cfg.rnn_dropout_rate if training else 0.0
@@ -415,15 +419,21 @@ class CTCModel:
             # biases that are plain additive terms are folded into xw (LSTM / RNN: both vectors;
             # GRU: everything but the recurrent bias of the candidate gate) - as the GEMM's bias
             # epilogue, which saves a read-modify-write pass over xw
-            if self.fuse_xw_bias:
+            if pipelined_xw is not None:       # built beside the previous layer's recurrence
+                xw, pipelined_xw = pipelined_xw, None
+            elif self.fuse_xw_bias:
                 xw = torch.addmm(self._rnn_bias(i), x.view(t_out * batch, -1), w_ih.t())
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
                 hip.bias_act_fwd(xw, self._rnn_bias(i), 0.0)
-            y, reserve, workspace = hip.rnn_fwd(
-                cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
-                rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,
-                workspace=workspace)
+            if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
+                y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
+                    i, xw, t_out, batch, hidden, gates, workspace)
+            else:
+                y, reserve, workspace = hip.rnn_fwd(
+                    cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
+                    rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,
+                    workspace=workspace)
             layer_in.append(x)
             layer_out.append(y)
             reserves.append(reserve)
@@ -442,6 +452,78 @@ class CTCModel:
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
         self._acts = acts
         return logits.view(t_out, batch, cfg.num_classes), seq_length
+
+    def _pipeline_forward(self, layer, cell, t_out, batch, hidden, rnn_len, rnn_rate):
+        """Whether layer ``layer``'s forward recurrence runs on half of the chip in step ranges
+        with the NEXT layer's input projection on the other half: pays when that projection is a
+        big GEMM (another LSTM layer follows), the steps map to the same time index for every row
+        and nothing (dropout) sits between the layers."""
+        return (self.fwd_chunks > 1 and cell == 'lstm' and batch <= 16 and rnn_len is None and
+                rnn_rate == 0.0 and layer + 1 < self.cfg.num_layers_rnn and
+                t_out >= 8 * self.fwd_chunks and
+                hip.rnn_persistent_supported(cell, t_out, batch, hidden))
+
+    def _rnn_fwd_pipelined(self, layer, xw, t_out, batch, hidden, gates, workspace):
+        """Forward recurrence of ``layer`` in ``fwd_chunks`` launches on 128 CUs; after each launch
+        the finished steps' share of the next layer's xw = y W_ih^T + b (split by direction:
+        times [lo, hi) of the forward half of y, [T-hi, T-lo) of the backward half) is added on
+        the side stream.  Returns (y, reserve, workspace, xw of the next layer)."""
+        p, cell = self.arena.p, 'lstm'
+        name, nxt = 'rnn{}'.format(layer), 'rnn{}'.format(layer + 1)
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        side = self._side_stream
+        dev = xw.device
+        gh = gates * hidden
+        y = torch.empty((t_out, batch, 2 * hidden), dtype=torch.float32, device=dev)
+        reserve = hip._workspace(hip.rnn_reserve_bytes(cell, t_out, batch, hidden), dev)
+        if workspace is None:
+            workspace = hip._workspace(hip.rnn_workspace_bytes(cell, t_out, batch, hidden), dev)
+        xw_next = torch.empty((t_out * batch, 2 * gh), dtype=torch.float32, device=dev)
+        w_next = p[nxt + '/w_ih'].view(2 * gh, 2 * hidden)
+        bias_next = self._rnn_bias(layer + 1)
+        started = set()            # time ranges of xw_next that already hold bias + one half
+
+        def contribute(lo, hi):
+            for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
+                rows = xw_next[a * batch:b * batch]
+                src = y[a:b, :, d * hidden:(d + 1) * hidden].reshape((b - a) * batch, hidden)
+                w_half = w_next[:, d * hidden:(d + 1) * hidden].t()
+                if (a, b) in started:
+                    rows.addmm_(src, w_half)
+                else:
+                    torch.addmm(bias_next, src, w_half, out=rows)
+                    started.add((a, b))
+
+        chunks = self.fwd_chunks
+        # symmetric cuts (bounds[c] + bounds[chunks - c] == T'): the backward direction's time
+        # ranges then coincide with the forward direction's
+        bounds = [t_out * c // chunks for c in range(chunks + 1)]
+        for c in range(chunks + 1):
+            if c > chunks - c:
+                bounds[c] = t_out - bounds[chunks - c]
+        hip.set_option('rnn_fwd_half_chip', 1)
+        try:
+            for c in range(chunks):
+                lo, hi = bounds[c], bounds[c + 1]
+                hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
+                            reserve=reserve, workspace=workspace, steps=(lo, hi))
+                if c + 1 < chunks:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        hip.stream_delay(self.side_head_start_us)
+                        contribute(lo, hi)
+                else:
+                    main.wait_stream(side)
+                    contribute(lo, hi)
+        finally:
+            hip.set_option('rnn_fwd_half_chip', 0)
+        for tensor in (y, xw_next):
+            tensor.record_stream(side)
+        return y, reserve, workspace, xw_next
 
     def _own_conv0_layer(self, layer, freq_in):
         return (self.own_conv and layer == 0 and freq_in == 80 and

@@ -88,6 +88,33 @@ def test_tiled_convolutions_equal_direct_convolutions(case, frames, tile, per_ca
                                      frames=frames)
 
 
+def test_pipelined_forward_equals_single_launch_forward():
+    """fwd_chunks = 4 (layer 1's forward recurrence on half of the chip in four step ranges, layer
+    2's input projection accumulated range by range on the side stream) against fwd_chunks = 1
+    (whole-chip launch, one GEMM): logits, loss and gradients agree to fp32 rounding, in
+    training and in evaluation mode."""
+    cfg, flat, feats, flen, labels = _setup('ds2_lstm_2conv', hidden=1024, frames=131, batch=2)
+    out = {}
+    for chunks in (1, 4):
+        model = CTCModel(cfg, 'cuda', params=flat)
+        model.fwd_chunks = chunks
+        assert model._pipeline_forward(0, 'lstm', 66, 2, 1024, None, 0.0) == (chunks > 1)
+        logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen),
+                                             training=True)
+        loss = model.loss_fn(logits, seq_len, labels)
+        model.backward()
+        eval_logits, _ = model.inference_fn(torch.tensor(feats), torch.tensor(flen),
+                                            training=False)
+        out[chunks] = (logits.cpu().numpy(), float(loss), model.arena.export('grad'),
+                       eval_logits.cpu().numpy())
+    assert np.abs(out[4][0] - out[1][0]).max() < 1e-5
+    assert abs(out[4][1] - out[1][1]) < 1e-4
+    assert np.abs(out[4][3] - out[1][3]).max() < 1e-5
+    for name, ref_g in out[1][2].items():
+        err = np.abs(out[4][2][name] - ref_g).max()
+        assert err < 1e-5 * max(1.0, np.abs(ref_g).max()), (name, err)
+
+
 def _check_logits_loss_and_gradients(case, bwd_chunks=None, conv_mode=None, conv_tile=None,
                                      **setup):
     cfg, flat, feats, flen, labels = _setup(case, **setup)

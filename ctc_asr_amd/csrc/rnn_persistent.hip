@@ -865,7 +865,8 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
     p.nwg = 128;
     if (cell == CTCASR_CELL_LSTM && g_fwd_half_chip && mt == 1) {
         // 64 workgroups per direction, 16 units = 4 N tiles each; 256 KB of weights: half in LDS,
-        // half in registers
+        // half in registers.  (Two batch tiles - B = 32 - were tried with 24 / 40 slots in LDS /
+        // registers: 10.9 instead of 7.3 us per step, more than the pipelined GEMM gives back.)
         p.nwg = 64;
         return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, 4, 16, 1, 32>, p,
                                  (size_t)4 * 32 * 64 * 16 + (size_t)4 * 4 * 16 * 17 * 4 + 16,

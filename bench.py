@@ -1,29 +1,40 @@
 #!/usr/bin/env python
 """Headline benchmark: audio-seconds/s of CTC acoustic-model *training* on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one full training pass over one synthetic minibatch of raw 16 kHz int16 PCM that is
 already resident in HBM: log-mel features + normalisation -> forward (conv front-end, BiLSTM
 stack, dense, logits) -> fused log-softmax + CTC loss/gradient -> backward -> RCCL gradient
-all-reduce (N > 1) -> TensorFlow-form Adam.  Workload =
-BASELINE.json configs[1]: DS2, 2 conv layers + 2 x BiLSTM-1024, batch 16 per GPU, 10 s
-utterances (999 feature frames -> T' = 500), fp32.  Scaling is weak: per-GPU batch fixed.
+all-reduce (N > 1) -> TensorFlow-form Adam.
+
+Workload (``--workload``, default ``c3``): BASELINE.json configs[2] - DS2, 2 conv layers +
+5 x BiLSTM-1024, batch 32 per GPU, 10 s utterances (999 feature frames -> T' = 500), fp32.  It is
+the per-GPU unit of configs[3] (global batch 256 on 8 GPUs), so the N = 1/2/4/8 curve is weak
+scaling of exactly this workload.  ``--workload c2`` is configs[1] (2 x BiLSTM-1024, batch 16);
+at N = 1 the default run measures it too and reports it under ``other_workloads``.
+
+One process per GPU.  Started without a torchrun environment and with ``--gpus N`` > 1, this
+script re-executes itself under ``torch.distributed.run`` with N ranks (backend nccl = RCCL) and
+exits non-zero if fewer than N GPUs are visible - it never silently falls back to one GPU.
 
 Rank 0 prints ONE JSON line (schema in the task contract) that also carries
-  "roofline":     the dominant kernel (the recurrent time-step kernel) against its roof,
-                  from HIP events recorded live around every recurrence call in the timed
-                  region, and
+  "roofline":     the dominant kernel (the recurrent time-step kernel) against its roof, from
+                  HIP events recorded by the library around every launch in the timed region;
+                  ``traffic`` comes from the committed rocprofv3 PMC summary
+                  (profiles/pmc_traffic.json, written by tools/make_profile_md.py), and
   "cpu_baseline": the same graph in stock torch CPU operators (oracle/torch_ref.py, kind
                   "port" - the reference's TensorFlow cannot run offline) on the host cores,
-                  rank 0, N = 1 only, bounded sample.
+                  rank 0, N = 1 only, SAME batch as the GPU line, bounded sample.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,22 +47,19 @@ if ROOT not in sys.path:
 
 WORKLOADS = {
     # name: (conv_filters, rnn layers, hidden, dense, per-GPU batch, seconds, rnn_cell)
-    'c2': ((32, 32), 2, 1024, 2048, 16, 10.0, 'lstm'),           # BASELINE.json configs[1] (metric)
+    'c2': ((32, 32), 2, 1024, 2048, 16, 10.0, 'lstm'),           # BASELINE.json configs[1]
     'c2_3conv': ((32, 32, 96), 2, 1024, 2048, 16, 10.0, 'lstm'),  # with the reference's 3 convs
-    'c3': ((32, 32), 5, 1024, 2048, 32, 10.0, 'lstm'),            # configs[2]
+    'c3': ((32, 32), 5, 1024, 2048, 32, 10.0, 'lstm'),            # configs[2] = per-GPU unit of [3]
     'c3_3conv': ((32, 32, 96), 5, 1024, 2048, 32, 10.0, 'lstm'),
     # the reference's own flag defaults (asr/params.py): 3 convs, 4 x ReLU-RNN-2048, batch 16
     'ref_default': ((32, 32, 96), 4, 2048, 2048, 16, 10.0, 'rnn_relu'),
     'tiny': ((8, 8), 1, 128, 128, 4, 2.0, 'lstm'),                # plumbing check
 }
+BASELINE_NAMES = {'c2': 'BASELINE.json configs[1]', 'c3': 'BASELINE.json configs[2]'}
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip table
-# (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch, measured with rocprofv3 PMC passes
-# (key: workload, pass, time steps per launch)
-PMC_TRAFFIC = {('c2', 'rnn_bwd', 167): int((486779 + 171415) * 1024),
-               ('c2', 'rnn_bwd', 500): int((1426952 + 513996) * 1024),
-               ('c2', 'rnn_fwd', 500): int((793441 + 451992) * 1024)}
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
 def forward_flops_per_utt(cfg, frames):
@@ -75,115 +83,158 @@ def forward_flops_per_utt(cfg, frames):
     return flops
 
 
+# ------------------------------------------------------------------------------ CPU baseline
 def _cpu_baseline_worker(spec):
-    """Runs in a child process: time the torch-CPU restatement (fwd + bwd + TF-Adam)."""
+    """Runs in a child process: time the torch-CPU restatement (fwd + bwd + TF-Adam).  First a
+    thread-count sweep on a small proxy batch, then the full batch with the best count."""
     from ctc_asr_amd.model import ModelConfig, init_params, to_oracle_layout
     from ctc_asr_amd.synth import synthetic_batch
     from oracle import torch_ref
     cfg = ModelConfig(**spec['cfg'])
-    threads, batch, seconds = spec['threads'], spec['batch'], spec['seconds']
-    torch.set_num_threads(threads)
-    feats, lengths, labels, _ = synthetic_batch(batch, seconds, seed=99, frames=spec['frames'])
-    label_rows = [[int(v) for v in row if v] for row in labels]
     model = torch_ref.TorchRefModel(to_oracle_layout(init_params(cfg, 0), cfg), cfg.used_model,
                                     cfg.rnn_cell, cfg.cudnn)
     opt = torch_ref.TFAdam(model.parameters())
-    feats_t = torch.tensor(feats)
 
-    def one_step():
-        opt.zero_grad()
-        logits, seq_len = model(feats_t, lengths)
-        loss, _ = model.loss(logits, seq_len, label_rows)
-        loss.backward()
-        opt.step()
+    def make_step(batch):
+        feats, lengths, labels, _ = synthetic_batch(batch, spec['seconds'], seed=99,
+                                                    frames=spec['frames'])
+        label_rows = [[int(v) for v in row if v] for row in labels]
+        feats_t = torch.tensor(feats)
 
+        def one_step():
+            opt.zero_grad()
+            logits, seq_len = model(feats_t, lengths)
+            loss, _ = model.loss(logits, seq_len, label_rows)
+            loss.backward()
+            opt.step()
+        return one_step
+
+    sweep = {}
+    proxy = make_step(spec['proxy_batch'])
+    deadline = time.perf_counter() + spec['sweep_budget_s']
+    for threads in spec['candidates']:
+        torch.set_num_threads(threads)
+        proxy()                                   # warm-up at this thread count
+        t0 = time.perf_counter()
+        proxy()
+        sweep[threads] = time.perf_counter() - t0
+        if time.perf_counter() > deadline:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    full = make_step(spec['batch'])
     t0 = time.perf_counter()
-    one_step()                               # warm-up (also tells us how long a step takes)
+    full()                                        # warm-up (also tells us how long a step takes)
     warm = time.perf_counter() - t0
     steps = int(max(1, min(10, (spec['budget_s'] - warm) // max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_step()
+        full()
     per_step = (time.perf_counter() - t0) / steps
-    print(json.dumps({'steps': steps, 'per_step': per_step, 'warm': warm}))
+    print(json.dumps({'steps': steps, 'per_step': per_step, 'warm': warm, 'threads': best,
+                      'sweep': {str(k): round(v, 3) for k, v in sweep.items()}}))
 
 
-def cpu_baseline(cfg_kwargs, seconds, frames, budget_s=20.0, hard_limit_s=150.0):
-    """CPU baseline (kind "port") on a bounded sample, in a child process with a hard time
-    limit so that a slow host can never stall the benchmark."""
-    import subprocess
+def host_cores():
+    """(usable logical CPUs, physical cores among them)."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        logical = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    batch = 2
+        logical = os.cpu_count() or 1
+    physical = logical
+    try:
+        import psutil
+        physical = min(logical, psutil.cpu_count(logical=False) or logical)
+    except Exception:
+        pass
+    return logical, physical
+
+
+def cpu_baseline(cfg_kwargs, batch, seconds, frames, budget_s=25.0, hard_limit_s=300.0):
+    """CPU baseline (kind "port") at the SAME batch as the GPU line, in a child process with a
+    hard time limit so that a slow host can never stall the benchmark.  The thread count is
+    swept up to all physical cores (torch's CPU LSTM stops scaling well before that on a big
+    host) on a 4-utterance proxy batch; the full batch then runs with the fastest count."""
+    logical, physical = host_cores()
+    candidates = sorted({c for c in (8, 16, 32, 64, 128, physical) if c <= physical} or {1})
     code = ('import json,sys; sys.path.insert(0, {!r}); import bench; '
             'bench._cpu_baseline_worker(json.loads(sys.argv[1]))').format(ROOT)
-    # torch's CPU LSTM stops scaling well before all cores of a big host: time two thread counts
-    # (half the budget each) and report the faster one with the thread count it used
-    info, threads = None, 1
-    for cand in sorted({max(1, min(cores, 16)), max(1, min(cores, 64))}):
-        spec = {'cfg': cfg_kwargs, 'threads': cand, 'batch': batch, 'seconds': seconds,
-                'frames': frames, 'budget_s': budget_s / 2}
-        env = dict(os.environ, OMP_NUM_THREADS=str(cand), MKL_NUM_THREADS=str(cand))
-        try:
-            out = subprocess.run([sys.executable, '-c', code, json.dumps(spec)], env=env,
-                                 capture_output=True, text=True, timeout=hard_limit_s / 2)
-            got = json.loads(out.stdout.strip().splitlines()[-1])
-        except Exception:      # timeout or failure of this candidate: never block the GPU result
-            continue
-        if info is None or got['per_step'] < info['per_step']:
-            info, threads = got, cand
-    if info is None:
-        return {'value': None, 'unit': 'audio-s/s', 'cores': threads, 'kind': 'port',
-                'sample': 'CPU baseline did not finish within {:.0f} s'.format(hard_limit_s)}
+    spec = {'cfg': cfg_kwargs, 'candidates': candidates, 'batch': batch,
+            'proxy_batch': min(4, batch), 'seconds': seconds, 'frames': frames,
+            'budget_s': budget_s, 'sweep_budget_s': 60.0}
+    try:
+        out = subprocess.run([sys.executable, '-c', code, json.dumps(spec)],
+                             capture_output=True, text=True, timeout=hard_limit_s)
+        info = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as err:      # timeout or failure: never block the GPU result
+        return {'value': None, 'unit': 'audio-s/s', 'cores': physical, 'kind': 'port',
+                'sample': 'CPU baseline did not finish within {:.0f} s ({})'.format(
+                    hard_limit_s, type(err).__name__)}
     return {'value': round(batch * seconds / info['per_step'], 3), 'unit': 'audio-s/s',
-            'cores': threads, 'kind': 'port',
-            'sample': '{} timed fwd+bwd+Adam steps after 1 warm-up, batch {} x {:.0f} s, torch '
-                      '{} CPU ops (oracle/torch_ref.py), {} of {} host cores, {:.2f} s/step'
-                      .format(info['steps'], batch, seconds, torch.__version__, threads, cores,
-                              info['per_step'])}
+            'cores': info['threads'], 'kind': 'port',
+            'sample': '{} timed fwd+bwd+Adam step(s) after 1 warm-up, batch {} x {:.0f} s (the '
+                      'GPU line\'s batch), torch {} CPU ops (oracle/torch_ref.py), {:.2f} s/step '
+                      'with {} threads = fastest of a sweep over {} threads on a batch-{} proxy '
+                      '(s/step {}); host: {} physical / {} logical cores'.format(
+                          info['steps'], batch, seconds, torch.__version__, info['per_step'],
+                          info['threads'], candidates, spec['proxy_batch'], info['sweep'],
+                          physical, logical)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--dropout', type=float, default=0.1,
-                    help='dense_dropout_rate (reference default 0.1)')
-    ap.add_argument('--rnn-bwd-whole-chip', action='store_true',
-                    help='persistent backward recurrence on all 256 CUs (default: 128)')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------ measurement
+def pmc_traffic(workload, which, launch_steps):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by tools/make_profile_md.py).  Returns a dict for the
+    roofline object; ``traffic`` is None (with the reason) when no matching entry exists."""
+    try:
+        with open(PMC_TRAFFIC_JSON) as handle:
+            table = json.load(handle)
+    except (OSError, ValueError):
+        return {'traffic': None, 'traffic_note': 'no profiles/pmc_traffic.json'}
+    for entry in table.get('entries', []):
+        if entry['workload'] == workload and entry['pass'] == which and \
+                abs(entry['steps_per_launch'] - launch_steps) <= 1:
+            fetch, write = entry['fetch_kb'] * 1024.0, entry['write_kb'] * 1024.0
+            out = {
+                # FETCH_SIZE reads half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md
+                # section HBM): the corrected figure doubles the read side
+                'traffic': int(2 * fetch + write),
+                'traffic_raw': int(fetch + write),
+                'traffic_note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of '
+                                'this workload, per launch; traffic = 2 x FETCH + WRITE (gfx950 '
+                                'FETCH_SIZE correction), traffic_raw = as reported; {}'.format(
+                                    entry.get('source', ''))}
+            if entry.get('algorithmic_bytes'):
+                out['algorithmic_bytes_per_launch'] = int(entry['algorithmic_bytes'])
+                out['traffic_over_algorithmic'] = round(out['traffic'] /
+                                                        entry['algorithmic_bytes'], 2)
+            return out
+    return {'traffic': None,
+            'traffic_note': 'no PMC entry for ({}, {}, {} steps per launch) in '
+                            'profiles/pmc_traffic.json'.format(workload, which, launch_steps)}
 
+
+def measure(name, args, rank, local_rank, world):
+    """Build the workload ``name`` on this rank's GPU, run warm-up + timed steps under the
+    contract's protocol and return the result dict (rank 0) or None."""
     from ctc_asr_amd import hip
-    from ctc_asr_amd.engine import Trainer, init_distributed
+    from ctc_asr_amd.engine import Trainer
     from ctc_asr_amd.model import CTCModel, GATES, ModelConfig
-    from ctc_asr_amd.synth import synthetic_batch
+    from ctc_asr_amd.synth import random_pcm, synthetic_batch
     import torch.distributed as dist
 
-    if args.rnn_bwd_whole_chip:
-        hip.set_option('rnn_bwd_half_chip', 0)
-    rank, local_rank, world = init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus {} does not match WORLD_SIZE {}'.format(args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X; no GPU is visible.')
-    torch.cuda.set_device(local_rank)
     device = 'cuda:{}'.format(local_rank)
-
-    filters, layers, hidden, dense, batch, seconds, rnn_cell = WORKLOADS[args.workload]
+    filters, layers, hidden, dense, batch, seconds, rnn_cell = WORKLOADS[name]
     cfg = ModelConfig(used_model='ds2', conv_filters=filters, num_units_dense=dense,
                       num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell, cudnn=True,
                       dense_dropout_rate=args.dropout)
     # fixed input shape: let MIOpen benchmark its convolution kernels once (warm-up steps)
     trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True)
     model = trainer.model
+    if args.rnn_bwd_whole_chip:
+        model.rnn_bwd_flags = hip.RNN_WHOLE_CHIP
 
     # synthetic 16 kHz utterances: int16 PCM resident in HBM (SURVEY.md 8d recipe), random labels
-    from ctc_asr_amd.synth import random_pcm
     _, _, labels, _ = synthetic_batch(batch, seconds, seed=1234 + rank, frames=1)
     rng = np.random.default_rng(4321 + rank)
     num_samples = int(round(seconds * 16000))
@@ -205,12 +256,14 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     CTCModel.check_status(model.last_status)
+    model.check_rnn_error()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     hip.EVENTS = {}
     hip.set_option('rnn_kernel_events', 1)      # event pairs right around the persistent kernels
     hip.rnn_kernel_events()
+    trainer.reducer.launched = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -229,8 +282,10 @@ def main():
         elapsed = float(t.item())
     CTCModel.check_status(model.last_status)
     # a persistent recurrence launch that gave up at a grid barrier would have produced garbage
-    hip.rnn_poll_error(cfg.cell, model._acts['rnn_ws'], cfg.output_time(frames), batch, hidden)
+    # (sticky word: covers every layer, pass and step since the check before the timed region)
+    model.check_rnn_error()
 
+    result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         audio_s = world * batch * seconds
@@ -238,8 +293,8 @@ def main():
         t_out = cfg.output_time(frames)
         flops_per_audio_s = 3.0 * forward_flops_per_utt(cfg, frames) / seconds
         gates = GATES[cfg.cell]
-        # dominant kernel: the recurrence.  Persistent variant: one launch per layer-pass runs all
-        # T' steps with the recurrent weights resident in LDS -> fp32-MFMA roof (the limiter is the
+        # dominant kernel: the recurrence.  Persistent variant: one launch runs a range of steps
+        # with the recurrent weights resident in LDS -> fp32-MFMA roof (the limiter is the
         # per-step all-to-all exchange of h / dgates).  Streaming variant: one launch per time
         # step re-reads the weights -> HBM/MALL bandwidth roof.
         persistent = hip.rnn_persistent_supported(cfg.cell, t_out, batch, hidden)
@@ -253,24 +308,28 @@ def main():
                 # the kernel alone (library-side event pair), not the call incl. its memsets
                 calls, dom_ms = kernel_events[dom[4:]]
                 avg_s = dom_ms * 1e-3 / calls
-                # the backward recurrence of a layer may be cut into several launches
-                # (CTCModel.bwd_chunks); a launch then covers T' / chunks time steps
+                # a layer's recurrence may be cut into several launches (CTCModel.bwd_chunks /
+                # fwd_chunks); a launch then covers T' / chunks time steps
                 launch_steps = t_out * args.steps * cfg.num_layers_rnn / float(calls)
                 achieved = flops_per_step * launch_steps / avg_s / 1e12
                 roofline = {
                     'kernel': 'prnn_{}_kernel<{}> (persistent, LDS-resident recurrent weights; '
-                              'one launch = {:.0f} time steps x 2 directions)'.format(
-                                  dom[4:], rnn_cell.upper(), launch_steps),
+                              'one launch = {:.0f} time steps x 2 directions, batch {})'.format(
+                                  dom[4:], rnn_cell.upper(), launch_steps, batch),
                     'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-                    # passes of this workload (profiles/r01_final_c2_kernel_trace_and_pmc.md)
-                    'traffic': PMC_TRAFFIC.get((args.workload, dom, round(launch_steps))),
+                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
+                roofline.update(pmc_traffic(name, dom, round(launch_steps)))
+                roofline.update({
                     'avg_launch_us': round(avg_s * 1e6, 1), 'launches': calls,
                     'algorithmic_flops_per_launch': flops_per_step * launch_steps,
                     'us_per_time_step': round(avg_s * 1e6 / launch_steps, 3),
-                    'share_of_step': round(dom_ms / (elapsed * 1e3), 3)}
+                    'share_of_step': round(dom_ms / (elapsed * 1e3), 3),
+                    'other_pass': {
+                        'kernel': 'prnn_{}_kernel'.format('fwd' if dom == 'rnn_bwd' else 'bwd'),
+                        'us_per_time_step': round(
+                            kernel_events['fwd' if dom == 'rnn_bwd' else 'bwd'][1] * 1e3 /
+                            max(1.0, t_out * args.steps * cfg.num_layers_rnn), 3)}})
             else:
                 launches = calls * t_out
                 avg_s = dom_ms * 1e-3 / launches
@@ -293,12 +352,10 @@ def main():
                                     'utterances resident in HBM, random labels at 15 chars/s)',
             'config': {'workload': '{}: DS2 {}-conv + {}xBi{}-{}, '
                                    'batch {}/GPU, {:.0f} s utterances'.format(
-                                       {'c2': 'BASELINE.json configs[1]',
-                                        'c3': 'BASELINE.json configs[2]'}.get(
-                                            args.workload, args.workload), len(filters), layers,
+                                       BASELINE_NAMES.get(name, name), len(filters), layers,
                                        {'lstm': 'LSTM', 'rnn_relu': 'RNN(relu)'}[rnn_cell],
                                        hidden, batch, seconds),
-                       'name': args.workload, 'global_batch': world * batch, 'frames': frames,
+                       'name': name, 'global_batch': world * batch, 'frames': frames,
                        'ctc_steps': t_out, 'parallelism': 'dp{}'.format(world),
                        'dense_dropout_rate': args.dropout,
                        'parameters': model.arena.num_parameters()},
@@ -309,13 +366,109 @@ def main():
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             'roofline': roofline,
         }
+        if world > 1:
+            result['allreduce'] = {
+                'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ''),
+                'bytes_per_step': int(model.arena.size * 4),
+                'launches_per_step': trainer.reducer.launched / float(args.steps),
+                'bucket_bytes': int(trainer.reducer.bucket_elems * 4)}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return result, (cfg, frames, batch, seconds)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` outside torchrun: start the N ranks (one per GPU, RCCL)."""
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < args.gpus:
+        sys.stderr.write('bench.py: --gpus {} requested but only {} GPU(s) visible; refusing to '
+                         'run a smaller job under that label.\n'.format(args.gpus, visible))
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        'HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the secondary C2 measurement of the default N = 1 run')
+    ap.add_argument('--dropout', type=float, default=0.1,
+                    help='dense_dropout_rate (reference default 0.1)')
+    ap.add_argument('--rnn-bwd-whole-chip', action='store_true',
+                    help='persistent backward recurrence on all 256 CUs (default: 128)')
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    from ctc_asr_amd.engine import init_distributed
+    import torch.distributed as dist
+
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env != args.gpus:
+        raise SystemExit('--gpus {} does not match WORLD_SIZE {}'.format(args.gpus, world_env))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X; no GPU is visible.')
+    if torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', world_env)):
+        raise SystemExit('bench.py: {} ranks on this node but only {} GPU(s) visible.'.format(
+            os.environ.get('LOCAL_WORLD_SIZE', world_env), torch.cuda.device_count()))
+    rank, local_rank, world = init_distributed()
+    torch.cuda.set_device(local_rank)
+
+    ranks_seen, devices = 1, None
+    if world > 1:
+        # proof that the collective backend really connects `world` ranks, one GPU each
+        ones = torch.ones(1, device='cuda:{}'.format(local_rank))
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {'rank': rank, 'device': local_rank, 'name': props.name,
+                'uuid': str(getattr(props, 'uuid', ''))}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        if ranks_seen != world or len({(d['device'], d['uuid']) for d in devices}) != world:
+            raise SystemExit('bench.py: ranks do not map to {} distinct GPUs: {}'.format(
+                world, devices))
+
+    result, (cfg, frames, batch, seconds) = measure(args.workload, args, rank, local_rank, world)
+    other = {}
+    if world == 1 and args.workload == 'c3' and not args.no_other_workloads:
+        second, _ = measure('c2', args, rank, local_rank, world)
+        other['c2'] = {k: second[k] for k in ('value', 'unit', 'ms_per_step', 'config',
+                                              'step_tflops_fp32', 'frac_of_fp32_mfma_peak',
+                                              'kernel_ms_per_step', 'roofline')}
+    if rank == 0:
+        if world > 1:
+            result['allreduce']['ranks_seen_by_allreduce'] = ranks_seen
+            result['devices'] = devices
+        if other:
+            result['other_workloads'] = other
         if world == 1 and not args.no_cpu_baseline:
+            filters, layers, hidden, dense, _, _, rnn_cell = WORKLOADS[args.workload]
             cfg_kwargs = dict(used_model='ds2', conv_filters=list(filters), num_units_dense=dense,
                               num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell,
                               cudnn=True, dense_dropout_rate=0.0)
-            result['cpu_baseline'] = cpu_baseline(cfg_kwargs, seconds, frames)
+            result['cpu_baseline'] = cpu_baseline(cfg_kwargs, batch, seconds, frames)
             if result['cpu_baseline']['value']:
-                result['gpu_over_cpu'] = round(value / result['cpu_baseline']['value'], 1)
+                result['gpu_over_cpu'] = round(result['value'] / result['cpu_baseline']['value'],
+                                               1)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

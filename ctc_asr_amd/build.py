@@ -12,6 +12,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libctcasr.so')
+HOST_LIB_PATH = os.path.join(PKG_DIR, 'libctcasr_host.so')     # plain C helpers, no device code
+HOST_SOURCES = [os.path.join(PKG_DIR, 'host', 'crc32c.c')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -29,8 +31,24 @@ def _stale():
     return any(os.path.getmtime(d) > built for d in deps)
 
 
+def build_host(force=False, verbose=True):
+    """gcc over ``host/*.c`` -> ``libctcasr_host.so`` (``include/ctcasr_host.h``)."""
+    deps = HOST_SOURCES + [os.path.join(PKG_DIR, '..', 'include', 'ctcasr_host.h')]
+    if not force and os.path.exists(HOST_LIB_PATH) and \
+            all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
+        return HOST_LIB_PATH
+    cmd = [os.environ.get('CC', 'gcc'), '-O2', '-std=c99', '-fPIC', '-shared', '-Wall', '-o',
+           HOST_LIB_PATH] + HOST_SOURCES
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_LIB_PATH
+
+
 def build(force=False, verbose=True):
-    """Compile every ``csrc/*.hip`` into one shared object; returns its path."""
+    """Compile every ``csrc/*.hip`` into one shared object (and the host helper library);
+    returns the device library's path."""
+    build_host(force, verbose)
     if not force and not _stale():
         return LIB_PATH
     obj_dir = os.path.join(PKG_DIR, 'csrc', '_obj')

@@ -755,14 +755,13 @@ int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_flo
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const bool continued = p.dxw ? p.s_hi < p.T : p.s_lo > 0;
-    if (continued) {
-        // continuing a pass: fresh barrier counters, but the error word, the exchange buffer and
-        // its all-zero step stay as the previous launch left them
-        if (hipMemsetAsync(p.sync, 0, offsetof(SyncWords, error), s) != hipSuccess)
-            return CTCASR_ERR_LAUNCH;
-    } else {
-        if (hipMemsetAsync(p.sync, 0, sizeof(SyncWords), s) != hipSuccess)
-            return CTCASR_ERR_LAUNCH;
+    // Fresh barrier counters for every launch.  The error word behind them is STICKY: a launch
+    // never clears it, so a timeout in any layer or pass survives until ctcasr_rnn_poll_error
+    // reads (and clears) it - the workspace must be zero-filled once before its first use.
+    if (hipMemsetAsync(p.sync, 0, offsetof(SyncWords, error), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    if (!continued) {
+        // (a continued pass keeps the exchange buffer and its all-zero step as they are)
         if (hipMemsetAsync(p.xchg + (size_t)p.T * zero_step_floats, 0,
                            zero_step_floats * sizeof(float), s) != hipSuccess)
             return CTCASR_ERR_LAUNCH;
@@ -824,16 +823,10 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
 
 size_t prnn_sync_bytes() { return sizeof(SyncWords); }
 
-int g_fwd_half_chip = 0;
-int g_bwd_half_chip = 1;   // measured faster than the whole-chip variant even without overlap
-
-// Process-wide options.  "rnn_bwd_half_chip" (default 1): the persistent backward recurrence runs on 128
-// CUs (64 workgroups per direction, weights split between LDS and registers) so that GEMMs
-// issued on another stream can run beside it.
+// Process-wide profiling switch (the only option): "rnn_kernel_events".  Which variant of a
+// persistent kernel runs is a per-call argument (`flags` of ctcasr_rnn_fwd_steps / _bwd_steps).
 extern "C" int ctcasr_set_option(const char *name, int value) {
     if (!name) return CTCASR_ERR_BAD_ARGUMENT;
-    if (strcmp(name, "rnn_bwd_half_chip") == 0) { g_bwd_half_chip = value ? 1 : 0; return CTCASR_OK; }
-    if (strcmp(name, "rnn_fwd_half_chip") == 0) { g_fwd_half_chip = value ? 1 : 0; return CTCASR_OK; }
     if (strcmp(name, "rnn_kernel_events") == 0) { g_kernel_events = value ? 1 : 0; return CTCASR_OK; }
     return CTCASR_ERR_BAD_ARGUMENT;
 }
@@ -844,7 +837,9 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
 
 int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
              int H, float *y, float *gates, float *cells, void *sync, float *carry, int step_begin,
-             int step_end, hipStream_t s) {
+             int step_end, int flags, hipStream_t s) {
+    // forward default: the whole chip (nothing of the same layer can overlap it)
+    const bool fwd_half_chip = (flags & CTCASR_RNN_HALF_CHIP) != 0;
     PArgs p = {};
     p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
@@ -863,7 +858,7 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
                                  (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 16,                     \
                              (size_t)2 * B * H, s)
     p.nwg = 128;
-    if (cell == CTCASR_CELL_LSTM && g_fwd_half_chip && mt == 1) {
+    if (cell == CTCASR_CELL_LSTM && fwd_half_chip && mt == 1) {
         // 64 workgroups per direction, 16 units = 4 N tiles each; 256 KB of weights: half in LDS,
         // half in registers.  (Two batch tiles - B = 32 - were tried with 24 / 40 slots in LDS /
         // registers: 10.9 instead of 7.3 us per step, more than the pipelined GEMM gives back.)
@@ -887,14 +882,17 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
 
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, void *sync, float *carry, int step_begin, int step_end, hipStream_t s) {
+             float *dxw, void *sync, float *carry, int step_begin, int step_end, int flags,
+             hipStream_t s) {
     PArgs p = {};
     p.s_lo = step_begin; p.s_hi = step_end; p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
     p.sync = reinterpret_cast<SyncWords *>(sync);
-    const bool half_chip = g_bwd_half_chip != 0;
+    // backward default: half of the chip (measured faster than the whole-chip variant even
+    // without GEMMs beside it)
+    const bool half_chip = (flags & CTCASR_RNN_WHOLE_CHIP) == 0;
     p.T = T; p.B = B; p.H = H;
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;

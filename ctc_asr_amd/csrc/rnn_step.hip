@@ -273,10 +273,11 @@ size_t prnn_error_offset();
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
              int H, float *y, float *gates, float *cells, void *sync, float *carry, int step_begin,
-             int step_end, hipStream_t s);
+             int step_end, int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, void *sync, float *carry, int step_begin, int step_end, hipStream_t s);
+             float *dxw, void *sync, float *carry, int step_begin, int step_end, int flags,
+             hipStream_t s);
 
 static size_t rnn_state_bytes(int B, int H) {
     return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256);
@@ -315,9 +316,10 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh
                                     const float *b_hh_n, const int32_t *seq_len, int T, int B,
                                     int H, float *y, void *reserve, void *workspace,
                                     size_t workspace_bytes, int step_begin, int step_end,
-                                    ctcasr_stream_t stream) {
+                                    int flags, ctcasr_stream_t stream) {
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
+    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP)) return CTCASR_ERR_BAD_ARGUMENT;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
     if (cell == CTCASR_CELL_GRU && !b_hh_n) return CTCASR_ERR_BAD_ARGUMENT;
@@ -334,7 +336,7 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
         return prnn_fwd(cell, xw, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
-                        step_begin, step_end, s);
+                        step_begin, step_end, flags, s);
     if (seq_len && step_begin == 0 &&
         hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
@@ -358,7 +360,7 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, cons
                               const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
                               void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
     return ctcasr_rnn_fwd_steps(cell, xw, w_hh, b_hh_n, seq_len, T, B, H, y, reserve, workspace,
-                                workspace_bytes, 0, T, stream);
+                                workspace_bytes, 0, T, CTCASR_RNN_DEFAULT, stream);
 }
 
 // Steps [step_begin, step_end) of the backward recurrence, walked downwards.  A whole pass is
@@ -371,10 +373,11 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
                                     const int32_t *seq_len, int T, int B, int H,
                                     const void *reserve, float *dxw, float *db_hh_n,
                                     void *workspace, size_t workspace_bytes, int step_begin,
-                                    int step_end, ctcasr_stream_t stream) {
+                                    int step_end, int flags, ctcasr_stream_t stream) {
     (void)b_hh_n; (void)db_hh_n;   // the GRU bias gradient is the column sum of drec (caller)
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
+    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP)) return CTCASR_ERR_BAD_ARGUMENT;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
@@ -392,7 +395,7 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
         return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
-                        step_begin, step_end, s);
+                        step_begin, step_end, flags, s);
     if (seq_len && step_end == T &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
@@ -419,22 +422,25 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
                               const void *reserve, float *dxw, float *db_hh_n, void *workspace,
                               size_t workspace_bytes, ctcasr_stream_t stream) {
     return ctcasr_rnn_bwd_steps(cell, dy, y, w_hh_t, b_hh_n, seq_len, T, B, H, reserve, dxw,
-                                db_hh_n, workspace, workspace_bytes, 0, T, stream);
+                                db_hh_n, workspace, workspace_bytes, 0, T, CTCASR_RNN_DEFAULT,
+                                stream);
 }
 
-// Synchronises `stream` and reports whether the last persistent launch that used `workspace`
-// gave up at a grid barrier (CTCASR_ERR_TIMEOUT).  Streaming launches never set the word.
-extern "C" int ctcasr_rnn_poll_error(const void *workspace, size_t workspace_bytes, int cell,
+// Synchronises `stream` and reports whether ANY persistent launch that used `workspace` since
+// the last poll gave up at a grid barrier (CTCASR_ERR_TIMEOUT); the word is sticky across
+// launches and cleared by this call.  Streaming launches never set it.
+extern "C" int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, int cell,
                                      int T, int B, int H, ctcasr_stream_t stream) {
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
         return CTCASR_ERR_WORKSPACE;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CTCASR_ERR_LAUNCH;
     if (!ctcasr_rnn_persistent_supported(cell, T, B, H)) return CTCASR_OK;
     unsigned err = 0;
-    const char *word = reinterpret_cast<const char *>(workspace) + rnn_state_bytes(B, H) +
-                       prnn_error_offset();
+    char *word = reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
+                 prnn_error_offset();
     if (hipMemcpy(&err, word, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
+    if (err && hipMemset(word, 0, sizeof(err)) != hipSuccess) return CTCASR_ERR_LAUNCH;
     return err ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
 }
 

@@ -55,6 +55,7 @@ class GradientReducer:
         self.pending_start = None
         self.pending_stop = None
         self.works = []
+        self.launched = 0               # all-reduce launches so far (bench.py reports per step)
         # Collective kernels must not be in flight while a persistent recurrence kernel starts:
         # that kernel needs all of its workgroups co-resident (one per CU) and spins at grid
         # barriers, so RCCL workgroups holding CUs could stall it past its spin limit.  With
@@ -63,6 +64,18 @@ class GradientReducer:
         # GEMMs and the conv backward, which have no residency requirement.
         self.hold_until = hold_until
         self.released = hold_until is None
+
+    def __call__(self, layer, start, stop):
+        self.hook(layer, start, stop)
+
+    def flush(self):
+        """Launch whatever is pending now (if released).  `CTCModel.backward` calls this at the
+        end of the block of hooks that run with the side stream current: those slices were
+        produced by side-stream GEMMs, so their all-reduce must be enqueued while that stream is
+        still the current one - never merged into a bucket that is launched later from the main
+        stream, which is not ordered after them."""
+        if self.world > 1 and self.released:
+            self._flush()
 
     def hook(self, layer, start, stop):
         if self.world <= 1:
@@ -87,6 +100,7 @@ class GradientReducer:
         view = self.grad[self.pending_start:self.pending_stop]
         self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
                                           async_op=True))
+        self.launched += 1
         self.pending_start = self.pending_stop = None
 
     def finish(self):
@@ -123,7 +137,12 @@ class Trainer:
         ranks of the local means (equal shard sizes), so gradients are summed and scaled by
         1 / world_size inside the Adam kernel."""
         loss = self.model.forward_backward(features, feature_len, labels,
-                                           reduce_hook=self.reducer.hook, check=check)
+                                           reduce_hook=self.reducer, check=check)
+        if check:
+            # a persistent recurrence kernel that gave up at a grid barrier (e.g. starved of
+            # co-residency by another process on the GPU) produced garbage: stop before Adam
+            # consumes it.  (check=False callers poll `model.check_rnn_error()` themselves.)
+            self.model.check_rnn_error()
         self.reducer.finish()
         self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
                                    grad_scale=1.0 / self.world)

@@ -32,6 +32,7 @@ def evaluate_dataset(model, target, rank=0, world=1, max_batches=None, report_sa
         logits, seq_len = model.inference_fn(features['spectrogram'],
                                              features['spectrogram_length'], training=False)
         loss = model.loss_fn(logits, seq_len, labels)
+        model.check_rnn_error()       # a timed-out persistent recurrence would score garbage
         decoded, plaintext, summary = model.decode_fn(logits, seq_len,
                                                       np.array([t.encode('utf-8') for t in
                                                                 features['label_plaintext']],

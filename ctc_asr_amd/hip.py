@@ -6,6 +6,7 @@ non-zero status raises.
 """
 
 import ctypes
+import functools
 import os
 
 import torch
@@ -13,6 +14,8 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libctcasr.so')
 
+ABI_VERSION = 2
+RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP = 0, 1, 2      # `flags` of rnn_fwd / rnn_bwd
 CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
 CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}
 
@@ -23,7 +26,6 @@ _c_f, _c_p, _c_sz = ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     'ctcasr_abi_version': (_c_int, []),
     'ctcasr_error_string': (ctypes.c_char_p, [_c_int]),
-    'ctcasr_crc32c': (ctypes.c_uint32, [_c_p, _c_sz, ctypes.c_uint32]),
     'ctcasr_set_option': (_c_int, [ctypes.c_char_p, _c_int]),
     'ctcasr_rnn_kernel_events': (_c_int, [_c_p, _c_p]),
     'ctcasr_log_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
@@ -42,9 +44,9 @@ SIGNATURES = {
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
     'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 +
-                             [_c_sz, _c_int, _c_int, _c_p]),
+                             [_c_sz, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 +
-                             [_c_sz, _c_int, _c_int, _c_p]),
+                             [_c_sz, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
@@ -121,7 +123,7 @@ def load(path=None):
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the ABI does not export the symbol
         fn.restype, fn.argtypes = restype, argtypes
-    if lib.ctcasr_abi_version() != 1:
+    if lib.ctcasr_abi_version() != ABI_VERSION:
         raise CtcAsrError('libctcasr ABI version mismatch')
     _lib = lib
     return lib
@@ -150,25 +152,33 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_tensor_device(fn):
+    """Run a launching wrapper with the device of its first GPU tensor argument current, so that
+    the stream it launches on (`_stream`) and the memory it is given belong to the same GPU even
+    when the caller's current device is another one (``CTCModel(cfg, 'cuda:1')`` from a
+    process whose current device is 0)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for value in list(args) + list(kwargs.values()):
+            if torch.is_tensor(value) and value.is_cuda:
+                if value.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(value.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 # ------------------------------------------------------------------------------------------
-def crc32c(data, crc=0):
-    """CRC-32C of a bytes-like object / contiguous numpy array in host memory."""
-    view = memoryview(data).cast('B')
-    if len(view) == 0:
-        return int(crc)
-    buf = (ctypes.c_char * len(view)).from_buffer_copy(view) if view.readonly \
-        else (ctypes.c_char * len(view)).from_buffer(view)
-    return int(load().ctcasr_crc32c(ctypes.addressof(buf), len(view), int(crc)))
-
-
 def set_option(name, value):
     _check(load().ctcasr_set_option(name.encode(), int(value)), 'set_option')
 
 
+@_on_tensor_device
 def log_softmax_fwd(x, out=None):
     rows, classes = x.numel() // x.shape[-1], x.shape[-1]
     out = torch.empty_like(x) if out is None else out
@@ -177,6 +187,7 @@ def log_softmax_fwd(x, out=None):
     return out
 
 
+@_on_tensor_device
 def log_softmax_bwd(y, dy, out=None):
     rows, classes = y.numel() // y.shape[-1], y.shape[-1]
     out = torch.empty_like(y) if out is None else out
@@ -190,6 +201,7 @@ def ctc_loss_workspace_bytes(num_steps, batch, classes, max_label_len):
     return load().ctcasr_ctc_loss_workspace_bytes(num_steps, batch, classes, max_label_len)
 
 
+@_on_tensor_device
 def ctc_loss_fwd_bwd(logits, labels, label_offsets, seq_len, max_label_len, blank=None,
                      grad_scale=1.0, loss=None, grad=None, status=None, workspace=None):
     """logits f32[T,B,C]; labels/label_offsets/seq_len int32 device tensors.
@@ -214,6 +226,7 @@ def ctc_loss_fwd_bwd(logits, labels, label_offsets, seq_len, max_label_len, blan
     return loss, grad, status
 
 
+@_on_tensor_device
 def ctc_greedy_decode(logits, seq_len, blank=None, out=None, out_len=None):
     num_steps, batch, classes = logits.shape
     blank = classes - 1 if blank is None else blank
@@ -227,6 +240,7 @@ def ctc_greedy_decode(logits, seq_len, blank=None, out=None, out_len=None):
     return out, out_len
 
 
+@_on_tensor_device
 def ctc_beam_decode(logits, seq_len, beam_width, blank=None, normalization='max'):
     num_steps, batch, classes = logits.shape
     blank = classes - 1 if blank is None else blank
@@ -268,8 +282,10 @@ def rnn_persistent_supported(cell, num_steps, batch, hidden):
     return bool(load().ctcasr_rnn_persistent_supported(CELL_IDS[cell], num_steps, batch, hidden))
 
 
+@_on_tensor_device
 def rnn_poll_error(cell, workspace, num_steps, batch, hidden):
-    """Synchronise and raise if the last persistent recurrence launch timed out at a barrier."""
+    """Synchronise and raise if any persistent recurrence launch on ``workspace`` since the last
+    poll timed out at a grid barrier (sticky word; cleared by this call)."""
     _check(load().ctcasr_rnn_poll_error(_dev(workspace, torch.uint8, 'workspace'),
                                         workspace.numel(), CELL_IDS[cell], num_steps, batch,
                                         hidden, _stream()), 'rnn persistent kernel')
@@ -283,13 +299,23 @@ def rnn_gru_drec(reserve, num_steps, batch, hidden):
                                                                       3 * hidden)
 
 
+@_on_tensor_device
+def rnn_workspace(cell, num_steps, batch, hidden, device):
+    """A zero-filled workspace for `rnn_fwd` / `rnn_bwd` (the sticky time-out word of the
+    persistent kernels must start at zero; launches never clear it, `rnn_poll_error` does)."""
+    return torch.zeros(max(int(rnn_workspace_bytes(cell, num_steps, batch, hidden)), 256),
+                       dtype=torch.uint8, device=device)
+
+
+@_on_tensor_device
 def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None,
-            steps=None):
+            steps=None, flags=RNN_DEFAULT):
     """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace).
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_fwd_steps`): cut
     a pass into calls covering 0..T in ascending order, passing the same ``y``, ``reserve`` and
-    ``workspace`` to each."""
+    ``workspace`` to each.  ``flags``: RNN_DEFAULT / RNN_HALF_CHIP / RNN_WHOLE_CHIP (which
+    variant of the persistent kernel runs - a per-call choice, no process-wide state)."""
     num_steps, batch = xw.shape[0], xw.shape[1]
     hidden = w_hh.shape[2]
     dev = xw.device
@@ -302,18 +328,19 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
     if reserve is None:
         reserve = _workspace(rnn_reserve_bytes(cell, num_steps, batch, hidden), dev)
     if workspace is None:
-        workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
+        workspace = rnn_workspace(cell, num_steps, batch, hidden, dev)
     with _Timed('rnn_fwd'):
       _check(load().ctcasr_rnn_fwd_steps(
         CELL_IDS[cell], _dev(xw, name='xw'), _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
         _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
         _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
-        workspace.numel(), int(begin), int(end), _stream()), 'rnn_fwd')
+        workspace.numel(), int(begin), int(end), int(flags), _stream()), 'rnn_fwd')
     return y, reserve, workspace
 
 
+@_on_tensor_device
 def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, db_hh_n=None,
-            workspace=None, steps=None):
+            workspace=None, steps=None, flags=RNN_DEFAULT):
     """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H].
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_bwd_steps`): cut
@@ -330,17 +357,18 @@ def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, d
     dxw = torch.empty((num_steps, batch, 2, gates * hidden), dtype=torch.float32, device=dev) \
         if dxw is None else dxw
     if workspace is None:
-        workspace = _workspace(rnn_workspace_bytes(cell, num_steps, batch, hidden), dev)
+        workspace = rnn_workspace(cell, num_steps, batch, hidden, dev)
     with _Timed('rnn_bwd'):
       _check(load().ctcasr_rnn_bwd_steps(
         CELL_IDS[cell], _dev(dy, name='dy'), _dev(y, name='y'), _dev(w_hh_t, name='w_hh_t'),
         _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
         hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),
         _dev(db_hh_n, name='db_hh_n'), _dev(workspace, torch.uint8, 'workspace'),
-        workspace.numel(), int(begin), int(end), _stream()), 'rnn_bwd')
+        workspace.numel(), int(begin), int(end), int(flags), _stream()), 'rnn_bwd')
     return dxw
 
 
+@_on_tensor_device
 def bias_act_fwd(y, bias, cutoff, dropout_rate=0.0, seed=0):
     """In place: y = dropout(min(max(y + bias, 0), cutoff)); cutoff <= 0 -> bias add only."""
     cols = y.shape[-1]
@@ -350,6 +378,7 @@ def bias_act_fwd(y, bias, cutoff, dropout_rate=0.0, seed=0):
     return y
 
 
+@_on_tensor_device
 def bias_act_bwd(y, dy, cutoff, dropout_rate=0.0, dbias=None, dz=None):
     cols = y.shape[-1]
     dz = torch.empty_like(dy) if dz is None else dz
@@ -360,6 +389,7 @@ def bias_act_bwd(y, dy, cutoff, dropout_rate=0.0, dbias=None, dz=None):
     return dz
 
 
+@_on_tensor_device
 def dropout(src, rate, seed, out=None):
     """out = src * mask(seed) / (1 - rate); same call (same seed) back-propagates a gradient."""
     out = torch.empty_like(src) if out is None else out
@@ -369,6 +399,7 @@ def dropout(src, rate, seed, out=None):
     return out
 
 
+@_on_tensor_device
 def colsum_accumulate(dz, dbias):
     cols = dz.shape[-1]
     _check(load().ctcasr_colsum_accumulate(_dev(dz, name='dz'), _dev(dbias, name='dbias'),
@@ -386,6 +417,7 @@ def conv_s12_packed_floats(cout):
     return 2 * 11 * 21 * 32 * cout
 
 
+@_on_tensor_device
 def conv_s12_pack_weights(weight, packed=None):
     """Fragment-ordered copies (backward, forward) of w f32[cout,32,11,21] ([Cout,Cin,kt,kf])."""
     cout = weight.shape[0]
@@ -399,6 +431,7 @@ def conv_s12_pack_weights(weight, packed=None):
     return packed
 
 
+@_on_tensor_device
 def conv_s12_fwd(x, packed, cout, bias=None, out=None):
     """x f32[B,T,F,32] (NHWC) -> conv(x) + bias, f32[B,T,F/2,cout]; 11x21 taps, stride (1,2),
     TensorFlow SAME padding.  ``packed`` from `conv_s12_pack_weights`."""
@@ -415,6 +448,7 @@ def conv_s12_fwd(x, packed, cout, bias=None, out=None):
     return out
 
 
+@_on_tensor_device
 def conv_s12_bwd_data(dz, packed, out=None):
     """dz f32[B,T,F/2,cout] (NHWC) -> dx f32[B,T,F,32] of the same layer."""
     batch, frames, freq_out, cout = dz.shape
@@ -429,6 +463,7 @@ def conv_s12_bwd_data(dz, packed, out=None):
     return out
 
 
+@_on_tensor_device
 def conv0_fwd(x, weight, bias=None, out=None):
     """First DS2 convolution: x f32[B,T,80] -> f32[B,ceil(T/2),40,32] (NHWC); weight
     f32[32,1,11,41], stride (2,2), TensorFlow SAME padding."""
@@ -444,6 +479,7 @@ def conv0_fwd(x, weight, bias=None, out=None):
     return out
 
 
+@_on_tensor_device
 def conv0_wrw(dz, x, out=None):
     """Kernel gradient of the first DS2 convolution: dz f32[B,ceil(T/2),40,32] (NHWC),
     x f32[B,T,80] -> dw f32[32,1,11,41]."""
@@ -461,11 +497,13 @@ def conv0_wrw(dz, x, out=None):
     return out
 
 
+@_on_tensor_device
 def stream_delay(microseconds):
     """Idle the current stream for ``microseconds`` (a one-lane spacer kernel)."""
     _check(load().ctcasr_stream_delay(int(microseconds), _stream()), 'stream_delay')
 
 
+@_on_tensor_device
 def transpose_batched(src, out=None):
     """src f32[N, R, C] -> out f32[N, C, R]."""
     batch, rows, cols = src.shape
@@ -476,6 +514,7 @@ def transpose_batched(src, out=None):
     return out
 
 
+@_on_tensor_device
 def adam_step(param, grad, m, v, step, lr=1e-5, beta1=0.9, beta2=0.999, epsilon=1e-8,
               grad_scale=1.0):
     _check(load().ctcasr_adam_step(_dev(param, name='param'), _dev(grad, name='grad'),
@@ -491,6 +530,7 @@ def features_num_frames(num_samples):
     return load().ctcasr_features_num_frames(int(num_samples))
 
 
+@_on_tensor_device
 def features(pcm, num_samples, feature_type='mel', normalization='local',
              drop_every_second_frame=False, sampling_rate=16000, out=None, out_len=None):
     """pcm int16[B, N] (device), num_samples int32[B] (device) -> (f32[B, T, 80], i32[B])."""

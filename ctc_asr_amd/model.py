@@ -188,6 +188,39 @@ def to_oracle_layout(flat_params, cfg):
     return out
 
 
+def xw_pipeline_plan(t_out, chunks):
+    """Schedule of the pipelined input projection (`CTCModel._rnn_fwd_pipelined`).
+
+    The forward recurrence of a layer runs as ``chunks`` launches over the step ranges
+    [bounds[c], bounds[c+1]); after launch c the forward direction's y is final for the TIMES
+    [lo, hi) and the backward direction's for [T'-hi, T'-lo), and each contributes its half-K
+    product to those rows of the next layer's xw.  Returns (bounds, plan): plan[c] is a list of
+    (direction, t_begin, t_end, first) GEMMs, ``first`` = the rows are written with the bias
+    (no read) instead of accumulated into.  Every time index is initialised exactly once and
+    before anything is accumulated into it, for any T' and chunk count (the cuts are symmetric,
+    so for even T' the two directions' ranges coincide and nothing is split)."""
+    bounds = [t_out * c // chunks for c in range(chunks + 1)]
+    for c in range(chunks + 1):
+        if c > chunks - c:
+            bounds[c] = t_out - bounds[chunks - c]
+    started = np.zeros(t_out, dtype=bool)
+    plan = []
+    for c in range(chunks):
+        lo, hi = bounds[c], bounds[c + 1]
+        ops = []
+        for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
+            run = a
+            while run < b:
+                end = run + 1
+                while end < b and started[end] == started[run]:
+                    end += 1
+                ops.append((d, run, end, not started[run]))
+                started[run:end] = True
+                run = end
+        plan.append(ops)
+    return bounds, plan
+
+
 class ParamArena:
     """Flat fp32 arenas in HBM for parameters, gradients and the two Adam moments.
 
@@ -311,6 +344,10 @@ class CTCModel:
         # pipelined with it on the other half of the chip (1 = off: whole-chip single launch)
         self.fwd_chunks = max(1, int(os.environ.get('CTCASR_FWD_CHUNKS', '4')))
         self._side_stream = None
+        # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
+        # other half of the chip runs the weight-gradient GEMMs of the layer above
+        self.rnn_bwd_flags = hip.RNN_DEFAULT
+        self._rnn_ws = {}               # (cell, B, H) -> (zero-initialised workspace, T')
         self.dropout_seed = int(seed) * 0x9E3779B1 + 1
         self._acts = None
         self._w_hh_t = [torch.empty((2, cfg.num_units_rnn, GATES[cfg.cell] * cfg.num_units_rnn),
@@ -345,19 +382,21 @@ class CTCModel:
             # logical NCHW [B, 1, T, F], physically NHWC (channels_last) like the reference: the
             # implicit-GEMM convolution kernels are NHWC-native, no transposes around them
             x = sequences.unsqueeze(1).contiguous(memory_format=torch.channels_last)
-            conv_in, conv_out, pads = [], [], []
+            conv_in, conv_out, pads, own_kind = [], [], [], []
             for i in range(len(cfg.conv_filters)):
                 k_t, k_f = CONV_KERNEL_SIZES[i]
                 s_t, s_f = CONV_STRIDES[i]
                 _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
-                if self._own_conv0_layer(i, x.shape[3]):
+                own_kind.append('conv0' if self._own_conv0_layer(i, x.shape[3]) else
+                                's12' if self._own_conv_layer(i, x.shape[3]) else None)
+                if own_kind[i] == 'conv0':
                     # first layer: straight from the [B, T, 80] features, no padded copy
                     y = hip.conv0_fwd(sequences, p['conv0/kernel'],
                                       p['conv0/bias']).permute(0, 3, 1, 2)
                     conv_in.append(None)
                     acts['features'] = sequences
-                elif self._own_conv_layer(i, x.shape[3]):
+                elif own_kind[i] == 's12':
                     # weights change every step: re-pack (2 x 946 KB), then one launch
                     kernel = p['conv{}/kernel'.format(i)]
                     self._conv_packed[i] = hip.conv_s12_pack_weights(kernel,
@@ -386,7 +425,8 @@ class CTCModel:
             t_out = x.shape[2]
             # [B, C, T', F'] -> time-major [T', B, F'*C] (freq-major, channel-minor like NHWC)
             rnn_in = x.permute(2, 0, 3, 1).reshape(t_out, batch, -1)
-            acts.update(conv_in=conv_in, conv_out=conv_out, pads=pads)
+            # (which layers ran on the own kernels is decided HERE, once: backward reads it back)
+            acts.update(conv_in=conv_in, conv_out=conv_out, pads=pads, conv_own=own_kind)
             seq_length = torch.full((batch,), t_out, dtype=torch.int32, device=self.device)
         else:
             t_out = frames
@@ -405,7 +445,7 @@ class CTCModel:
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
         pipelined_xw = None
         x = rnn_in.contiguous()
-        workspace = None
+        workspace = self._rnn_workspace(cell, t_out, batch, hidden)
         rnn_rate = cfg.rnn_dropout_rate if training else 0.0
         for i in range(cfg.num_layers_rnn):
             # dropout placement: cuDNN drops the input of layers 2..L (asr/model.py:203); the
@@ -453,6 +493,28 @@ class CTCModel:
         self._acts = acts
         return logits.view(t_out, batch, cfg.num_classes), seq_length
 
+    def _rnn_workspace(self, cell, t_out, batch, hidden):
+        """The recurrence workspace shared by every layer and pass of this model: zero-filled
+        when created (the persistent kernels' time-out word is sticky - a launch never clears
+        it, `check_rnn_error` reads and clears it), kept across steps and re-created only when
+        the batch changes or a longer sequence needs a bigger exchange buffer."""
+        need = hip.rnn_workspace_bytes(cell, t_out, batch, hidden)
+        key = (cell, batch, hidden)
+        have = self._rnn_ws.get(key)
+        if have is None or have[0].numel() < need:
+            if have is not None:        # do not lose a time-out recorded in the old buffer
+                hip.rnn_poll_error(cell, have[0], have[1], batch, hidden)
+            have = (hip.rnn_workspace(cell, t_out, batch, hidden, self.device), t_out)
+            self._rnn_ws[key] = have
+        return have[0]
+
+    def check_rnn_error(self):
+        """Raise `hip.CtcAsrError` (CTCASR_ERR_TIMEOUT) if a persistent recurrence kernel of
+        any layer, pass or step since the last check gave up at a grid barrier: its output -
+        and every gradient computed from it - is invalid.  Synchronises the stream."""
+        for (cell, batch, hidden), (workspace, t_out) in self._rnn_ws.items():
+            hip.rnn_poll_error(cell, workspace, t_out, batch, hidden)
+
     def _pipeline_forward(self, layer, cell, t_out, batch, hidden, rnn_len, rnn_rate):
         """Whether layer ``layer``'s forward recurrence runs on half of the chip in step ranges
         with the NEXT layer's input projection on the other half: pays when that projection is a
@@ -478,49 +540,38 @@ class CTCModel:
         gh = gates * hidden
         y = torch.empty((t_out, batch, 2 * hidden), dtype=torch.float32, device=dev)
         reserve = hip._workspace(hip.rnn_reserve_bytes(cell, t_out, batch, hidden), dev)
-        if workspace is None:
-            workspace = hip._workspace(hip.rnn_workspace_bytes(cell, t_out, batch, hidden), dev)
         xw_next = torch.empty((t_out * batch, 2 * gh), dtype=torch.float32, device=dev)
         w_next = p[nxt + '/w_ih'].view(2 * gh, 2 * hidden)
         bias_next = self._rnn_bias(layer + 1)
-        started = set()            # time ranges of xw_next that already hold bias + one half
+        w_halves = [w_next[:, d * hidden:(d + 1) * hidden].t() for d in (0, 1)]
+        bounds, plan = xw_pipeline_plan(t_out, self.fwd_chunks)
 
-        def contribute(lo, hi):
-            for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
-                rows = xw_next[a * batch:b * batch]
-                src = y[a:b, :, d * hidden:(d + 1) * hidden].reshape((b - a) * batch, hidden)
-                w_half = w_next[:, d * hidden:(d + 1) * hidden].t()
-                if (a, b) in started:
-                    rows.addmm_(src, w_half)
+        def contribute(chunk):
+            for d, run, end, first in plan[chunk]:
+                rows = xw_next[run * batch:end * batch]
+                src = y[run:end, :, d * hidden:(d + 1) * hidden] \
+                    .reshape((end - run) * batch, hidden)
+                if first:
+                    torch.addmm(bias_next, src, w_halves[d], out=rows)
                 else:
-                    torch.addmm(bias_next, src, w_half, out=rows)
-                    started.add((a, b))
+                    rows.addmm_(src, w_halves[d])
 
         chunks = self.fwd_chunks
-        # symmetric cuts (bounds[c] + bounds[chunks - c] == T'): the backward direction's time
-        # ranges then coincide with the forward direction's
-        bounds = [t_out * c // chunks for c in range(chunks + 1)]
-        for c in range(chunks + 1):
-            if c > chunks - c:
-                bounds[c] = t_out - bounds[chunks - c]
-        hip.set_option('rnn_fwd_half_chip', 1)
-        try:
-            for c in range(chunks):
-                lo, hi = bounds[c], bounds[c + 1]
-                hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
-                            reserve=reserve, workspace=workspace, steps=(lo, hi))
-                if c + 1 < chunks:
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
-                        hip.stream_delay(self.side_head_start_us)
-                        contribute(lo, hi)
-                else:
-                    main.wait_stream(side)
-                    contribute(lo, hi)
-        finally:
-            hip.set_option('rnn_fwd_half_chip', 0)
+        for c in range(chunks):
+            lo, hi = bounds[c], bounds[c + 1]
+            hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
+                        reserve=reserve, workspace=workspace, steps=(lo, hi),
+                        flags=hip.RNN_HALF_CHIP)
+            if c + 1 < chunks:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    hip.stream_delay(self.side_head_start_us)
+                    contribute(c)
+            else:
+                main.wait_stream(side)
+                contribute(c)
         for tensor in (y, xw_next):
             tensor.record_stream(side)
         return y, reserve, workspace, xw_next
@@ -822,7 +873,8 @@ class CTCModel:
             bounds = [t_out * (chunks - c) // chunks for c in range(chunks + 1)]   # T ... 0
             for c in range(chunks):
                 hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
-                            dxw=dxw, workspace=acts['rnn_ws'], steps=(bounds[c + 1], bounds[c]))
+                            dxw=dxw, workspace=acts['rnn_ws'], steps=(bounds[c + 1], bounds[c]),
+                            flags=self.rnn_bwd_flags)
                 if c + 1 < chunks:
                     on_side([dxw], lambda lo=bounds[c + 1], hi=bounds[c]:
                             partial_weight_grads(lo, hi), head_start_us=self.side_head_start_us)
@@ -873,6 +925,8 @@ class CTCModel:
         with torch.cuda.stream(side):
             for name in deferred:
                 done(name)
+            if hasattr(reduce_hook, 'flush'):
+                reduce_hook.flush()     # pending slices were produced on THIS stream
 
         # front-end
         if cfg.used_model == 'ds2':
@@ -892,13 +946,13 @@ class CTCModel:
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 # the 11x21 / stride (1,2) / 32->32 layer has its own data-gradient kernel
                 # (implicit GEMM, any T, no padded intermediates: 0.62 ms vs 1.6 ms at C2)
-                if self._own_conv0_layer(i, 2 * dz.shape[3]):
+                if acts['conv_own'][i] == 'conv0':
                     # first layer: kernel gradient straight from the features, no padded copy
                     hip.conv0_wrw(dz.permute(0, 2, 3, 1), acts['features'],
                                   out=g[name + '/kernel'])
                     done(name)
                     continue
-                own = self._own_conv_layer(i, 2 * dz.shape[3])
+                own = acts['conv_own'][i] == 's12'
                 own_dx = i > 0 and own
                 need_dx = i > 0 and not own_dx
                 conv_in = acts['conv_in'][i]
@@ -965,6 +1019,7 @@ class CTCModel:
         logits, seq_length = self.inference_fn(features['spectrogram'],
                                                features['spectrogram_length'],
                                                training=(mode == 'train'))
+        self.check_rnn_error()
         if mode == 'infer':
             decoded, plaintext, _ = self.decode_fn(logits, seq_length, None)
             return {'decoded': decoded, 'plaintext': plaintext}

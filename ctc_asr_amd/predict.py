@@ -16,6 +16,7 @@ from ctc_asr_amd.params import FLAGS
 def predict(model, wav_path):
     feats, lengths = features_from_pcm([read_wav(wav_path)], model.device)
     logits, seq_len = model.inference_fn(feats, lengths, training=False)
+    model.check_rnn_error()
     decoded, plaintext, _ = model.decode_fn(logits, seq_len, None)
     return {'decoded': np.array(decoded[0], dtype=np.int32), 'plaintext': plaintext[0]}
 

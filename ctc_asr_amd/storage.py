@@ -91,9 +91,12 @@ def import_tf_checkpoint(path, arena, cfg):
     if prefix is None or not os.path.isfile(prefix + '.index'):
         raise ValueError('No TensorFlow checkpoint at {}'.format(path))
     present = tf_bundle.list_bundle(prefix)
-    wanted = [n for n in present if '/Adam' not in n and not n.startswith('beta')]
+    tf_names.check_names(present, cfg)      # ValueError naming missing / unexpected variables
+    wanted = [n for n in present if n == 'global_step' or n in set(tf_names.expected_names(cfg))]
     variables = tf_bundle.read_bundle(prefix, wanted)
+    step = variables.pop('global_step', None)
     arena.load(tf_names.from_tf_variables(variables, cfg))
+    variables['global_step'] = 0 if step is None else step
     arena.m.zero_()
     arena.v.zero_()
-    return int(variables['global_step']) if 'global_step' in variables else 0
+    return int(variables['global_step'])

@@ -24,7 +24,7 @@ import struct
 
 import numpy as np
 
-from ctc_asr_amd import hip
+from ctc_asr_amd import hostlib
 
 TABLE_MAGIC = 0xdb4775248b80fb57
 BLOCK_SIZE = 4096
@@ -38,7 +38,7 @@ _DTYPE_IDS = {np.dtype(v): k for k, v in _DTYPES.items()}
 
 
 def masked_crc32c(data):
-    crc = hip.crc32c(data)
+    crc = hostlib.crc32c(data)
     return (((crc >> 15) | (crc << 17)) + CRC_MASK_DELTA) & 0xFFFFFFFF
 
 

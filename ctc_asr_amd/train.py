@@ -80,11 +80,17 @@ def main(argv=None):
             print('Restored {} (step {:,d}); continuing with epoch {}.'.format(
                 latest, model.step_count, start_epoch))
     elif tf_bundle.latest_checkpoint(FLAGS.train_dir) is not None:
-        # a train_dir written by the reference (tf.estimator): take its variables over
-        model.step_count = storage.import_tf_checkpoint(FLAGS.train_dir, model.arena, cfg)
-        if rank == 0:
-            print('Imported TensorFlow checkpoint {} (global_step {:,d}).'.format(
-                tf_bundle.latest_checkpoint(FLAGS.train_dir), model.step_count))
+        # a train_dir written by the reference (tf.estimator).  Taking its variables over is
+        # opt-in: the variable-name mapping (tf_names.py) has never seen a file TensorFlow wrote.
+        if os.environ.get('CTCASR_IMPORT_TF_CHECKPOINT') == '1':
+            model.step_count = storage.import_tf_checkpoint(FLAGS.train_dir, model.arena, cfg)
+            if rank == 0:
+                print('Imported TensorFlow checkpoint {} (global_step {:,d}).'.format(
+                    tf_bundle.latest_checkpoint(FLAGS.train_dir), model.step_count))
+        elif rank == 0:
+            print('Note: {} holds a TensorFlow checkpoint; set CTCASR_IMPORT_TF_CHECKPOINT=1 to '
+                  'start from its variables.  Starting from a fresh initialisation.'
+                  .format(FLAGS.train_dir))
 
     for epoch in range(start_epoch, FLAGS.max_epochs + 1):
         target = 'train_batch' if epoch == 1 else 'train_bucket'

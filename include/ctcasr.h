@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTCASR_ABI_VERSION 1
+#define CTCASR_ABI_VERSION 2
 
 enum {
     CTCASR_OK = 0,
@@ -49,20 +49,14 @@ enum {
 typedef void *ctcasr_stream_t;
 
 int ctcasr_abi_version(void);
-/* Process-wide switches.  "rnn_bwd_half_chip" (0/1, default 1): run the persistent backward
- * recurrence (LSTM H=1024, plain RNN H=2048) on 128 of the 256 CUs (weights split between LDS and
- * registers) so that GEMMs launched on another stream can overlap it; 0 selects the whole-chip
- * variant.  "rnn_fwd_half_chip" (0/1, default 0): the same for the persistent forward LSTM
- * recurrence (64 workgroups per direction; 6.0 instead of 5.0 us per step, 128 CUs free).
+/* Process-wide PROFILING switch (no option changes what a call computes or which kernel variant
+ * it runs - that is the per-call `flags` argument of ctcasr_rnn_fwd_steps / _bwd_steps):
  * "rnn_kernel_events" (0/1, default 0): record a HIP event pair on the launch stream around every
  * persistent recurrence kernel; ctcasr_rnn_kernel_events() waits for them, returns launch counts
  * and summed durations ([0] forward, [1] backward) and clears the record (benchmarking). */
 int ctcasr_set_option(const char *name, int value);
 int ctcasr_rnn_kernel_events(int launches[2], double total_ms[2]);
 const char *ctcasr_error_string(int code);
-/* CRC-32C (Castagnoli) of a HOST buffer, chained through `crc` (0 to start): the checksum of
- * TensorFlow's tensor-bundle checkpoint files (ctc_asr_amd/tf_bundle.py). */
-uint32_t ctcasr_crc32c(const void *data, size_t size, uint32_t crc);
 
 /* ---- K8: (log-)softmax over the class axis ------------------------------------------------
  * Replaces the softmax inside tf.nn.ctc_loss / ctc_beam_search_decoder (asr/model.py:259,292).
@@ -124,7 +118,9 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
  *            t >= seq_len[b] emit zeros and keep the state; backward direction reversed per row).
  *   y        [T, B, 2H]  = [h_fw || h_bw]
  *   reserve  activations kept for the backward pass, ctcasr_rnn_reserve_bytes()
- *   workspace ctcasr_rnn_workspace_bytes() (state ping-pong, grid-barrier words)
+ *   workspace ctcasr_rnn_workspace_bytes() (state ping-pong, grid-barrier words, exchange
+ *            buffer).  ZERO-FILL IT ONCE before its first use: it holds the sticky time-out word
+ *            that ctcasr_rnn_poll_error reads; launches never clear that word.
  * bwd: dy [T,B,2H] -> dxw [T,B,2,G*H] (gradient w.r.t. xw, which is also what the weight
  * gradients are GEMMs of), w_hh_t = w_hh transposed to [2, H, G*H] (caller keeps it current;
  * ctcasr_transpose_batched does it).  GRU: the recurrent path differs from dxw in the candidate
@@ -140,17 +136,30 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_
  * be cut into launches covering 0..T in ascending order on the same workspace and reserve: after
  * a launch, y of the steps it covered is final (time s of the forward direction, time
  * seq_len-1-s of the backward direction), so the next layer's input projection of those steps
- * can run on another stream while the next launch continues the recurrence. */
+ * can run on another stream while the next launch continues the recurrence.
+ *
+ * `flags` (CTCASR_RNN_*) picks the variant of the persistent kernel for THIS call - there is no
+ * process-wide state, so calls from different threads / streams do not interact:
+ *   CTCASR_RNN_DEFAULT     forward: all 256 CUs; backward: 128 CUs
+ *   CTCASR_RNN_HALF_CHIP   128 CUs (64 workgroups per direction, weights split between LDS and
+ *                          registers), so that GEMMs on another stream can run beside it
+ *   CTCASR_RNN_WHOLE_CHIP  all 256 CUs
+ * Shapes without the requested variant, and the streaming kernels, ignore it. */
+#define CTCASR_RNN_DEFAULT 0
+#define CTCASR_RNN_HALF_CHIP 1
+#define CTCASR_RNN_WHOLE_CHIP 2
 int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
                          const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
                          void *workspace, size_t workspace_bytes, int step_begin, int step_end,
-                         ctcasr_stream_t stream);
+                         int flags, ctcasr_stream_t stream);
 /* 1 when the LDS-resident single-launch kernels cover (cell, T, B, H) on this device, else the
  * per-step streaming kernels run.  CTCASR_RNN_MODE=stream in the environment forces the latter. */
 int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
-/* Synchronises the stream and returns CTCASR_ERR_TIMEOUT if the last persistent launch that used
- * `workspace` abandoned a grid barrier (its results are then invalid), else CTCASR_OK. */
-int ctcasr_rnn_poll_error(const void *workspace, size_t workspace_bytes, int cell, int T, int B,
+/* Synchronises the stream and returns CTCASR_ERR_TIMEOUT if ANY persistent launch that used
+ * `workspace` since the previous poll abandoned a grid barrier (the results of that pass are then
+ * invalid), else CTCASR_OK.  The time-out word is sticky across launches, layers and passes and
+ * is cleared by this call. */
+int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, int cell, int T, int B,
                           int H, ctcasr_stream_t stream);
 int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                    const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
@@ -165,7 +174,7 @@ int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_
 int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y, const float *w_hh_t,
                          const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                          const void *reserve, float *dxw, float *db_hh_n, void *workspace,
-                         size_t workspace_bytes, int step_begin, int step_end,
+                         size_t workspace_bytes, int step_begin, int step_end, int flags,
                          ctcasr_stream_t stream);
 
 /* ---- fused dense / conv epilogues (tf.layers.dense + ReLU + tf.minimum(., relu_cutoff) +

@@ -17,8 +17,8 @@ def lib():
     return hip.load()
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, 'include', 'ctcasr.h')).read()
+def _declared_functions(header='ctcasr.h'):
+    text = open(os.path.join(ROOT, 'include', header)).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(ctcasr_[a-z0-9_]+)\s*\(', text)))
 
@@ -30,10 +30,22 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(hip.SIGNATURES) == declared
+    # the device ABI holds device entry points only: host helpers live in their own library
+    assert not any('crc' in name or 'host' in name for name in declared)
+
+
+def test_host_helper_library_exports_its_header(lib):
+    from ctc_asr_amd import hostlib
+    declared = _declared_functions('ctcasr_host.h')
+    host = hostlib.load()
+    for name in declared:
+        assert hasattr(host, name), name
+    assert sorted(hostlib.SIGNATURES) == declared
+    assert hostlib.crc32c(b'123456789') == 0xE3069283
 
 
 def test_version_and_error_strings(lib):
-    assert lib.ctcasr_abi_version() == 1
+    assert lib.ctcasr_abi_version() == 2
     assert lib.ctcasr_error_string(0) == b'ok'
     assert b'workspace' in lib.ctcasr_error_string(-3)
     assert lib.ctcasr_error_string(-5) == b'in-kernel wait timed out'
@@ -44,6 +56,12 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.ctcasr_ctc_loss_fwd_bwd(None, None, None, None, 5, 2, 29, 28, 3, 1.0, None, None,
                                        None, None, 0, None) == -1
     assert lib.ctcasr_rnn_fwd(2, None, None, None, None, 0, 2, 64, None, None, None, 0, None) == -1
+    # unknown flag bits of the step-range entry points are an argument error
+    assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, 8, 2, 64, None, None, None, 0, 0, 8,
+                                    64, None) == -1
+    # the only process-wide option is the profiling switch
+    assert lib.ctcasr_set_option(b'rnn_fwd_half_chip', 1) == -1
+    assert lib.ctcasr_set_option(b'rnn_kernel_events', 0) == 0
     assert lib.ctcasr_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0,
                                 None) == -1
     # workspace sizing is pure host arithmetic

@@ -1,0 +1,49 @@
+"""bench.py's launcher logic on a GPU-less host: `--gpus N` must never silently run a smaller
+job (round-1 finding: it ran dp1 and labelled nothing)."""
+
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    full_env = {k: v for k, v in os.environ.items()
+                if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE')}
+    full_env.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args,
+                          capture_output=True, text=True, env=full_env, timeout=300)
+
+
+def test_more_gpus_than_visible_is_refused_with_a_clear_message():
+    import torch
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    out = _run(['--gpus', str(visible + 1 if visible else 2), '--steps', '1', '--warmup', '0'])
+    assert out.returncode != 0
+    assert 'GPU(s) visible' in out.stderr
+    assert out.stdout.strip() == ''          # no JSON line that could be mistaken for a result
+
+
+def test_world_size_mismatch_is_refused():
+    out = _run(['--gpus', '4'], env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert out.returncode != 0
+    assert 'does not match WORLD_SIZE' in (out.stderr + out.stdout)
+
+
+def test_pmc_traffic_lookup_reports_the_reason_when_absent(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, 'PMC_TRAFFIC_JSON', str(tmp_path / 'none.json'))
+    got = bench.pmc_traffic('c3', 'rnn_bwd', 167)
+    assert got['traffic'] is None and 'pmc_traffic.json' in got['traffic_note']
+    path = tmp_path / 'pmc.json'
+    path.write_text(json.dumps({'entries': [
+        {'workload': 'c3', 'pass': 'rnn_bwd', 'steps_per_launch': 167, 'fetch_kb': 1000.0,
+         'write_kb': 500.0, 'algorithmic_bytes': 1024000, 'source': 'x.md'}]}))
+    monkeypatch.setattr(bench, 'PMC_TRAFFIC_JSON', str(path))
+    got = bench.pmc_traffic('c3', 'rnn_bwd', 167)
+    assert got['traffic_raw'] == 1500 * 1024 and got['traffic'] == 2500 * 1024
+    assert got['traffic_over_algorithmic'] == 2.5
+    assert bench.pmc_traffic('c3', 'rnn_bwd', 500)['traffic'] is None

@@ -105,11 +105,10 @@ def test_greedy_decode(hip, shape):
                                   (5, 35, 1024),   # B > 32 -> streaming at H=1024
                                   (8, 16, 2048), (5, 21, 2048)])
 def test_rnn_fwd_bwd(hip, cell, use_len, dims):
+    # every cell at every shape: the shapes a cell has no persistent kernel for (gru / relu / tanh
+    # at H=1024, lstm / gru at H=2048, B > 32) are exactly where the streaming kernels are the
+    # only path
     num_steps, batch, hidden = dims
-    if hidden == 1024 and cell != 'lstm':
-        pytest.skip('H=1024 cases exercise the persistent LSTM kernels')
-    if hidden == 2048 and cell not in ('rnn_relu', 'rnn_tanh'):
-        pytest.skip('H=2048 cases exercise the persistent plain-RNN kernels')
     gates = onn.GATES[cell]
     rng = np.random.default_rng(5)
     xw = (rng.normal(size=(num_steps, batch, 2, gates * hidden)) * 0.5).astype(np.float32)
@@ -180,12 +179,8 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
         with pytest.raises(ValueError):
             hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl, steps=(0, 2))
     if cell == 'lstm' and hidden == 1024 and batch <= 16:
-        hip.set_option('rnn_fwd_half_chip', 1)
-        try:
-            y_half, _, ws_half = hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl)
-            hip.rnn_poll_error(cell, ws_half, num_steps, batch, hidden)
-        finally:
-            hip.set_option('rnn_fwd_half_chip', 0)
+        y_half, _, ws_half = hip.rnn_fwd(cell, _t(xw), _t(w_hh), sl, flags=hip.RNN_HALF_CHIP)
+        hip.rnn_poll_error(cell, ws_half, num_steps, batch, hidden)
         assert np.abs((y_half - y).cpu().numpy()).max() < 1e-6
     w_hh_t = hip.transpose_batched(_t(w_hh))
     assert torch.equal(w_hh_t.cpu(), torch.tensor(w_hh).transpose(1, 2).contiguous())
@@ -212,6 +207,59 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
         yd = ys.detach()
         dw0 = drec[1:, :, 0].reshape(-1, 3 * hidden).t() @ yd[:-1, :, :hidden].reshape(-1, hidden)
         assert np.abs(dw0.numpy() - w_t.grad[0].numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize('cell,dims', [('lstm', (12, 16, 1024)), ('lstm', (9, 32, 1024)),
+                                       ('rnn_relu', (8, 16, 2048))])
+def test_streaming_kernels_on_persistent_shapes(hip, cell, dims, monkeypatch):
+    """CTCASR_RNN_MODE=stream forces the per-step kernels for shapes the persistent kernels
+    cover: both paths must agree (y to 1e-5, dxw to 1e-4), with and without the whole-chip /
+    half-chip flags of the persistent backward pass."""
+    num_steps, batch, hidden = dims
+    gates = onn.GATES[cell]
+    rng = np.random.default_rng(17)
+    xw = _t((rng.normal(size=(num_steps, batch, 2, gates * hidden)) * 0.5).astype(np.float32))
+    w_hh = _t((rng.normal(size=(2, gates * hidden, hidden)) / np.sqrt(hidden))
+              .astype(np.float32))
+    dy = _t(rng.normal(size=(num_steps, batch, 2 * hidden)).astype(np.float32))
+    w_hh_t = hip.transpose_batched(w_hh)
+    assert hip.rnn_persistent_supported(cell, num_steps, batch, hidden)
+    y_p, reserve_p, ws_p = hip.rnn_fwd(cell, xw, w_hh)
+    dxw_p = hip.rnn_bwd(cell, dy, y_p, w_hh_t, reserve_p, workspace=ws_p)
+    dxw_w = hip.rnn_bwd(cell, dy, y_p, w_hh_t, reserve_p, workspace=ws_p,
+                        flags=hip.RNN_WHOLE_CHIP)
+    hip.rnn_poll_error(cell, ws_p, num_steps, batch, hidden)
+    monkeypatch.setenv('CTCASR_RNN_MODE', 'stream')
+    assert not hip.rnn_persistent_supported(cell, num_steps, batch, hidden)
+    y_s, reserve_s, ws_s = hip.rnn_fwd(cell, xw, w_hh)
+    dxw_s = hip.rnn_bwd(cell, dy, y_s, w_hh_t, reserve_s, workspace=ws_s)
+    torch.cuda.synchronize()
+    monkeypatch.delenv('CTCASR_RNN_MODE')
+    assert float((y_s - y_p).abs().max()) < 1e-5
+    assert float((dxw_s - dxw_p).abs().max()) < 1e-4
+    assert float((dxw_w - dxw_p).abs().max()) < 1e-4
+
+
+def test_rnn_timeout_word_is_sticky_until_polled(hip):
+    """A time-out raised by ANY persistent launch must survive later launches on the same
+    workspace (other layers, the other pass) until `rnn_poll_error` reads it - round-1 finding:
+    every launch used to clear it.  The word is poked by hand here (a real time-out needs a
+    starved GPU): later launches must leave it alone, the poll must raise once and clear it."""
+    num_steps, batch, hidden = 6, 4, 1024
+    rng = np.random.default_rng(23)
+    xw = _t((rng.normal(size=(num_steps, batch, 2, 4 * hidden)) * 0.5).astype(np.float32))
+    w_hh = _t((rng.normal(size=(2, 4 * hidden, hidden)) / 32).astype(np.float32))
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    state = (6 * batch * hidden * 4 + 255) // 256 * 256
+    error_word = state + 2 * 8 * 64 * 4          # SyncWords: group_cnt[2][8][64] then `error`
+    ws[error_word:error_word + 4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device=DEV)
+    hip.rnn_fwd('lstm', xw, w_hh, y=y, reserve=reserve, workspace=ws)            # another "layer"
+    dy = torch.ones_like(y)
+    hip.rnn_bwd('lstm', dy, y, hip.transpose_batched(w_hh), reserve, workspace=ws)  # other pass
+    with pytest.raises(hip.CtcAsrError, match='timed out'):
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)        # cleared by the read
 
 
 def test_bias_act_and_colsum(hip):

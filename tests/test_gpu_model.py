@@ -88,30 +88,36 @@ def test_tiled_convolutions_equal_direct_convolutions(case, frames, tile, per_ca
                                      frames=frames)
 
 
-def test_pipelined_forward_equals_single_launch_forward():
-    """fwd_chunks = 4 (layer 1's forward recurrence on half of the chip in four step ranges, layer
+@pytest.mark.parametrize('frames,pipelined', [(131, 4), (129, 4), (97, 2), (141, 3)])
+def test_pipelined_forward_equals_single_launch_forward(frames, pipelined):
+    """fwd_chunks > 1 (layer 1's forward recurrence on half of the chip in step ranges, layer
     2's input projection accumulated range by range on the side stream) against fwd_chunks = 1
     (whole-chip launch, one GEMM): logits, loss and gradients agree to fp32 rounding, in
-    training and in evaluation mode."""
-    cfg, flat, feats, flen, labels = _setup('ds2_lstm_2conv', hidden=1024, frames=131, batch=2)
+    training and in evaluation mode.  frames = 129 / 97 give an ODD T' (65 / 49): with an even
+    chunk count the two directions' time ranges then do not coincide (round-1 bug: rows were
+    initialised twice, logits off by O(1))."""
+    cfg, flat, feats, flen, labels = _setup('ds2_lstm_2conv', hidden=1024, frames=frames, batch=2)
+    t_out = (frames + 1) // 2
     out = {}
-    for chunks in (1, 4):
+    for chunks in (1, pipelined):
         model = CTCModel(cfg, 'cuda', params=flat)
         model.fwd_chunks = chunks
-        assert model._pipeline_forward(0, 'lstm', 66, 2, 1024, None, 0.0) == (chunks > 1)
+        assert model._pipeline_forward(0, 'lstm', t_out, 2, 1024, None, 0.0) == (chunks > 1)
         logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen),
                                              training=True)
         loss = model.loss_fn(logits, seq_len, labels)
         model.backward()
         eval_logits, _ = model.inference_fn(torch.tensor(feats), torch.tensor(flen),
                                             training=False)
+        model.check_rnn_error()
         out[chunks] = (logits.cpu().numpy(), float(loss), model.arena.export('grad'),
                        eval_logits.cpu().numpy())
-    assert np.abs(out[4][0] - out[1][0]).max() < 1e-5
-    assert abs(out[4][1] - out[1][1]) < 1e-4
-    assert np.abs(out[4][3] - out[1][3]).max() < 1e-5
+    piped = out[pipelined]
+    assert np.abs(piped[0] - out[1][0]).max() < 1e-5
+    assert abs(piped[1] - out[1][1]) < 1e-4
+    assert np.abs(piped[3] - out[1][3]).max() < 1e-5
     for name, ref_g in out[1][2].items():
-        err = np.abs(out[4][2][name] - ref_g).max()
+        err = np.abs(piped[2][name] - ref_g).max()
         assert err < 1e-5 * max(1.0, np.abs(ref_g).max()), (name, err)
 
 
@@ -284,3 +290,66 @@ def test_full_size_c1_shape_with_gradients():
                         ('logits/kernel', ref_g['logits'][0])):
         err = np.abs(got[name] - ref_t.numpy()).max()
         assert err < 1e-3 * max(1.0, np.abs(ref_t.numpy()).max()), (name, err)
+
+
+def _assembled_against_torch_ref(cfg, batch, frames, label_len, seed, grad_names):
+    rng = np.random.default_rng(seed)
+    flat = init_params(cfg, seed)
+    feats = rng.normal(size=(batch, frames, 80)).astype(np.float32)
+    flen = np.full(batch, frames, dtype=np.int32)
+    labels = [list(rng.integers(1, 28, size=label_len)) for _ in range(batch)]
+    model = CTCModel(cfg, 'cuda', params=flat)
+    logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
+    loss = model.loss_fn(logits, seq_len, labels)
+    model.backward()
+    model.check_rnn_error()
+    ref = torch_ref.TorchRefModel(to_oracle_layout(flat, cfg), cfg.used_model, cfg.rnn_cell,
+                                  cfg.cudnn, dtype=torch.float64)
+    t_logits, t_len = ref(torch.tensor(feats, dtype=torch.float64), flen)
+    t_loss, _ = ref.loss(t_logits, t_len, labels)
+    t_loss.backward()
+    t_out = cfg.output_time(frames)
+    assert logits.shape == (t_out, batch, 29) and (seq_len.cpu().numpy() == t_out).all()
+    assert np.abs(logits.cpu().numpy() - t_logits.detach().numpy()).max() < 1e-3
+    assert abs(float(loss) - float(t_loss.detach())) < 1e-3 * max(1.0, abs(float(t_loss)))
+    decoded, _, _ = model.decode_fn(logits, seq_len, None, greedy=True)
+    assert decoded == octc.greedy_decode(t_logits.detach().numpy(), [t_out] * batch)
+    got = model.arena.export('grad')
+    ref_g = ref.grads_in_shared_layout()
+    for name in grad_names:
+        layer, leaf = name.split('/')
+        if layer.startswith('rnn'):
+            want = ref_g['rnn'][int(layer[3:])][leaf]
+        elif layer.startswith('conv'):
+            want = ref_g['conv'][int(layer[4:])][0 if leaf == 'kernel' else 1]
+        else:
+            want = ref_g[layer][0 if leaf == 'kernel' else 1]
+        want = want.numpy()
+        err = np.abs(got[name] - want).max()
+        assert err < 1e-3 * max(1.0, np.abs(want).max()), (name, err)
+    return model
+
+
+def test_assembled_c3_model_batch_32():
+    """BASELINE configs[2] assembled: DS2 2-conv + FIVE BiLSTM-1024 layers at batch 32 (the
+    per-GPU unit of the 8-GPU config) - the batch that takes the two-batch-tile kernels and no
+    forward pipelining - at T' = 100: logits, loss, greedy strings and gradients of the first /
+    middle / last layers against the float64 torch restatement; no recurrence time-out."""
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=5, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0)
+    _assembled_against_torch_ref(
+        cfg, batch=32, frames=199, label_len=30, seed=21,
+        grad_names=('conv0/kernel', 'conv1/kernel', 'rnn0/w_ih', 'rnn0/w_hh', 'rnn2/w_hh',
+                    'rnn4/w_ih', 'rnn4/b_ih', 'dense4/kernel', 'logits/bias'))
+
+
+def test_assembled_reference_default_model():
+    """The reference's own flag defaults (asr/params.py): 3 convolutions (32, 32, 96) + 4 x
+    bidirectional ReLU-RNN-2048 + dense 2048, batch 16, at T' = 40."""
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32, 96), num_units_dense=2048,
+                      num_layers_rnn=4, num_units_rnn=2048, rnn_cell='rnn_relu', cudnn=True,
+                      dense_dropout_rate=0.0)
+    _assembled_against_torch_ref(
+        cfg, batch=16, frames=79, label_len=12, seed=22,
+        grad_names=('conv2/kernel', 'rnn0/w_ih', 'rnn1/w_hh', 'rnn3/w_hh', 'dense4/kernel'))

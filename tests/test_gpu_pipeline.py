@@ -120,3 +120,33 @@ def test_model_fn_modes(corpus):
     assert not torch.equal(before, model.arena.param) and torch.isfinite(tr['loss'])
     with pytest.raises(RuntimeError):
         model.model_fn(features, labels, 'tune')
+
+
+def test_predict_main_transcribes_one_file(corpus, capsys):
+    """`predict.main --input file.wav` (asr/predict.py:44-67): restores the latest checkpoint and
+    prints {'decoded', 'plaintext'}; the transcription equals a beam decode of the same logits
+    through the model API.  Missing file -> ValueError like the reference."""
+    from ctc_asr_amd import predict, train
+    from ctc_asr_amd.labels import decode
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    FLAGS.max_epochs = 1
+    assert train.main([]) == 0
+    capsys.readouterr()
+    rows = input_functions.read_manifest(FLAGS.test_csv)
+    wav = os.path.join(FLAGS.corpus_dir, rows[2]['path'])
+    assert predict.main(['--input', wav]) == 0
+    out = capsys.readouterr().out
+    assert 'Inputs: ' + wav in out and "'plaintext'" in out and "'decoded'" in out
+    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=1)
+    storage.restore_checkpoint(storage.latest_checkpoint(FLAGS.train_dir), model)
+    got = predict.predict(model, wav)
+    assert got['decoded'].dtype == np.int32
+    assert got['plaintext'] == decode(got['decoded'].tolist())
+    assert repr(got['plaintext']) in out
+    feats, lengths = input_functions.features_from_pcm([input_functions.read_wav(wav)],
+                                                       model.device)
+    logits, seq_len = model.inference_fn(feats, lengths, training=False)
+    decoded, _, _ = model.decode_fn(logits, seq_len, None)
+    assert decoded[0] == got['decoded'].tolist()
+    with pytest.raises(ValueError):
+        predict.main(['--input', wav + '.missing'])

@@ -151,3 +151,38 @@ def test_data_parallel_ranks_share_each_group(tmp_path):
                     assert len(keys) == 1
     finally:
         FLAGS.reset()
+
+
+def test_pipelined_input_projection_plan_covers_every_row_once():
+    """`xw_pipeline_plan` (the schedule of `CTCModel._rnn_fwd_pipelined`): replayed in numpy,
+    the per-launch half-K products reproduce y W^T + b for odd and even T' and any chunk count -
+    every row is initialised (bias form) exactly once and before anything is accumulated into
+    it, and only rows whose y is final after that launch are touched.  (Round-1 bug: odd T' with
+    an even chunk count initialised a range twice.)"""
+    from ctc_asr_amd.model import xw_pipeline_plan
+    rng = np.random.default_rng(0)
+    hidden, n_out, batch = 3, 5, 2
+    for t_out in (8, 9, 49, 65, 66, 251, 499, 500, 501):
+        for chunks in (1, 2, 3, 4, 5, 6):
+            y = rng.normal(size=(t_out, batch, 2 * hidden))
+            w = rng.normal(size=(n_out, 2 * hidden))
+            bias = rng.normal(size=n_out)
+            want = (y.reshape(t_out * batch, -1) @ w.T + bias).reshape(t_out, batch, n_out)
+            got = np.full((t_out, batch, n_out), np.nan)
+            bounds, plan = xw_pipeline_plan(t_out, chunks)
+            assert bounds[0] == 0 and bounds[-1] == t_out and len(plan) == chunks
+            assert all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
+            for c, ops in enumerate(plan):
+                hi = bounds[c + 1]
+                for d, a, b, first in ops:
+                    # forward direction: times < hi are final; backward direction: times >= T'-hi
+                    assert (d == 0 and b <= hi) or (d == 1 and a >= t_out - hi)
+                    part = y[a:b, :, d * hidden:(d + 1) * hidden] @ \
+                        w[:, d * hidden:(d + 1) * hidden].T
+                    if first:
+                        assert np.isnan(got[a:b]).all()
+                        got[a:b] = part + bias
+                    else:
+                        assert not np.isnan(got[a:b]).any()
+                        got[a:b] += part
+            assert np.abs(got - want).max() < 1e-12, (t_out, chunks)

@@ -8,20 +8,20 @@ import struct
 import numpy as np
 import pytest
 
-from ctc_asr_amd import hip, storage, tf_bundle
+from ctc_asr_amd import hostlib, storage, tf_bundle
 from ctc_asr_amd.model import ModelConfig, ParamArena, init_params
 
 
 def test_crc32c_known_answers():
     # RFC 3720 B.4 / the LevelDB crc32c test
-    assert hip.crc32c(b'123456789') == 0xE3069283
-    assert hip.crc32c(bytes(32)) == 0x8A9136AA
-    assert hip.crc32c(b'\xff' * 32) == 0x62A8AB43
-    assert hip.crc32c(bytes(range(32))) == 0x46DD794E
-    assert hip.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
-    assert hip.crc32c(b'6789', hip.crc32c(b'12345')) == 0xE3069283     # chaining
-    assert hip.crc32c(np.arange(8, dtype=np.uint8)) == hip.crc32c(bytes(range(8)))
-    crc = hip.crc32c(b'foo')
+    assert hostlib.crc32c(b'123456789') == 0xE3069283
+    assert hostlib.crc32c(bytes(32)) == 0x8A9136AA
+    assert hostlib.crc32c(b'\xff' * 32) == 0x62A8AB43
+    assert hostlib.crc32c(bytes(range(32))) == 0x46DD794E
+    assert hostlib.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    assert hostlib.crc32c(b'6789', hostlib.crc32c(b'12345')) == 0xE3069283     # chaining
+    assert hostlib.crc32c(np.arange(8, dtype=np.uint8)) == hostlib.crc32c(bytes(range(8)))
+    crc = hostlib.crc32c(b'foo')
     masked = tf_bundle.masked_crc32c(b'foo')
     assert masked != crc
     rot = (masked - tf_bundle.CRC_MASK_DELTA) & 0xFFFFFFFF

@@ -19,20 +19,22 @@ def main():
     cell = sys.argv[4] if len(sys.argv) >= 5 else 'lstm'
     G = hip.CELL_GATES[cell]
     hip.load(os.environ.get('CTCASR_LIB'))      # A/B builds of the library
-    if os.environ.get('CTCASR_FULL'):      # backward recurrence on the whole chip (default: half)
-        hip.set_option('rnn_bwd_half_chip', 0)
-    if os.environ.get('CTCASR_FWD_HALF'):  # forward recurrence on half of the chip
-        hip.set_option('rnn_fwd_half_chip', 1)
+    # CTCASR_FULL: backward recurrence on the whole chip (default: half);
+    # CTCASR_FWD_HALF: forward recurrence on half of the chip (default: whole)
+    bwd_flags = hip.RNN_WHOLE_CHIP if os.environ.get('CTCASR_FULL') else hip.RNN_DEFAULT
+    fwd_flags = hip.RNN_HALF_CHIP if os.environ.get('CTCASR_FWD_HALF') else hip.RNN_DEFAULT
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
     dy = torch.randn(T, B, 2 * H, device='cuda', generator=g)
     wt = hip.transpose_batched(w)
-    y, reserve, ws = hip.rnn_fwd(cell, xw, w)
-    dxw = hip.rnn_bwd(cell, dy, y, wt, reserve, workspace=ws)
+    y, reserve, ws = hip.rnn_fwd(cell, xw, w, flags=fwd_flags)
+    dxw = hip.rnn_bwd(cell, dy, y, wt, reserve, workspace=ws, flags=bwd_flags)
     hip.rnn_poll_error(cell, ws, T, B, H)
-    for name, fn in (('fwd', lambda: hip.rnn_fwd(cell, xw, w, y=y, reserve=reserve, workspace=ws)),
-                     ('bwd', lambda: hip.rnn_bwd(cell, dy, y, wt, reserve, dxw=dxw, workspace=ws))):
+    for name, fn in (('fwd', lambda: hip.rnn_fwd(cell, xw, w, y=y, reserve=reserve, workspace=ws,
+                                              flags=fwd_flags)),
+                     ('bwd', lambda: hip.rnn_bwd(cell, dy, y, wt, reserve, dxw=dxw, workspace=ws,
+                                              flags=bwd_flags))):
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         start.record()

@@ -426,7 +426,11 @@ def main():
         raise SystemExit('--gpus {} does not match WORLD_SIZE {}'.format(args.gpus, world_env))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; no GPU is visible.')
-    if torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', world_env)):
+    # tools/two_rank_one_gpu.py (plumbing check of the N > 1 path on a one-GPU box: gloo, shared
+    # device, streaming recurrence) sets this; the line then says so and means nothing else
+    share_gpu = os.environ.get('CTCASR_BENCH_SHARE_GPU') == '1'
+    if not share_gpu and \
+            torch.cuda.device_count() < int(os.environ.get('LOCAL_WORLD_SIZE', world_env)):
         raise SystemExit('bench.py: {} ranks on this node but only {} GPU(s) visible.'.format(
             os.environ.get('LOCAL_WORLD_SIZE', world_env), torch.cuda.device_count()))
     rank, local_rank, world = init_distributed()
@@ -443,7 +447,8 @@ def main():
                 'uuid': str(getattr(props, 'uuid', ''))}
         devices = [None] * world
         dist.all_gather_object(devices, mine)
-        if ranks_seen != world or len({(d['device'], d['uuid']) for d in devices}) != world:
+        if ranks_seen != world or \
+                (not share_gpu and len({(d['device'], d['uuid']) for d in devices}) != world):
             raise SystemExit('bench.py: ranks do not map to {} distinct GPUs: {}'.format(
                 world, devices))
 
@@ -458,6 +463,8 @@ def main():
         if world > 1:
             result['allreduce']['ranks_seen_by_allreduce'] = ranks_seen
             result['devices'] = devices
+            if share_gpu:
+                result['devices_shared'] = True      # not a measurement: plumbing check only
         if other:
             result['other_workloads'] = other
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,9 @@
 #define PRNN_GROUPS 8
 #endif
 #define PRNN_SPIN_LIMIT (1u << 22)
+#ifndef PRNN_CHAIN0_PRIO
+#define PRNN_CHAIN0_PRIO 1
+#endif
 #ifndef PRNN_POLL_SLEEP
 #define PRNN_POLL_SLEEP 1
 #endif
@@ -41,8 +44,13 @@ namespace {
 // Every arrival counter sits in its own 256-byte block: the 16 counters of a launch then map to
 // different memory channels instead of serialising 256 arrivals + all polls on one line.
 #define PRNN_CNT_STRIDE 64
+#define PRNN_MAX_CHAINS 2
 struct SyncWords {
-    unsigned group_cnt[2][PRNN_GROUPS][PRNN_CNT_STRIDE];
+    // [direction][chain][group]: a chain is one 16-row batch tile running its own recurrence
+    unsigned group_cnt[2][PRNN_MAX_CHAINS][PRNN_GROUPS][PRNN_CNT_STRIDE];
+    // workgroups of a (direction, chain) that are through their LAST wait of the launch; the last
+    // one zeroes that group's counters again, so a launch needs no memset before it
+    unsigned done[2][PRNN_MAX_CHAINS][PRNN_CNT_STRIDE];
     unsigned error;
     unsigned pad[63];
     unsigned long long prof[16];   // CTCASR_RNN_PROF=1: per-phase 100 MHz ticks of workgroup 0
@@ -60,7 +68,8 @@ struct PArgs {
     float *cells;          // LSTM reserve [T, B, 2, H]
     SyncWords *sync;
     float *xchg;           // exchange buffer [T steps][2][K/16 chunks][B][16] (see below)
-    int T, B, H, nwg;      // nwg = workgroups per direction
+    const float *bias;     // forward: [2, G*H] added to xw (NULL: none)
+    int T, B, H, nwg;      // nwg = workgroups per direction (and chain)
     int s_lo, s_hi;        // backward: this launch runs steps s_hi-1 ... s_lo (a whole pass: 0, T)
     float *carry;          // backward, LSTM: dc [2, B, H] handed from one launch to the next
     int prof;              // record phase timings of workgroup 0
@@ -116,19 +125,67 @@ __device__ __forceinline__ float4 load16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsign
                        __uint_as_float(v.w));
 }
 
-// Direction-wide barrier, split in two so that the arrival is posted as soon as a step's
-// published stores are out and the wait happens at the top of the next step.
-// `step` counts arrivals (0-based).
-__device__ __forceinline__ void dir_arrive(SyncWords *sy, int dir, int grp, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-    __syncthreads();
-    if (tid == 0)
-        __hip_atomic_fetch_add(&sy->group_cnt[dir][grp][0], 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+// Two chains per workgroup (CHAINS = 2, batches of 17..32 rows).  The two 16-row batch tiles of
+// such a batch are INDEPENDENT recurrences that share the weights.  Run through one barrier
+// (the MT = 2 kernels of round 1) each step costs wait + 2 x MFMA work; here every workgroup has
+// 8 waves instead - waves 0-3 carry tile 0, waves 4-7 tile 1, two waves per SIMD - and each tile
+// has its own arrival counters, so while one tile's waves wait for their exchange round trip the
+// SIMD issues the other tile's MFMAs: the hardware interleaves the chains, no software
+// pipelining.  The LDS weight slice is shared by both chains.  A workgroup-wide s_barrier would
+// couple the chains again, so the three per-step synchronisations among the 4 waves of a chain
+// go through LDS words instead (LDS executes a wave's DS instructions in issue order, so a
+// counter update issued after a wave's ds_writes is seen only after them):
+//   chain_flag_*   one-way: the polling wave tells the other three that the direction barrier
+//                  has been passed
+//   chain_barrier  all four waves have written their partial tiles before any of them reads
+//   chain_arrive   non-blocking: every wave drains its published stores, the LAST one to get
+//                  there posts the workgroup's arrival on the global counter.
+struct ChainSync {          // in LDS, one per chain
+    unsigned flag;          // steps whose direction barrier the poller has seen complete
+    unsigned bar;           // chain_barrier arrivals
+    unsigned arrive;        // chain_arrive arrivals
+    unsigned pad;
+};
+__device__ __forceinline__ unsigned lds_load(unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void chain_barrier(ChainSync *cs, unsigned &epoch, int lane) {
+    epoch += 4;
+    asm volatile("" ::: "memory");          // (compiler) LDS writes above stay above
+    if (lane == 0)
+        __hip_atomic_fetch_add(&cs->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (lds_load(&cs->bar) < epoch) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");          // LDS reads below stay below
 }
 
-// Wait until every workgroup of this direction has posted arrival number `step` (0-based).
-// Only wave 0 polls (8 lanes, one counter each): more pollers measurably slow the arrivals down.
+// Direction-wide barrier, split in two so that the arrival is posted as soon as a step's
+// published stores are out and the wait happens at the top of the next step.
+// `step` counts arrivals (0-based).  CHAINS = 1: `ctid` is threadIdx.x and the workgroup barrier
+// separates the phases; CHAINS = 2: `ctid` is the thread index within the chain's 4 waves.
+template <int CHAINS>
+__device__ __forceinline__ void dir_arrive(SyncWords *sy, ChainSync *cs, int dir, int chain,
+                                           int grp, int ctid, unsigned &arrivals) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+    if constexpr (CHAINS == 1) {
+        __syncthreads();
+        if (ctid == 0)
+            __hip_atomic_fetch_add(&sy->group_cnt[dir][chain][grp][0], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        arrivals += 4;
+        if ((ctid & 63) == 0) {
+            const unsigned before = __hip_atomic_fetch_add(
+                &cs->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (before + 1 == arrivals)     // the last of the chain's four waves
+                __hip_atomic_fetch_add(&sy->group_cnt[dir][chain][grp][0], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Wait until every workgroup of this direction (and chain) has posted arrival number `step`
+// (0-based).  Only one wave polls (8 lanes, one counter each): more pollers measurably slow the
+// arrivals down.
 // (One flag word per workgroup - a plain write-through store instead of the atomic, every poller
 // reading all 128 flags - was measured too: 5.4 / 7.6 us per step against 5.3 / 7.2.  So was
 // running the forward pass as 2 x 256 four-unit workgroups, two per CU, so that one's MFMAs
@@ -138,28 +195,56 @@ __device__ __forceinline__ void dir_arrive(SyncWords *sy, int dir, int grp, int 
 // arrive; every extra access to the counter lines makes it longer.)
 // On timeout the error word is raised and the workgroup carries on with whatever it reads
 // (results are invalid, the host reports CTCASR_ERR_TIMEOUT) so that no barrier is abandoned.
-__device__ __forceinline__ void dir_wait(SyncWords *sy, int dir, int group_size, unsigned step,
-                                         int tid) {
-    if (tid < 64) {
+template <int CHAINS>
+__device__ __forceinline__ void dir_wait(SyncWords *sy, ChainSync *cs, int dir, int chain,
+                                         int group_size, unsigned step, int ctid) {
+    if (ctid < 64) {
         const unsigned target = (unsigned)group_size * (step + 1);
         unsigned spins = 0;
         for (;;) {
             bool ready = true;
-            if (tid < PRNN_GROUPS)
-                ready = __hip_atomic_load(&sy->group_cnt[dir][tid][0], __ATOMIC_RELAXED,
+            if (ctid < PRNN_GROUPS)
+                ready = __hip_atomic_load(&sy->group_cnt[dir][chain][ctid][0], __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT) >= target;
             if (__all(ready)) break;
             __builtin_amdgcn_s_sleep(PRNN_POLL_SLEEP);
             if (++spins > PRNN_SPIN_LIMIT ||
                 ((spins & 1023u) == 0 &&
                  __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                if (tid == 0)
+                if (ctid == 0)
                     __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
+        if constexpr (CHAINS > 1) {
+            asm volatile("" ::: "memory");
+            if (ctid == 0)
+                __hip_atomic_store(&cs->flag, step + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if constexpr (CHAINS > 1) {
+        while (lds_load(&cs->flag) < step + 1) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
     }
-    __syncthreads();
+    if constexpr (CHAINS == 1) __syncthreads();
+}
+
+// Called by a workgroup (thread 0 of the chain) after its LAST dir_wait of a launch: none of its
+// threads touches the arrival counters again.  The last workgroup of the (direction, chain) group
+// to get here - by then every poller of the group has finished - zeroes the group's counters, so
+// the next launch on this workspace finds them clean without a memset on the critical path (a
+// 4 KB hipMemsetAsync between two launches measured 0.26-0.43 ms when GEMMs of another stream
+// were holding the CUs).
+__device__ __forceinline__ void counters_done(SyncWords *sy, int dir, int chain, int nwg) {
+    const unsigned before = __hip_atomic_fetch_add(&sy->done[dir][chain][0], 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1 == (unsigned)nwg) {
+        for (int g = 0; g < PRNN_GROUPS; ++g)
+            __hip_atomic_store(&sy->group_cnt[dir][chain][g][0], 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->done[dir][chain][0], 0u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,8 +255,9 @@ __device__ __forceinline__ void dir_wait(SyncWords *sy, int dir, int group_size,
 // REGW > 0: the last REGW of a wave's QW * NT B-fragment slots (slot = chunk * NT + tile) live in
 // registers instead of LDS - the variant for 64 workgroups per direction (half of the chip), whose
 // 256 KB weight slice does not fit LDS alone.
-template <int CELL, int NT, int QW, int MT, int REGW = 0>
-__global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
+template <int CELL, int NT, int QW, int MT, int REGW = 0, int CHAINS = 1>
+__global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p) {
+    static_assert(CHAINS == 1 || (MT == 1 && REGW == 0), "two chains: one batch tile each");
     constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
     constexpr int COLS = 16 * NT;
     constexpr int UPB = COLS / G;
@@ -180,10 +266,35 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *frag = reinterpret_cast<float4 *>(smem);
-    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(float4));
+    constexpr int RED_FLOATS = 4 * NT * MT * 16 * 17;
+    // chain = batch tile with its own barrier (CHAINS = 2: waves 0-3 / 4-7); `tid` and `wave`
+    // count within the chain, `row0` is the tile's first batch row
+    // (readfirstlane: wave-uniform, so that branches on it are scalar branches - s_setprio is a
+    // scalar instruction and ignores the exec mask of a predicated block)
+    // CHAINS = 1 with a grid of 2 x (2 * nwg) workgroups: the two tiles run as separate groups of
+    // workgroups (each tile on its own CUs, nothing shared but the launch)
+    const int chain =
+        CHAINS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PRNN_THREADS)
+                   : (int)blockIdx.x / (2 * p.nwg);
+    const int row0 = chain * 16;
+    const int lchain = CHAINS > 1 ? chain : 0;      // chain index WITHIN the workgroup (LDS carve)
+    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(float4)) +
+                 lchain * RED_FLOATS;
+    ChainSync *cs = reinterpret_cast<ChainSync *>(
+                        smem + (size_t)4 * QL * 64 * sizeof(float4) +
+                        (size_t)CHAINS * RED_FLOATS * sizeof(float)) + lchain;
+    unsigned bar_epoch = 0, arrivals = 0;
+    // Two chains left alone run in lockstep (both wait, then both want the matrix pipe, sharing
+    // it 50:50 - measured 8.5 us per forward step against 7.3 with one barrier): a static
+    // priority for chain 0 lets it through first, after which the chains stay out of phase and
+    // each one's exchange round trip hides behind the other's MFMAs.
+    if constexpr (CHAINS > 1) {
+        if (chain == 0) __builtin_amdgcn_s_setprio(PRNN_CHAIN0_PRIO);
+    }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = blockIdx.x / p.nwg, slice = blockIdx.x % p.nwg;
+    const int tid = threadIdx.x % PRNN_THREADS, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x % (2 * p.nwg);
+    const int dir = wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int H = p.H, B = p.B, T = p.T;
     const int u0 = slice * UPB;
@@ -198,7 +309,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                 p.w + ((size_t)dir * G * H + (c / UPB) * H + u0 + (c % UPB)) * H + kq;
             return ldg4(wrow + 16 * (wave * QW + i));
         };
-        for (int sl = 0; sl < QL; ++sl) frag[(wave * QL + sl) * 64 + lane] = slot(sl);
+        // (two chains share the LDS copy: each stages every other slot)
+        for (int sl = lchain; sl < QL; sl += CHAINS) frag[(wave * QL + sl) * 64 + lane] = slot(sl);
+        if (CHAINS > 1 && tid == 0) *cs = ChainSync{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int sl = 0; sl < REGW; ++sl) wreg[sl] = slot(QL + sl);
     }
@@ -210,8 +323,11 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
     // Reading fragments from y itself (rows 8 KB apart: 16 half-used lines per instruction) ran
     // at ~25 GB/s per CU, and a contiguous block with lanes permuted inside it (4 address cycles
     // per lane quad) was still texture-addresser bound at ~37 GB/s per CU.
+    // The buffer starts with an all-zero block of 2*B*G*H floats that no kernel ever writes (rows
+    // that are not running read it; zero-filled once with the workspace), the steps follow.
+    const size_t x_base = (size_t)2 * B * G * H;      // floats of the all-zero block
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * H * sizeof(float)), 0x00020000);
+        p.xchg, 0, (int)((x_base + (size_t)T * 2 * B * H) * sizeof(float)), 0x00020000);
     const size_t x_step = (size_t)2 * B * H;          // floats per step
     // every workgroup of a direction reads the same rows: start each one at a different chunk so
     // that the 16 workgroups sharing an XCD's L2 do not all hit the same channel at once
@@ -226,19 +342,31 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
         if constexpr (CELL == CTCASR_CELL_LSTM) {
             // continuing a pass that an earlier launch started: pick up its cell state
             const int item = tid + it * PRNN_THREADS;
-            if (p.s_lo > 0 && item < 16 * MT * UPB && item / UPB < B)
-                c_state[it] = p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB];
+            if (p.s_lo > 0 && item < 16 * MT * UPB && row0 + item / UPB < B)
+                c_state[it] = p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB];
         }
     }
 
     int a_steps[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int row = mt * 16 + (lane & 15);
+        const int row = row0 + mt * 16 + (lane & 15);
         a_steps[mt] = row < B ? row_steps(p.seq_len, row, T) : 0;
+    }
+    // the input projection's bias: an item's unit is the same in every step, so its G bias
+    // values live in registers (saves the bias epilogue of the xw GEMM: 0.23 ms of 4.16 at C3)
+    float xb[ITEMS][G];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = tid + it * PRNN_THREADS;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            xb[it][g] = p.bias && item < 16 * MT * UPB
+                            ? p.bias[(size_t)dir * G * H + (size_t)g * H + u0 + item % UPB] : 0.f;
     }
 
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
+    // phase timings: thread 0 of each chain (chain 1's go to prof[8..12] of workgroup 0)
     const bool prof = p.prof && tid == 0;
     for (int s = p.s_lo; s < p.s_hi; ++s) {
         unsigned long long c0 = prof ? wall_clock64() : 0;
@@ -251,7 +379,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             const int item = tid + it * PRNN_THREADS;
             it_t[it] = -1;
             if (item < 16 * MT * UPB) {
-                const int b = item / UPB, u = item % UPB;
+                const int b = row0 + item / UPB, u = item % UPB;
                 if (b < B) {
                     const int steps = row_steps(p.seq_len, b, T);
                     if (s < steps) {
@@ -259,7 +387,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                         it_t[it] = t;
                         const float *x = p.xw + (((size_t)t * B + b) * 2 + dir) * G * H + u0 + u;
 #pragma unroll
-                        for (int g = 0; g < G; ++g) xw[it][g] = x[(size_t)g * H];
+                        for (int g = 0; g < G; ++g) xw[it][g] = x[(size_t)g * H] + xb[it][g];
                     }
                 }
             }
@@ -273,18 +401,22 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 
         if (s > 0) {
             // (the first step of a continued pass reads what the previous launch published)
-            if (s > p.s_lo) dir_wait(p.sync, dir, group_size, (unsigned)(s - 1 - p.s_lo), tid);
+            if (s > p.s_lo) {
+                dir_wait<CHAINS>(p.sync, cs, dir, chain, group_size, (unsigned)(s - 1 - p.s_lo),
+                                 tid);
+                if (s == p.s_hi - 1 && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
             if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
             // A fragments: h_{s-1} rows straight from y, every load issued before the first MFMA
             float4 a[MT][QW];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int row = mt * 16 + (lane & 15);
+                const int row = row0 + mt * 16 + (lane & 15);
                 // rows that are not running (beyond B, or past their length) read the all-zero
-                // step T of the exchange buffer: the loads stay unconditional, so the compiler
+                // block at the start of the exchange buffer: the loads stay unconditional, so the compiler
                 // can count them (vmcnt(N)) and start the MFMAs as the first ones land
                 const bool ok = s < a_steps[mt];     // row still running (implies s-1 ran too)
-                const unsigned aoff = (unsigned)(((size_t)(ok ? s - 1 : T) * x_step +
+                const unsigned aoff = (unsigned)(((ok ? x_base + (size_t)(s - 1) * x_step : 0) +
                                                   (size_t)dir * B * H +
                                                   (size_t)(wave * QW) * B * 16 +
                                                   (size_t)(lane >> 4) * B * 4 +
@@ -352,7 +484,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                 for (int r = 0; r < 4; ++r)
                     red[((wave * NT + nt) * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 +
                         (lane & 15)] = acc[mt][nt][r];
-        __syncthreads();
+        if constexpr (CHAINS == 1) __syncthreads();
+        else chain_barrier(cs, bar_epoch, lane);
+        if (prof) { unsigned long long c = wall_clock64(); pt[4] += c - c0; }
 
         float hv[ITEMS], rsv[ITEMS][5];
 #pragma unroll
@@ -360,7 +494,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             hv[it] = 0.f;
             if (it_t[it] >= 0) {
                 const int item = tid + it * PRNN_THREADS;
-                const int b = item / UPB, u = item % UPB;
+                const int b = item / UPB, u = item % UPB;      // row within the tile
                 float rec[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -391,8 +525,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
                         h3 = __shfl_down(hv[it], 3, 64);
             if (it_t[it] >= 0 && (tid & 3) == 0) {
                 const int item = tid + it * PRNN_THREADS;
-                const int b = item / UPB, unit = u0 + item % UPB;
-                store16_sc1(x_rsrc, (unsigned)(((size_t)s * x_step + (size_t)dir * B * H +
+                const int b = row0 + item / UPB, unit = u0 + item % UPB;
+                store16_sc1(x_rsrc, (unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * H +
                                                 (size_t)(unit >> 4) * B * 16 +
                                                 (size_t)((unit & 15) >> 2) * B * 4 +
                                                 (size_t)b * 4) * sizeof(float)),
@@ -400,13 +534,13 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
-        if (s + 1 < p.s_hi) dir_arrive(p.sync, dir, grp, tid);
+        if (s + 1 < p.s_hi) dir_arrive<CHAINS>(p.sync, cs, dir, chain, grp, tid, arrivals);
         // y and the reserve for the backward pass: nobody inside this launch reads them
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             if (it_t[it] < 0) continue;
             const int item = tid + it * PRNN_THREADS;
-            const int b = item / UPB, unit = u0 + item % UPB;
+            const int b = row0 + item / UPB, unit = u0 + item % UPB;
             p.y[((size_t)it_t[it] * B + b) * 2 * H + dir * H + unit] = hv[it];
         }
         if constexpr (CELL == CTCASR_CELL_LSTM) {
@@ -414,7 +548,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
             for (int it = 0; it < ITEMS; ++it) {
                 if (it_t[it] < 0) continue;
                 const int item = tid + it * PRNN_THREADS;
-                const int b = item / UPB, unit = u0 + item % UPB;
+                const int b = row0 + item / UPB, unit = u0 + item % UPB;
                 float *gr = p.gates + (((size_t)it_t[it] * B + b) * 2 + dir) * 4 * H + unit;
                 gr[0] = rsv[it][0]; gr[H] = rsv[it][1]; gr[2 * H] = rsv[it][2];
                 gr[3 * H] = rsv[it][3];
@@ -428,16 +562,19 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int item = tid + it * PRNN_THREADS;
-                if (item < 16 * MT * UPB && item / UPB < B)
-                    p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB] = c_state[it];
+                if (item < 16 * MT * UPB && row0 + item / UPB < B)
+                    p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB] =
+                        c_state[it];
             }
         }
     }
     if (prof) {
         for (int i = 0; i < 4; ++i) {
-            if (blockIdx.x == 0) p.sync->prof[i] = pt[i];
-            if (blockIdx.x < 256) p.sync->prof_all[blockIdx.x][i] = pt[i];
+            if (blockIdx.x == 0) p.sync->prof[chain * 8 + i] = pt[i];
+            if (blockIdx.x < 256 && chain == 0) p.sync->prof_all[blockIdx.x][i] = pt[i];
         }
+        // (of which, inside phase 2: partial-tile writes + the barrier of the chain's 4 waves)
+        if (blockIdx.x == 0) p.sync->prof[chain * 8 + 4] = pt[4];
     }
 }
 
@@ -456,8 +593,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd_kernel(PArgs p) {
 //                        128-workgroup variant: 6.7 vs 5.7 us per step, 128 CUs free).
 // Reduction scratch [4][MT*16][17] follows the fragments.
 // ---------------------------------------------------------------------------------------------
-template <int CELL, int QW, int MT, int LB, int UPB, int REGW>
-__global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
+template <int CELL, int QW, int MT, int LB, int UPB, int REGW, int CHAINS = 1>
+__global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p) {
+    static_assert(CHAINS == 1 || MT == 1, "two chains: one batch tile each");
     constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
     constexpr bool HALF_TILE = UPB == 8;
     // UPB = 32: TWO N tiles per workgroup.  The B-fragment slots of a wave then alternate
@@ -476,10 +614,34 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
     static_assert(!TWO_TILES || (G == 1 && REGW > 0), "two tiles: plain RNN, static slot map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *frag = reinterpret_cast<float4 *>(smem);
-    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * SLOTS * sizeof(float4));
+    constexpr int RED_FLOATS = 4 * NT * MT * 16 * 17;
+    // chain = batch tile with its own barrier (see ChainSync); `tid` / `wave` count within it
+    // (readfirstlane: wave-uniform, so that branches on it are scalar branches - s_setprio is a
+    // scalar instruction and ignores the exec mask of a predicated block)
+    // CHAINS = 1 with a grid of 2 x (2 * nwg) workgroups: the two tiles run as separate groups of
+    // workgroups (each tile on its own CUs, nothing shared but the launch)
+    const int chain =
+        CHAINS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PRNN_THREADS)
+                   : (int)blockIdx.x / (2 * p.nwg);
+    const int row0 = chain * 16;
+    const int lchain = CHAINS > 1 ? chain : 0;      // chain index WITHIN the workgroup (LDS carve)
+    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * SLOTS * sizeof(float4)) +
+                 lchain * RED_FLOATS;
+    ChainSync *cs = reinterpret_cast<ChainSync *>(
+                        smem + (size_t)4 * QL * SLOTS * sizeof(float4) +
+                        (size_t)CHAINS * RED_FLOATS * sizeof(float)) + lchain;
+    unsigned bar_epoch = 0, arrivals = 0;
+    // Two chains left alone run in lockstep (both wait, then both want the matrix pipe, sharing
+    // it 50:50 - measured 8.5 us per forward step against 7.3 with one barrier): a static
+    // priority for chain 0 lets it through first, after which the chains stay out of phase and
+    // each one's exchange round trip hides behind the other's MFMAs.
+    if constexpr (CHAINS > 1) {
+        if (chain == 0) __builtin_amdgcn_s_setprio(PRNN_CHAIN0_PRIO);
+    }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int dir = blockIdx.x / p.nwg, slice = blockIdx.x % p.nwg;
+    const int tid = threadIdx.x % PRNN_THREADS, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x % (2 * p.nwg);
+    const int dir = wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int H = p.H, B = p.B, T = p.T, GH = G * p.H;
     const int u0 = slice * UPB;
@@ -496,16 +658,20 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             const int c = i / NT;
             return ldg4(wrow + (size_t)(i % NT) * 16 * GH + (c / CPG) * H + (c % CPG) * 16);
         };
-        for (int i = 0; i < QL; ++i) frag[(wave * QL + i) * SLOTS + half] = slot(i);
+        // (two chains share the LDS part: each stages every other slot; the register part is
+        // per wave, so both chains load it)
+        for (int i = lchain; i < QL; i += CHAINS) frag[(wave * QL + i) * SLOTS + half] = slot(i);
 #pragma unroll
         for (int i = 0; i < REGW; ++i) wreg[i] = slot(QL + i);
     }
+    if (CHAINS > 1 && tid == 0) *cs = ChainSync{0u, 0u, 0u, 0u};
     __syncthreads();
 
     // exchange buffer [step][dir][16-float chunk of n = g*H + unit][k group][b][4] (see forward)
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
-    const size_t x_step = (size_t)2 * B * GH;
+    const size_t x_step = (size_t)2 * B * GH;      // = the all-zero block in front of the steps
+    const size_t x_base = x_step;
     // de-synchronise the workgroups' walk over the chunks (LDS-only variant; register-resident
     // fragments need a static chunk -> register map)
     const int rot = REGW == 0 ? (slice & (QW - 1)) : 0;
@@ -516,19 +682,19 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
         if constexpr (CELL == CTCASR_CELL_LSTM) {
             // continuing a pass that an earlier launch started: pick up its cell-state gradient
             const int item = tid + it * PRNN_THREADS;
-            if (p.s_hi < T && item < 16 * MT * UPB && item / UPB < B)
-                dc_state[it] = p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB];
+            if (p.s_hi < T && item < 16 * MT * UPB && row0 + item / UPB < B)
+                dc_state[it] = p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB];
         }
     }
     int a_steps[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int row = mt * 16 + (lane & 15);
+        const int row = row0 + mt * 16 + (lane & 15);
         a_steps[mt] = row < B ? row_steps(p.seq_len, row, T) : 0;
     }
 
     unsigned long long pt[4] = {0, 0, 0, 0};
-    const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
+    const bool prof = p.prof && blockIdx.x == 0 && threadIdx.x == 0;
     for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
         unsigned long long c0 = prof ? wall_clock64() : 0;
         // everything the cell derivative needs except dh_rec: prefetched before the barrier
@@ -539,7 +705,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
             const int item = tid + it * PRNN_THREADS;
             it_t[it] = -1;
             if (item < 16 * MT * UPB) {
-                const int b = item / UPB, u = item % UPB;
+                const int b = row0 + item / UPB, u = item % UPB;
                 if (b < B) {
                     const int steps = row_steps(p.seq_len, b, T);
                     if (s < steps) {
@@ -575,16 +741,20 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
         if (s < T - 1) {
             // dgates of step s+1 from every workgroup of this direction (the first step of a
             // continued pass reads what the previous launch left: nothing to wait for)
-            if (s < p.s_hi - 1)
-                dir_wait(p.sync, dir, group_size, (unsigned)(p.s_hi - 2 - s), tid);
+            if (s < p.s_hi - 1) {
+                dir_wait<CHAINS>(p.sync, cs, dir, chain, group_size, (unsigned)(p.s_hi - 2 - s),
+                                 tid);
+                if (s == p.s_lo && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
             if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
             unsigned aoff[MT];
             bool ok[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int row = mt * 16 + (lane & 15);
-                ok[mt] = s + 1 < a_steps[mt];     // otherwise: the all-zero step T
-                aoff[mt] = (unsigned)(((size_t)(ok[mt] ? s + 1 : T) * x_step + (size_t)dir * B * GH +
+                const int row = row0 + mt * 16 + (lane & 15);
+                ok[mt] = s + 1 < a_steps[mt];     // otherwise: the all-zero block
+                aoff[mt] = (unsigned)(((ok[mt] ? x_base + (size_t)(s + 1) * x_step : 0) +
+                                       (size_t)dir * B * GH +
                                        (size_t)(wave * (H / 64)) * B * 16 +
                                        (size_t)(lane >> 4) * B * 4 +
                                        (size_t)(ok[mt] ? row : 0) * 4) * sizeof(float));
@@ -659,7 +829,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                     red[((wave * NT + 1) * MT * 16 + mt * 16 + 4 * (lane >> 4) + r) * 17 +
                         (lane & 15)] = acc2[mt][r];
             }
-        __syncthreads();
+        if constexpr (CHAINS == 1) __syncthreads();
+        else chain_barrier(cs, bar_epoch, lane);
 
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -667,7 +838,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
 #pragma unroll
             for (int g = 0; g < G; ++g) dg[g] = 0.f;
             const int item = tid + it * PRNN_THREADS;
-            const int b = item / UPB, u = item % UPB;
+            const int b = item / UPB, u = item % UPB;          // row within the tile
             if (it_t[it] >= 0) {
                 float dh = dyv[it];
 #pragma unroll
@@ -696,21 +867,22 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
                 if (it_t[it] >= 0 && (tid & 3) == 0) {
                     const int n = g * H + u0 + u;
                     store16_sc1(x_rsrc,
-                                (unsigned)(((size_t)s * x_step + (size_t)dir * B * GH +
+                                (unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * GH +
                                             (size_t)(n >> 4) * B * 16 +
-                                            (size_t)((n & 15) >> 2) * B * 4 + (size_t)b * 4) *
+                                            (size_t)((n & 15) >> 2) * B * 4 +
+                                            (size_t)(row0 + b) * 4) *
                                            sizeof(float)),
                                 dg[g], d1, d2, d3);
                 }
             }
             if (it_t[it] >= 0) {      // dxw in its GEMM layout: read after the launch only
-                float *dx = p.dxw + (((size_t)it_t[it] * B + b) * 2 + dir) * GH + u0 + u;
+                float *dx = p.dxw + (((size_t)it_t[it] * B + row0 + b) * 2 + dir) * GH + u0 + u;
 #pragma unroll
                 for (int g = 0; g < G; ++g) dx[(size_t)g * H] = dg[g];
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
-        if (s > p.s_lo) dir_arrive(p.sync, dir, grp, tid);
+        if (s > p.s_lo) dir_arrive<CHAINS>(p.sync, cs, dir, chain, grp, tid, arrivals);
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
     }
     if constexpr (CELL == CTCASR_CELL_LSTM) {
@@ -718,8 +890,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd_kernel(PArgs p) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int item = tid + it * PRNN_THREADS;
-                if (item < 16 * MT * UPB && item / UPB < B)
-                    p.carry[((size_t)dir * B + item / UPB) * H + u0 + item % UPB] = dc_state[it];
+                if (item < 16 * MT * UPB && row0 + item / UPB < B)
+                    p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB] =
+                        dc_state[it];
             }
         }
     }
@@ -749,29 +922,21 @@ int g_kernel_events = 0;
 std::vector<TimedLaunch> g_timed;
 
 template <typename K>
-int launch_persistent(K kernel, const PArgs &p, size_t lds, size_t zero_step_floats,
-                      hipStream_t s) {
+int launch_persistent(K kernel, const PArgs &p, size_t lds, hipStream_t s, int chains = 1,
+                      int tile_groups = 1) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    const bool continued = p.dxw ? p.s_hi < p.T : p.s_lo > 0;
-    // Fresh barrier counters for every launch.  The error word behind them is STICKY: a launch
-    // never clears it, so a timeout in any layer or pass survives until ctcasr_rnn_poll_error
-    // reads (and clears) it - the workspace must be zero-filled once before its first use.
-    if (hipMemsetAsync(p.sync, 0, offsetof(SyncWords, error), s) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
-    if (!continued) {
-        // (a continued pass keeps the exchange buffer and its all-zero step as they are)
-        if (hipMemsetAsync(p.xchg + (size_t)p.T * zero_step_floats, 0,
-                           zero_step_floats * sizeof(float), s) != hipSuccess)
-            return CTCASR_ERR_LAUNCH;
-    }
+    // No memsets: the arrival counters are zeroed again by the launch that used them
+    // (counters_done), the all-zero block of the exchange buffer is never written, and the
+    // time-out word is sticky (ctcasr_rnn_poll_error reads and clears it).  All three rely on the
+    // workspace having been zero-filled ONCE before its first use with this (B, H).
     TimedLaunch timed = {};
     const bool record = g_kernel_events && g_timed.size() < 65536 &&
                         hipEventCreate(&timed.start) == hipSuccess &&
                         hipEventCreate(&timed.stop) == hipSuccess;
     if (record) (void)hipEventRecord(timed.start, s);
-    kernel<<<2 * p.nwg, PRNN_THREADS, lds, s>>>(p);
+    kernel<<<2 * p.nwg * tile_groups, PRNN_THREADS * chains, lds, s>>>(p);
     if (record) {
         (void)hipEventRecord(timed.stop, s);
         timed.backward = p.dxw != nullptr;
@@ -835,15 +1000,16 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
     return ctcasr_align_up((size_t)(T + 1) * 2 * B * G * H * sizeof(float), 256);
 }
 
-int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
-             int H, float *y, float *gates, float *cells, void *sync, float *carry, int step_begin,
-             int step_end, int flags, hipStream_t s) {
+int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
+             const int32_t *seq_len, int T, int B, int H, float *y, float *gates, float *cells,
+             void *sync, float *carry, int step_begin, int step_end, int flags, hipStream_t s) {
     // forward default: the whole chip (nothing of the same layer can overlap it)
     const bool fwd_half_chip = (flags & CTCASR_RNN_HALF_CHIP) != 0;
     PArgs p = {};
     p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
+    p.bias = xw_bias;
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H;
     p.s_lo = step_begin; p.s_hi = step_end;
@@ -851,21 +1017,25 @@ int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_le
     if (seq_len && step_begin == 0 && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
+    const bool one_barrier = (flags & CTCASR_RNN_ONE_BARRIER) != 0;
     // 128 workgroups per direction, 16 * NT gate columns each, QW = H / 64 K chunks per wave
 #define PRNN_FWD(CELL_, NT_, QW_, MT_)                                                        \
     return launch_persistent(prnn_fwd_kernel<CELL_, NT_, QW_, MT_>, p,                         \
                              (size_t)NT_ * 4 * QW_ * 64 * 16 +                                 \
-                                 (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 16,                     \
-                             (size_t)2 * B * H, s)
+                                 (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 32, s)
     p.nwg = 128;
-    if (cell == CTCASR_CELL_LSTM && fwd_half_chip && mt == 1) {
-        // 64 workgroups per direction, 16 units = 4 N tiles each; 256 KB of weights: half in LDS,
-        // half in registers.  (Two batch tiles - B = 32 - were tried with 24 / 40 slots in LDS /
-        // registers: 10.9 instead of 7.3 us per step, more than the pipelined GEMM gives back.)
+    // LSTM on 64 workgroups per direction: 16 units = 4 N tiles each, 256 KB of weights - half in
+    // LDS, half in registers.  Two uses: (1) B <= 16 with CTCASR_RNN_HALF_CHIP (128 CUs stay free
+    // for the next layer's input projection); (2) B = 17..32: the two 16-row batch tiles are
+    // independent recurrences, so each gets its own half of the chip and its own barrier in ONE
+    // launch of 2 x 128 workgroups - 6.0 us per step against 7.3 for the kernel that walks both
+    // tiles behind one barrier (and 8.7 for two chains inside every workgroup: the in-order
+    // memory queue of a CU makes one chain's bulk loads delay the other's publish / poll).
+    if (cell == CTCASR_CELL_LSTM && ((fwd_half_chip && mt == 1) || (mt == 2 && !one_barrier))) {
         p.nwg = 64;
         return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, 4, 16, 1, 32>, p,
-                                 (size_t)4 * 32 * 64 * 16 + (size_t)4 * 4 * 16 * 17 * 4 + 16,
-                                 (size_t)2 * B * H, s);
+                                 (size_t)4 * 32 * 64 * 16 + (size_t)4 * 4 * 16 * 17 * 4 + 32,
+                                 s, 1, mt);
     }
     if (cell == CTCASR_CELL_LSTM) {
         if (mt == 1) { PRNN_FWD(CTCASR_CELL_LSTM, 2, 16, 1); }
@@ -901,36 +1071,57 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                                    sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
-#define PRNN_BWD(CELL_, QW_, MT_, LB_, UPB_, REGW_, G_)                                        \
-    return launch_persistent(prnn_bwd_kernel<CELL_, QW_, MT_, LB_, UPB_, REGW_>, p,             \
+    // batches of 17..32 rows = two independent 16-row tiles (see ChainSync):
+    //   half of the chip: two chains inside every workgroup (8 waves): LSTM 11.0 us per step
+    //     against 12.1 for the kernel that walks both tiles behind one barrier;
+    //   whole chip: each tile as its own group of half-chip workgroups (2 x 128 in one launch),
+    //     7.1 us per step against 14.0.
+    const bool chains = mt == 2 && !(flags & CTCASR_RNN_ONE_BARRIER);
+#define PRNN_BWD(CELL_, QW_, MT_, LB_, UPB_, REGW_, CH_, TG_)                                  \
+    return launch_persistent(prnn_bwd_kernel<CELL_, QW_, MT_, LB_, UPB_, REGW_, CH_>, p,        \
                              (size_t)4 * (QW_ - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +          \
-                                 (size_t)4 * (UPB_ == 32 ? 2 : 1) * MT_ * 16 * 17 * 4 + 16,    \
-                             (size_t)2 * B * G_ * H, s)
+                                 (size_t)CH_ * (4 * (UPB_ == 32 ? 2 : 1) * MT_ * 16 * 17 * 4 + \
+                                                16) + 16, s, CH_, TG_)
     if (cell == CTCASR_CELL_LSTM) {
-        if (half_chip) {
-            if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 16, 16, 32, 4); }
-            PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 8, 16, 32, 4);
+        if (chains && !half_chip) {
+            p.nwg = H / 16;
+            PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 16, 16, 32, 1, 2);
         }
-        if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 32, 8, 0, 4); }
-        PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 16, 8, 0, 4);
+        if (half_chip) {
+            if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 16, 16, 32, 1, 1); }
+            if (chains) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 4, 16, 32, 2, 1); }
+            PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 8, 16, 32, 1, 1);
+        }
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 32, 8, 0, 1, 1); }
+        PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 16, 8, 0, 1, 1);
     }
     // plain RNN, H = 2048, half of the chip: 32 units (two N tiles) x 2048 x 4 B = 256 KB per
     // workgroup, split between LDS and registers like the LSTM's; 64 workgroups per direction
-    if (half_chip && cell == CTCASR_CELL_RNN_RELU) {
-        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 1, 16, 32, 32, 1); }
-        PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 2, 8, 32, 32, 1);
+    if (cell == CTCASR_CELL_RNN_RELU) {
+        if (chains && !half_chip) {
+            p.nwg = H / 32;
+            PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 1, 16, 32, 32, 1, 2);
+        }
+        if (half_chip) {
+            if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 1, 16, 32, 32, 1, 1); }
+            if (chains) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 1, 8, 32, 32, 2, 1); }
+            PRNN_BWD(CTCASR_CELL_RNN_RELU, 64, 2, 8, 32, 32, 1, 1);
+        }
+        // 16 units x 2048 x 4 B = 128 KB per workgroup, 128 per direction
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 32, 1, 32, 16, 0, 1, 1); }
+        PRNN_BWD(CTCASR_CELL_RNN_RELU, 32, 2, 16, 16, 0, 1, 1);
+    }
+    if (chains && !half_chip) {
+        p.nwg = H / 32;
+        PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 1, 16, 32, 32, 1, 2);
     }
     if (half_chip) {
-        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 1, 16, 32, 32, 1); }
-        PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 2, 8, 32, 32, 1);
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 1, 16, 32, 32, 1, 1); }
+        if (chains) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 1, 8, 32, 32, 2, 1); }
+        PRNN_BWD(CTCASR_CELL_RNN_TANH, 64, 2, 8, 32, 32, 1, 1);
     }
-    // plain RNN, H = 2048: 16 units x 2048 x 4 B = 128 KB per workgroup, 128 per direction
-    if (cell == CTCASR_CELL_RNN_RELU) {
-        if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_RELU, 32, 1, 32, 16, 0, 1); }
-        PRNN_BWD(CTCASR_CELL_RNN_RELU, 32, 2, 16, 16, 0, 1);
-    }
-    if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 32, 1, 32, 16, 0, 1); }
-    PRNN_BWD(CTCASR_CELL_RNN_TANH, 32, 2, 16, 16, 0, 1);
+    if (mt == 1) { PRNN_BWD(CTCASR_CELL_RNN_TANH, 32, 1, 32, 16, 0, 1, 1); }
+    PRNN_BWD(CTCASR_CELL_RNN_TANH, 32, 2, 16, 16, 0, 1, 1);
 #undef PRNN_BWD
 }
 

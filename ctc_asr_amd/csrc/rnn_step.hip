@@ -29,6 +29,7 @@ struct StepArgs {
     float *hbuf;           // [2, 2, B, H] state ping-pong (fwd)
     float *cbuf;           // [2, B, H] LSTM cell state (fwd) / dc or GRU dh*z carry (bwd)
     const float *b_hh;     // GRU: recurrent bias [2, 3H] (candidate-gate third is read)
+    const float *xw_bias;  // forward: [2, G*H] added to xw (NULL: none)
     float *drec;           // GRU bwd: gradient w.r.t. the recurrent pre-activations [T,B,2,3H]
     int T, B, H, step;
 };
@@ -127,13 +128,24 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
             rec[g] = red[0][c >> 4][bl][c & 15] + red[1][c >> 4][bl][c & 15] +
                      red[2][c >> 4][bl][c & 15] + red[3][c >> 4][bl][c & 15];
         }
-        const float *xw = p.xw + (((size_t)t * B + b) * 2 + dir) * G * H + unit;
+        // input projection (+ its bias when the caller did not fold it into the GEMM)
+        float xv[G];
+        {
+            const float *xw = p.xw + (((size_t)t * B + b) * 2 + dir) * G * H + unit;
+#pragma unroll
+            for (int g = 0; g < G; ++g) xv[g] = xw[(size_t)g * H];
+            if (p.xw_bias) {
+                const float *xb = p.xw_bias + (size_t)dir * G * H + unit;
+#pragma unroll
+                for (int g = 0; g < G; ++g) xv[g] += xb[(size_t)g * H];
+            }
+        }
         float h;
         if (CELL == CTCASR_CELL_LSTM) {
-            float gi = sigmoidf_(xw[0] + rec[0]);
-            float gf = sigmoidf_(xw[H] + rec[G > 1 ? 1 : 0]);
-            float gg = tanhf_(xw[2 * H] + rec[G > 2 ? 2 : 0]);
-            float go = sigmoidf_(xw[3 * H] + rec[G > 3 ? 3 : 0]);
+            float gi = sigmoidf_(xv[0] + rec[0]);
+            float gf = sigmoidf_(xv[G > 1 ? 1 : 0] + rec[G > 1 ? 1 : 0]);
+            float gg = tanhf_(xv[G > 2 ? 2 : 0] + rec[G > 2 ? 2 : 0]);
+            float go = sigmoidf_(xv[G > 3 ? 3 : 0] + rec[G > 3 ? 3 : 0]);
             float *cst = p.cbuf + ((size_t)dir * B + b) * H + unit;
             float cprev = p.step > 0 ? *cst : 0.f;
             float c = gf * cprev + gi * gg;
@@ -145,15 +157,15 @@ __global__ void __launch_bounds__(RNN_THREADS) rnn_fwd_step_kernel(StepArgs p) {
         } else if (CELL == CTCASR_CELL_GRU) {
             // cuDNN GRU: n = tanh(W_n x + b_Wn + r * (R_n h + b_Rn)); h = (1 - z) n + z h_prev
             const float hp = p.step > 0 ? hprev[hoff] : 0.f;
-            const float gr_ = sigmoidf_(xw[0] + rec[0]);
-            const float gz = sigmoidf_(xw[H] + rec[G > 1 ? 1 : 0]);
+            const float gr_ = sigmoidf_(xv[0] + rec[0]);
+            const float gz = sigmoidf_(xv[G > 1 ? 1 : 0] + rec[G > 1 ? 1 : 0]);
             const float q = rec[G > 2 ? 2 : 0] + p.b_hh[(size_t)dir * 3 * H + 2 * H + unit];
-            const float gn = tanhf_(xw[2 * H] + gr_ * q);
+            const float gn = tanhf_(xv[G > 2 ? 2 : 0] + gr_ * q);
             h = (1.f - gz) * gn + gz * hp;
             float *rs = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
             rs[0] = gr_; rs[H] = gz; rs[2 * H] = gn; rs[3 * H] = q;
         } else {
-            float pre = xw[0] + rec[0];
+            float pre = xv[0] + rec[0];
             h = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf_(pre);
         }
         hnext[hoff] = h;
@@ -271,9 +283,9 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
 size_t prnn_sync_bytes();
 size_t prnn_error_offset();
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
-int prnn_fwd(int cell, const float *xw, const float *w_hh, const int32_t *seq_len, int T, int B,
-             int H, float *y, float *gates, float *cells, void *sync, float *carry, int step_begin,
-             int step_end, int flags, hipStream_t s);
+int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
+             const int32_t *seq_len, int T, int B, int H, float *y, float *gates, float *cells,
+             void *sync, float *carry, int step_begin, int step_end, int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
              float *dxw, void *sync, float *carry, int step_begin, int step_end, int flags,
@@ -312,14 +324,16 @@ static int rnn_check(int cell, int T, int B, int H) {
 // state between them (h through the exchange buffer / state ping-pong, c in the carry) stays in
 // the workspace.  After a launch, y of the steps it covered is final: their share of the NEXT
 // layer's input projection can run on another stream beside the following launch.
-extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh,
-                                    const float *b_hh_n, const int32_t *seq_len, int T, int B,
+extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_bias,
+                                    const float *w_hh, const float *b_hh_n,
+                                    const int32_t *seq_len, int T, int B,
                                     int H, float *y, void *reserve, void *workspace,
                                     size_t workspace_bytes, int step_begin, int step_end,
                                     int flags, ctcasr_stream_t stream) {
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
-    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP)) return CTCASR_ERR_BAD_ARGUMENT;
+    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER))
+        return CTCASR_ERR_BAD_ARGUMENT;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
     if (cell == CTCASR_CELL_GRU && !b_hh_n) return CTCASR_ERR_BAD_ARGUMENT;
@@ -332,9 +346,9 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh
     p.cells = p.gates + (size_t)T * B * 2 * 4 * H;
     p.hbuf = reinterpret_cast<float *>(workspace);
     p.cbuf = p.hbuf + (size_t)4 * B * H;
-    p.T = T; p.B = B; p.H = H; p.b_hh = b_hh_n;
+    p.T = T; p.B = B; p.H = H; p.b_hh = b_hh_n; p.xw_bias = xw_bias;
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
-        return prnn_fwd(cell, xw, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
+        return prnn_fwd(cell, xw, xw_bias, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
                         step_begin, step_end, flags, s);
     if (seq_len && step_begin == 0 &&
@@ -356,10 +370,12 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh
     return ctcasr_launch_status();
 }
 
-extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
-                              const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
-                              void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
-    return ctcasr_rnn_fwd_steps(cell, xw, w_hh, b_hh_n, seq_len, T, B, H, y, reserve, workspace,
+extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
+                              const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
+                              float *y, void *reserve, void *workspace, size_t workspace_bytes,
+                              ctcasr_stream_t stream) {
+    return ctcasr_rnn_fwd_steps(cell, xw, xw_bias, w_hh, b_hh_n, seq_len, T, B, H, y, reserve,
+                                workspace,
                                 workspace_bytes, 0, T, CTCASR_RNN_DEFAULT, stream);
 }
 
@@ -377,7 +393,8 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     (void)b_hh_n; (void)db_hh_n;   // the GRU bias gradient is the column sum of drec (caller)
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
-    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP)) return CTCASR_ERR_BAD_ARGUMENT;
+    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER))
+        return CTCASR_ERR_BAD_ARGUMENT;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
@@ -440,7 +457,11 @@ extern "C" int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, in
                  prnn_error_offset();
     if (hipMemcpy(&err, word, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
-    if (err && hipMemset(word, 0, sizeof(err)) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    // after a time-out the arrival counters are in an undefined state: start over with clean
+    // barrier words (this also clears the time-out word)
+    if (err && hipMemset(reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), 0,
+                         prnn_sync_bytes()) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
     return err ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
 }
 

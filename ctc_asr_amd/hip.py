@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libctcasr.so')
 
 ABI_VERSION = 2
-RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP = 0, 1, 2      # `flags` of rnn_fwd / rnn_bwd
+RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP, RNN_ONE_BARRIER = 0, 1, 2, 4   # rnn_fwd/bwd `flags`
 CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
 CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}
 
@@ -41,9 +41,9 @@ SIGNATURES = {
     'ctcasr_rnn_persistent_supported': (_c_int, [_c_int] * 4),
     'ctcasr_rnn_poll_error': (_c_int, [_c_p, _c_sz] + [_c_int] * 4 + [_c_p]),
     'ctcasr_rnn_gru_drec_offset': (_c_sz, [_c_int] * 3),
-    'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
+    'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
-    'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 3 + [_c_p] * 3 +
+    'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 3 +
                              [_c_sz, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 +
                              [_c_sz, _c_int, _c_int, _c_int, _c_p]),
@@ -309,13 +309,14 @@ def rnn_workspace(cell, num_steps, batch, hidden, device):
 
 @_on_tensor_device
 def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None,
-            steps=None, flags=RNN_DEFAULT):
+            steps=None, flags=RNN_DEFAULT, xw_bias=None):
     """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace).
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_fwd_steps`): cut
     a pass into calls covering 0..T in ascending order, passing the same ``y``, ``reserve`` and
     ``workspace`` to each.  ``flags``: RNN_DEFAULT / RNN_HALF_CHIP / RNN_WHOLE_CHIP (which
-    variant of the persistent kernel runs - a per-call choice, no process-wide state)."""
+    variant of the persistent kernel runs - a per-call choice, no process-wide state).
+    ``xw_bias`` f32[2*G*H] (optional) is added to xw inside the kernel."""
     num_steps, batch = xw.shape[0], xw.shape[1]
     hidden = w_hh.shape[2]
     dev = xw.device
@@ -331,7 +332,8 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
         workspace = rnn_workspace(cell, num_steps, batch, hidden, dev)
     with _Timed('rnn_fwd'):
       _check(load().ctcasr_rnn_fwd_steps(
-        CELL_IDS[cell], _dev(xw, name='xw'), _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
+        CELL_IDS[cell], _dev(xw, name='xw'), _dev(xw_bias, name='xw_bias'),
+        _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
         _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
         _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
         workspace.numel(), int(begin), int(end), int(flags), _stream()), 'rnn_fwd')

@@ -195,8 +195,8 @@ def xw_pipeline_plan(t_out, chunks):
     [bounds[c], bounds[c+1]); after launch c the forward direction's y is final for the TIMES
     [lo, hi) and the backward direction's for [T'-hi, T'-lo), and each contributes its half-K
     product to those rows of the next layer's xw.  Returns (bounds, plan): plan[c] is a list of
-    (direction, t_begin, t_end, first) GEMMs, ``first`` = the rows are written with the bias
-    (no read) instead of accumulated into.  Every time index is initialised exactly once and
+    (direction, t_begin, t_end, first) GEMMs, ``first`` = the rows are written
+    (plain product, no read) instead of accumulated into.  Every time index is initialised exactly once and
     before anything is accumulated into it, for any T' and chunk count (the cuts are symmetric,
     so for even T' the two directions' ranges coincide and nothing is split)."""
     bounds = [t_out * c // chunks for c in range(chunks + 1)]
@@ -330,7 +330,6 @@ class CTCModel:
         # weight-gradient GEMMs run on a low-priority side stream so that they fill the half of
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
-        self.fuse_xw_bias = os.environ.get('CTCASR_FUSE_XW_BIAS', '1') == '1'
         # the 11x21 / stride (1,2) convolutions over 32 input channels (layers 2 and 3 of the
         # reference's stack) run on this package's own implicit-GEMM kernels (forward and data
         # gradient; any T, no padded intermediates)
@@ -456,16 +455,14 @@ class CTCModel:
                 seeds[0] = self._next_seed()
                 x = hip.dropout(x, rnn_rate, seeds[0])
             w_ih = p['rnn{}/w_ih'.format(i)].view(2 * gates * hidden, -1)
-            # biases that are plain additive terms are folded into xw (LSTM / RNN: both vectors;
-            # GRU: everything but the recurrent bias of the candidate gate) - as the GEMM's bias
-            # epilogue, which saves a read-modify-write pass over xw
+            # biases that are plain additive terms (LSTM / RNN: both vectors; GRU: everything but
+            # the recurrent bias of the candidate gate) are added to xw INSIDE the recurrence
+            # kernel (`xw_bias`): the GEMM then is a plain product without a bias epilogue
+            # (3.93 instead of 4.16 ms per layer at C3) and no pass over xw is spent on it
             if pipelined_xw is not None:       # built beside the previous layer's recurrence
                 xw, pipelined_xw = pipelined_xw, None
-            elif self.fuse_xw_bias:
-                xw = torch.addmm(self._rnn_bias(i), x.view(t_out * batch, -1), w_ih.t())
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
-                hip.bias_act_fwd(xw, self._rnn_bias(i), 0.0)
             if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
                 y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
                     i, xw, t_out, batch, hidden, gates, workspace)
@@ -473,7 +470,7 @@ class CTCModel:
                 y, reserve, workspace = hip.rnn_fwd(
                     cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
                     rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,
-                    workspace=workspace)
+                    workspace=workspace, xw_bias=self._rnn_bias(i))
             layer_in.append(x)
             layer_out.append(y)
             reserves.append(reserve)
@@ -542,7 +539,7 @@ class CTCModel:
         reserve = hip._workspace(hip.rnn_reserve_bytes(cell, t_out, batch, hidden), dev)
         xw_next = torch.empty((t_out * batch, 2 * gh), dtype=torch.float32, device=dev)
         w_next = p[nxt + '/w_ih'].view(2 * gh, 2 * hidden)
-        bias_next = self._rnn_bias(layer + 1)
+        bias_here = self._rnn_bias(layer)
         w_halves = [w_next[:, d * hidden:(d + 1) * hidden].t() for d in (0, 1)]
         bounds, plan = xw_pipeline_plan(t_out, self.fwd_chunks)
 
@@ -552,7 +549,7 @@ class CTCModel:
                 src = y[run:end, :, d * hidden:(d + 1) * hidden] \
                     .reshape((end - run) * batch, hidden)
                 if first:
-                    torch.addmm(bias_next, src, w_halves[d], out=rows)
+                    torch.mm(src, w_halves[d], out=rows)
                 else:
                     rows.addmm_(src, w_halves[d])
 
@@ -561,7 +558,7 @@ class CTCModel:
             lo, hi = bounds[c], bounds[c + 1]
             hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
                         reserve=reserve, workspace=workspace, steps=(lo, hi),
-                        flags=hip.RNN_HALF_CHIP)
+                        flags=hip.RNN_HALF_CHIP, xw_bias=bias_here)
             if c + 1 < chunks:
                 ready = torch.cuda.Event()
                 ready.record(main)

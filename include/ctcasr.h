@@ -109,7 +109,9 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
  * BasicRNNCell (asr/model.py:171-183).  The input projection W x + b_W (+ b_R where it commutes)
  * is a plain GEMM done by the caller; this entry point runs h_t = cell(xw_t, h_{t-1}).
  *   cell     CTCASR_CELL_*; G = gates per unit (LSTM 4: i,f,g,o; GRU 3: r,z,n; RNN 1)
- *   xw       [T, B, 2, G*H] pre-computed input projections incl. bias, both directions
+ *   xw       [T, B, 2, G*H] pre-computed input projections, both directions
+ *   xw_bias  [2, G*H] or NULL: added to xw inside the kernel (b_W, + b_R where it commutes) - the
+ *            caller's GEMM then needs no bias epilogue; NULL when xw already includes the bias
  *   w_hh     [2, G*H, H] recurrent weights (cuDNN / torch layout, gate-major rows)
  *   b_hh_n   GRU only (NULL otherwise): the recurrent bias b_hh [2, 3H]; its candidate-gate third
  *            is applied inside r * (R_n h + b_Rn), the r / z thirds must be folded into xw
@@ -119,8 +121,10 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
  *   y        [T, B, 2H]  = [h_fw || h_bw]
  *   reserve  activations kept for the backward pass, ctcasr_rnn_reserve_bytes()
  *   workspace ctcasr_rnn_workspace_bytes() (state ping-pong, grid-barrier words, exchange
- *            buffer).  ZERO-FILL IT ONCE before its first use: it holds the sticky time-out word
- *            that ctcasr_rnn_poll_error reads; launches never clear that word.
+ *            buffer).  ZERO-FILL IT ONCE before its first use with a given (B, H): the launches
+ *            themselves issue no memset - the arrival counters are reset by the kernel that used
+ *            them, the all-zero block of the exchange buffer is never written, and the time-out
+ *            word is sticky until ctcasr_rnn_poll_error reads it.
  * bwd: dy [T,B,2H] -> dxw [T,B,2,G*H] (gradient w.r.t. xw, which is also what the weight
  * gradients are GEMMs of), w_hh_t = w_hh transposed to [2, H, G*H] (caller keeps it current;
  * ctcasr_transpose_batched does it).  GRU: the recurrent path differs from dxw in the candidate
@@ -129,9 +133,9 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
 size_t ctcasr_rnn_gru_drec_offset(int T, int B, int H);
 size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H);
 size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H);
-int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
-                   const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
-                   void *workspace, size_t workspace_bytes, ctcasr_stream_t stream);
+int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
+                   const float *b_hh_n, const int32_t *seq_len, int T, int B, int H, float *y,
+                   void *reserve, void *workspace, size_t workspace_bytes, ctcasr_stream_t stream);
 /* Steps [step_begin, step_end) of the forward recurrence only; ctcasr_rnn_fwd == (0, T).  A pass may
  * be cut into launches covering 0..T in ascending order on the same workspace and reserve: after
  * a launch, y of the steps it covered is final (time s of the forward direction, time
@@ -144,14 +148,20 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *w_hh, const float *b_
  *   CTCASR_RNN_HALF_CHIP   128 CUs (64 workgroups per direction, weights split between LDS and
  *                          registers), so that GEMMs on another stream can run beside it
  *   CTCASR_RNN_WHOLE_CHIP  all 256 CUs
+ * Batches of 17..32 rows are two independent 16-row tiles: on the whole chip each tile runs as
+ * its own group of half-chip workgroups, on half of the chip as a second chain of 4 waves inside
+ * every workgroup - each tile with its own barrier, results identical to one tile at a time.
  * Shapes without the requested variant, and the streaming kernels, ignore it. */
 #define CTCASR_RNN_DEFAULT 0
 #define CTCASR_RNN_HALF_CHIP 1
 #define CTCASR_RNN_WHOLE_CHIP 2
-int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *w_hh, const float *b_hh_n,
-                         const int32_t *seq_len, int T, int B, int H, float *y, void *reserve,
-                         void *workspace, size_t workspace_bytes, int step_begin, int step_end,
-                         int flags, ctcasr_stream_t stream);
+/* batches of 17..32 rows: the round-1 kernels (both 16-row tiles behind ONE barrier per step)
+ * instead of the default two independent chains per workgroup - for A/B measurements */
+#define CTCASR_RNN_ONE_BARRIER 4
+int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_bias, const float *w_hh,
+                         const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
+                         float *y, void *reserve, void *workspace, size_t workspace_bytes,
+                         int step_begin, int step_end, int flags, ctcasr_stream_t stream);
 /* 1 when the LDS-resident single-launch kernels cover (cell, T, B, H) on this device, else the
  * per-step streaming kernels run.  CTCASR_RNN_MODE=stream in the environment forces the latter. */
 int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);

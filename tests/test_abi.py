@@ -55,10 +55,11 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.ctcasr_log_softmax_fwd(None, None, 4, 29, None) == -1
     assert lib.ctcasr_ctc_loss_fwd_bwd(None, None, None, None, 5, 2, 29, 28, 3, 1.0, None, None,
                                        None, None, 0, None) == -1
-    assert lib.ctcasr_rnn_fwd(2, None, None, None, None, 0, 2, 64, None, None, None, 0, None) == -1
+    assert lib.ctcasr_rnn_fwd(2, None, None, None, None, None, 0, 2, 64, None, None, None, 0,
+                              None) == -1
     # unknown flag bits of the step-range entry points are an argument error
-    assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, 8, 2, 64, None, None, None, 0, 0, 8,
-                                    64, None) == -1
+    assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
+                                    0, 0, 8, 64, None) == -1
     # the only process-wide option is the profiling switch
     assert lib.ctcasr_set_option(b'rnn_fwd_half_chip', 1) == -1
     assert lib.ctcasr_set_option(b'rnn_kernel_events', 0) == 0

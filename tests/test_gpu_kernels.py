@@ -232,12 +232,36 @@ def test_streaming_kernels_on_persistent_shapes(hip, cell, dims, monkeypatch):
     monkeypatch.setenv('CTCASR_RNN_MODE', 'stream')
     assert not hip.rnn_persistent_supported(cell, num_steps, batch, hidden)
     y_s, reserve_s, ws_s = hip.rnn_fwd(cell, xw, w_hh)
-    dxw_s = hip.rnn_bwd(cell, dy, y_s, w_hh_t, reserve_s, workspace=ws_s)
+    # (the plain cells differentiate through y itself: hand both backward passes the same y, or
+    # a ReLU output that is 0 on one path and 1e-7 on the other flips a whole gradient entry)
+    dxw_s = hip.rnn_bwd(cell, dy, y_p if cell != 'lstm' else y_s, w_hh_t, reserve_s,
+                        workspace=ws_s)
     torch.cuda.synchronize()
     monkeypatch.delenv('CTCASR_RNN_MODE')
     assert float((y_s - y_p).abs().max()) < 1e-5
     assert float((dxw_s - dxw_p).abs().max()) < 1e-4
     assert float((dxw_w - dxw_p).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('cell,dims', [('lstm', (7, 16, 1024)), ('lstm', (7, 27, 1024)),
+                                       ('gru', (6, 5, 128)), ('rnn_tanh', (6, 20, 2048)),
+                                       ('rnn_relu', (5, 3, 64))])
+def test_rnn_fwd_adds_the_input_projection_bias_in_the_kernel(hip, cell, dims):
+    """``xw_bias`` (b_W + b_R where it commutes) added inside the recurrence kernels - persistent
+    and streaming - equals a forward pass over xw + bias."""
+    num_steps, batch, hidden = dims
+    gates = onn.GATES[cell]
+    rng = np.random.default_rng(29)
+    xw = (rng.normal(size=(num_steps, batch, 2, gates * hidden)) * 0.5).astype(np.float32)
+    bias = (rng.normal(size=(2, gates * hidden)) * 0.5).astype(np.float32)
+    w_hh = _t((rng.normal(size=(2, gates * hidden, hidden)) / np.sqrt(hidden)).astype(np.float32))
+    b_hh = _t((rng.normal(size=(2, gates * hidden)) * 0.3).astype(np.float32)) \
+        if cell == 'gru' else None
+    y_ref, _, ws = hip.rnn_fwd(cell, _t(xw + bias[None, None]), w_hh, b_hh_n=b_hh)
+    y_got, _, _ = hip.rnn_fwd(cell, _t(xw), w_hh, b_hh_n=b_hh, xw_bias=_t(bias.reshape(-1)),
+                              workspace=ws)
+    hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
+    assert float((y_got - y_ref).abs().max()) < 1e-6
 
 
 def test_rnn_timeout_word_is_sticky_until_polled(hip):
@@ -252,7 +276,7 @@ def test_rnn_timeout_word_is_sticky_until_polled(hip):
     y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh)
     hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
     state = (6 * batch * hidden * 4 + 255) // 256 * 256
-    error_word = state + 2 * 8 * 64 * 4          # SyncWords: group_cnt[2][8][64] then `error`
+    error_word = state + 2 * 2 * 8 * 64 * 4 + 2 * 2 * 64 * 4   # SyncWords: counters, done, `error`
     ws[error_word:error_word + 4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device=DEV)
     hip.rnn_fwd('lstm', xw, w_hh, y=y, reserve=reserve, workspace=ws)            # another "layer"
     dy = torch.ones_like(y)

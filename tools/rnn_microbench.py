@@ -23,6 +23,9 @@ def main():
     # CTCASR_FWD_HALF: forward recurrence on half of the chip (default: whole)
     bwd_flags = hip.RNN_WHOLE_CHIP if os.environ.get('CTCASR_FULL') else hip.RNN_DEFAULT
     fwd_flags = hip.RNN_HALF_CHIP if os.environ.get('CTCASR_FWD_HALF') else hip.RNN_DEFAULT
+    if os.environ.get('CTCASR_ONE_BARRIER'):   # B > 16: round-1 kernels (one barrier for both tiles)
+        bwd_flags |= hip.RNN_ONE_BARRIER
+        fwd_flags |= hip.RNN_ONE_BARRIER
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
@@ -46,11 +49,18 @@ def main():
         print('{}: {:.3f} ms per call, {:.2f} us per time step'.format(name, ms, ms * 1e3 / T))
         if os.environ.get('CTCASR_RNN_PROF'):
             state = (6 * B * H * 4 + 255) // 256 * 256
-            base = state + 4096 + 256 + (0 if name == "fwd" else 32)
+            base = state + 9216 + 256 + (0 if name == "fwd" else 32)   # SyncWords: counters, error
             words = ws[base: base + 32].cpu().numpy().view(np.uint64)
             labels = ['wait', 'loads+mfma', 'reduce+gates+publish', 'drain+arrive']
             print('  wg0 phases (us/step): ' + ', '.join(
                 '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
+            if name == 'fwd' and B > 16:
+                more = ws[state + 9216 + 256: state + 9216 + 256 + 128].cpu().numpy() \
+                    .view(np.uint64).astype(np.float64) / 100.0 / T
+                print('  chain 0: {}  (partials+barrier inside phase 2: {:.2f})'.format(
+                    np.round(more[0:4], 2).tolist(), more[4]))
+                print('  chain 1: {}  (partials+barrier inside phase 2: {:.2f})'.format(
+                    np.round(more[8:12], 2).tolist(), more[12]))
             if name == 'fwd':
                 every = ws[base + 128: base + 128 + 256 * 32].cpu().numpy().view(np.uint64) \
                     .reshape(256, 4).astype(np.float64) / 100.0 / T

@@ -14,9 +14,10 @@ def main():
     for rank in (0, 1):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE='2',
                    MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', CTCASR_DIST_BACKEND='gloo',
-                   CTCASR_RNN_MODE='stream')
+                   CTCASR_RNN_MODE='stream', CTCASR_BENCH_SHARE_GPU='1')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus',
-                                       '2', '--steps', '3', '--warmup', '2'] + sys.argv[1:],
+                                       '2', '--steps', '3', '--warmup', '2', '--workload', 'c2']
+                                      + sys.argv[1:],
                                       env=env))
     codes = [p.wait(timeout=600) for p in procs]
     print('exit codes', codes)

@@ -1,80 +1,136 @@
 #!/usr/bin/env python
-"""Assemble profiles/r01_final_c2_kernel_trace_and_pmc.md from the small summaries that
-tools/prof_final.sh leaves under gpurun_out/final/ (bench line, kernel trace, PMC passes,
-timeline)."""
+"""Assemble a committed profile summary from what tools/prof_round.sh leaves under gpurun_out/:
+
+    python tools/make_profile_md.py gpurun_out/r02/prof_c3_a c3 profiles/r02_c3_kernel_trace_and_pmc.md
+
+and record the PMC traffic of the dominant recurrence kernels in profiles/pmc_traffic.json (the
+file bench.py reads ``roofline.traffic`` from), keyed by workload, pass and steps per launch.
+"""
 import json
 import os
+import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, 'gpurun_out', 'final')
+sys.path.insert(0, ROOT)
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
-def read(name):
-    with open(os.path.join(O, name)) as handle:
-        return handle.read()
-
-
-def pmc_value(table, kernel):
+def pmc_rows(table):
+    """[(kernel, counter, dispatches, avg)] of a prof_summary.py --pmc table."""
+    rows = []
     for line in table.splitlines():
-        if kernel in line:
-            return float(line.split('|')[-2])
+        cells = [c.strip() for c in line.strip().strip('|').split('|')]
+        if len(cells) == 4 and cells[2].isdigit():
+            rows.append((cells[0].strip('`'), cells[1], int(cells[2]), float(cells[3])))
+    return rows
+
+
+def value(rows, kernel, counter):
+    for name, ctr, _, avg in rows:
+        if kernel in name and ctr == counter:
+            return avg
     return None
 
 
-def main():
-    bench = read('bench.json').strip().splitlines()[-1]
-    d = json.loads(bench)
-    kt_bench = json.loads(read('kt_bench.json').strip().splitlines()[-1])
-    fetch, write = read('fetch.md'), read('write.md')
+def algorithmic_bytes(which, batch, hidden, gates, steps):
+    """HBM bytes one launch of the persistent recurrence must move (both directions), fp32."""
+    row = batch * hidden * 4
+    if which == 'rnn_bwd':       # dy, gates, c_t + c_t-1 in; dxw + exchange (dgates) out
+        per = row * (1 + gates + (2 if gates == 4 else 1)) + 2 * gates * row
+    else:                        # xw in; y, reserve (gates + c), exchange (h) out
+        per = gates * row + row * (1 + (gates + 1 if gates == 4 else 0) + 1)
+    return 2 * steps * per + 2 * gates * hidden * hidden * 4
+
+
+def main(src, workload, out_md):
+    import bench
+    read = lambda name: open(os.path.join(src, name)).read()
+    line = json.loads(read('bench.json').strip().splitlines()[-1])
+    kt_line = json.loads(read('kt_bench.json').strip().splitlines()[-1])
+    fetch, write, sq = pmc_rows(read('fetch.md')), pmc_rows(read('write.md')), pmc_rows(read('sq.md'))
+    filters, layers, hidden, dense, batch, seconds, cell = bench.WORKLOADS[workload]
+    gates = {'lstm': 4, 'gru': 3}.get(cell, 1)
+    t_out = line['config']['ctc_steps']
     timeline = [l for l in read('timeline.txt').splitlines()
-                if not any(k in l for k in ('elementwise_kernel', 'fillBuffer', 'copyBuffer',
-                                            'SubTensor', 'batched_transpose',
-                                            'vectorized_elementwise', 'reduce_kernel'))]
-    f_kb, w_kb = pmc_value(fetch, 'prnn_bwd_kernel'), pmc_value(write, 'prnn_bwd_kernel')
-    out = ['# r01 final: C2 bench (DS2 2-conv + 2xBiLSTM-1024, B=16, 10 s) - rocprofv3 kernel '
-           'trace + PMC\n',
-           'All on one MI355X through gpurun; counters in their own passes with `--kernel-trace` '
-           'only (`tools/prof_final.sh`):\n```\n'
-           'rocprofv3 --kernel-trace --stats -d /tmp/pf/kt -o c2 -- python bench.py --steps 10 '
-           '--warmup 3 --no-cpu-baseline\n'
-           'rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf/fetch -o c2 -- python bench.py '
-           '--steps 2 --warmup 3 --no-cpu-baseline\n'
-           'rocprofv3 --pmc WRITE_SIZE --kernel-trace ...   (same)\n'
+                if not any(k in l for k in ('elementwise_kernel', 'copyBuffer', 'SubTensor',
+                                            'batched_transpose', 'vectorized_elementwise',
+                                            'reduce_kernel', 'transpose_kernel'))]
+    entries, traffic_text = [], []
+    for which, pattern in (('rnn_bwd', 'prnn_bwd_kernel'), ('rnn_fwd', 'prnn_fwd_kernel')):
+        f_kb, w_kb = value(fetch, pattern, 'FETCH_SIZE'), value(write, pattern, 'WRITE_SIZE')
+        if f_kb is None or w_kb is None:
+            continue
+        # launches per layer-pass as the model cuts them (bench's own roofline for the dominant
+        # pass, the model defaults for the other)
+        dominant = line['roofline']['kernel'].startswith('prnn_' + which[4:])
+        steps = round(line['roofline']['algorithmic_flops_per_launch'] /
+                      (2.0 * 2 * batch * hidden * gates * hidden)) if dominant else t_out
+        alg = algorithmic_bytes(which, batch, hidden, gates, steps)
+        kernel = next(n for n, c, _, _ in fetch if pattern in n)
+        busy = value(sq, pattern, 'SQ_VALU_MFMA_BUSY_CYCLES')
+        gui = value(sq, pattern, 'GRBM_GUI_ACTIVE')
+        entries.append({'workload': workload, 'pass': which, 'steps_per_launch': steps,
+                        'kernel': kernel, 'fetch_kb': f_kb, 'write_kb': w_kb,
+                        'algorithmic_bytes': alg, 'source': os.path.relpath(out_md, ROOT)})
+        raw, corrected = (f_kb + w_kb) * 1024, (2 * f_kb + w_kb) * 1024
+        text = ('`{}` (one launch = {} time steps x 2 directions): FETCH_SIZE {:.0f} KB + '
+                'WRITE_SIZE {:.0f} KB = {:.0f} MB as reported; with the gfx950 FETCH_SIZE x2 '
+                'correction (MI355X_MICROARCH.md, section HBM) {:.0f} MB.  Algorithmic HBM bytes '
+                'of such a launch: {:.0f} MB -> traffic / algorithmic = {:.2f} (corrected), '
+                '{:.2f} (raw).'.format(kernel[:60], steps, f_kb, w_kb, raw / 1e6, corrected / 1e6,
+                                       alg / 1e6, corrected / alg, raw / alg))
+        if busy and gui:
+            # GRBM_GUI_ACTIVE = cycles the kernel ran; busy cycles are summed over SIMDs
+            cus = 256 if 'fwd' in which and batch > 16 else (256 if 'fwd' in which else 128)
+            text += ('  MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES {:.0f} M / (GRBM_GUI_ACTIVE {:.1f} M '
+                     'x {} CUs x 4 SIMDs) = {:.0f} % of the CUs the kernel occupies.'.format(
+                         busy / 1e6, gui / 1e6, cus, 100.0 * busy / (gui * cus * 4)))
+        traffic_text.append(text)
+
+    out = ['# {}: bench workload `{}` - rocprofv3 kernel trace + PMC\n'.format(
+               os.path.basename(out_md)[:-3], workload),
+           line['config']['workload'] + '.  All on one MI355X through gpurun; counters in their '
+           'own passes with `--kernel-trace` only (`tools/prof_round.sh {} <out>`):\n```\n'
+           'rocprofv3 --kernel-trace --stats ... -- python bench.py --workload {w} --steps 4 '
+           '--warmup 2 --no-cpu-baseline --no-other-workloads\n'
+           'rocprofv3 --pmc FETCH_SIZE --kernel-trace ...   (--steps 2 --warmup 2)\n'
+           'rocprofv3 --pmc WRITE_SIZE --kernel-trace ...\n'
            'rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA '
            'SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE '
-           '--kernel-trace ...\n'
-           'python tools/prof_summary.py <db> 45 5        # steady state = last 5 training steps\n'
-           'python tools/prof_summary.py --pmc <db>\n'
-           'python tools/prof_summary.py --timeline <db>  # launch order per queue, last step\n'
-           '```\n',
-           'Unprofiled bench line of the same build (`python bench.py --steps 10 --warmup 3`, '
-           'incl. cpu_baseline):\n```\n' + bench + '\n```\n',
-           'Dominant kernel, HIP event pairs recorded by the library right around each launch '
+           '--kernel-trace ...\n```\n'.format(workload, w=workload),
+           'Unprofiled bench line of the same build (`--steps 8 --warmup 3`):\n```\n' +
+           json.dumps(line) + '\n```\n',
+           'Dominant kernel, HIP event pairs recorded by the library around each launch '
            '(`rnn_kernel_events`): **{} us** per launch unprofiled, {} us in the profiled run '
-           '(its kernel trace: `prnn_bwd_kernel` row below).\n'.format(
-               d['roofline']['avg_launch_us'], kt_bench['roofline']['avg_launch_us']),
+           '(kernel trace row below).\n'.format(line['roofline']['avg_launch_us'],
+                                                kt_line['roofline']['avg_launch_us']),
            '## Kernel trace, steady state\n\n' + read('kt.md'),
-           '\n## PMC FETCH_SIZE (KB per dispatch, as reported)\n\n' + fetch,
-           '\n## PMC WRITE_SIZE (KB per dispatch, as reported)\n\n' + write]
-    if f_kb and w_kb:
-        out.append("""
-`roofline.traffic` for `prnn_bwd_kernel` (one launch = 167 of 500 time steps) = ({:.0f} + {:.0f}) KB
-x 1024 = {:.0f} MB.  Algorithmic HBM bytes of such a launch, per step and direction (B = 16,
-H = 1024, fp32): read dy 64 KB + gates 256 KB + cells (c_t, c_t-1) 128 KB, write dxw 256 KB +
-exchange (dgates) 256 KB = 960 KB; x 2 directions x 167 steps = 321 MB, + 2 x 16 MB recurrent
-weights loaded once = 353 MB.  The difference is the exchange buffer, which all 64 workgroups of a
-direction re-read every step (16 MB per step and direction at the L2s; what misses L2 shows up as
-FETCH_SIZE).  The kernel is latency-, not bandwidth-bound (DESIGN.md section 4.1).
-""".format(f_kb, w_kb, (f_kb + w_kb) * 1024 / 1e6))
-    out.append('\n## PMC SQ counters\n\n' + read('sq.md'))
-    out.append('\n## Timeline of the last training step (queue 1 = main stream, queue 2 = '
-               'weight-gradient side stream; small elementwise kernels omitted)\n\n```\n' +
-               '\n'.join(timeline) + '\n```\n')
-    path = os.path.join(ROOT, 'profiles', 'r01_final_c2_kernel_trace_and_pmc.md')
-    with open(path, 'w') as handle:
+           '\n## PMC FETCH_SIZE (KB per dispatch, as reported)\n\n' + read('fetch.md'),
+           '\n## PMC WRITE_SIZE (KB per dispatch, as reported)\n\n' + read('write.md'),
+           '\n## Traffic and MFMA-busy of the recurrence kernels\n\n' + '\n\n'.join(traffic_text) +
+           '\n\nThe excess over the algorithmic bytes is the exchange buffer: every workgroup of a '
+           'direction re-reads the whole published block each step; what misses the XCD L2s shows '
+           'up as FETCH_SIZE (Infinity-Cache hits included).  The kernel is bound by the per-CU '
+           'load path and the exchange latency, not by HBM bandwidth (DESIGN.md section 4.1).\n',
+           '\n## PMC SQ counters\n\n' + read('sq.md'),
+           '\n## Timeline of the last training step (queue 1 = main stream, queue 2 = '
+           'weight-gradient side stream; small elementwise kernels omitted)\n\n```\n' +
+           '\n'.join(timeline) + '\n```\n']
+    with open(out_md, 'w') as handle:
         handle.write('\n'.join(out))
-    print(path, f_kb, w_kb)
+    table = {'entries': []}
+    if os.path.exists(TRAFFIC_JSON):
+        table = json.load(open(TRAFFIC_JSON))
+    keep = [e for e in table['entries']
+            if not any(e['workload'] == n['workload'] and e['pass'] == n['pass'] for n in entries)]
+    table['entries'] = keep + entries
+    table['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KB per dispatch as reported; '
+                     'written by tools/make_profile_md.py, read by bench.py (roofline.traffic)')
+    with open(TRAFFIC_JSON, 'w') as handle:
+        json.dump(table, handle, indent=1)
+    print(out_md, [(e['pass'], e['steps_per_launch'], e['fetch_kb'], e['write_kb']) for e in entries])
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

@@ -81,11 +81,12 @@ def main(src, workload, out_md):
                 '{:.2f} (raw).'.format(kernel[:60], steps, f_kb, w_kb, raw / 1e6, corrected / 1e6,
                                        alg / 1e6, corrected / alg, raw / alg))
         if busy and gui:
-            # GRBM_GUI_ACTIVE = cycles the kernel ran; busy cycles are summed over SIMDs
-            cus = 256 if 'fwd' in which and batch > 16 else (256 if 'fwd' in which else 128)
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = cycles the kernel ran (at the clock
+            # it really had); busy cycles are summed over the SIMDs of the CUs it occupies
+            cus = 256 if which == 'rnn_fwd' else 128
             text += ('  MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES {:.0f} M / (GRBM_GUI_ACTIVE {:.1f} M '
-                     'x {} CUs x 4 SIMDs) = {:.0f} % of the CUs the kernel occupies.'.format(
-                         busy / 1e6, gui / 1e6, cus, 100.0 * busy / (gui * cus * 4)))
+                     '/ 8 XCDs x {} CUs x 4 SIMDs) = {:.0f} % of the CUs the kernel occupies.'
+                     .format(busy / 1e6, gui / 1e6, cus, 100.0 * busy / (gui / 8 * cus * 4)))
         traffic_text.append(text)
 
     out = ['# {}: bench workload `{}` - rocprofv3 kernel trace + PMC\n'.format(

@@ -53,6 +53,8 @@ WORKLOADS = {
     'c3_3conv': ((32, 32, 96), 5, 1024, 2048, 32, 10.0, 'lstm'),
     # the reference's own flag defaults (asr/params.py): 3 convs, 4 x ReLU-RNN-2048, batch 16
     'ref_default': ((32, 32, 96), 4, 2048, 2048, 16, 10.0, 'rnn_relu'),
+    # the reference's best published model (testruns.md: 3c4r2d / 3c5r2d, LSTM cells, 2048 units)
+    'ref_best': ((32, 32, 96), 4, 2048, 2048, 16, 10.0, 'lstm'),
     'tiny': ((8, 8), 1, 128, 128, 4, 2.0, 'lstm'),                # plumbing check
 }
 BASELINE_NAMES = {'c2': 'BASELINE.json configs[1]', 'c3': 'BASELINE.json configs[2]'}

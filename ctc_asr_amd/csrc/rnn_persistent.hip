@@ -73,6 +73,8 @@ struct PArgs {
     float *xchg;           // exchange buffer [T steps][2][K/16 chunks][B][16] (see below)
     const float *bias;     // forward: [2, G*H] added to xw (NULL: none)
     int T, B, H, nwg;      // nwg = workgroups per direction (and chain)
+    int ndir, dir0;        // directions in this launch (2, or 1 when they run one after the other)
+    int chain0;            // first batch tile of this launch
     int s_lo, s_hi;        // backward: this launch runs steps s_hi-1 ... s_lo (a whole pass: 0, T)
     float *carry;          // backward, LSTM: dc [2, B, H] handed from one launch to the next
     int prof;              // record phase timings of workgroup 0
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     // workgroups (each tile on its own CUs, nothing shared but the launch)
     const int chain =
         CHAINS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PRNN_THREADS)
-                   : (int)blockIdx.x / (2 * p.nwg);
+                   : p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
     const int row0 = chain * 16;
     const int lchain = CHAINS > 1 ? chain : 0;      // chain index WITHIN the workgroup (LDS carve)
     float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(float4)) +
@@ -301,14 +303,14 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     // the Infinity Cache is then used by twice as many workgroups of that XCD.  Measured: no
     // difference at B = 16 or 32, forward or backward (4.5 / 7.2 / 6.1 / 11.3 us per step either
     // way), so the plain mapping stays.
-    const int wg = blockIdx.x % (2 * p.nwg);
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
 #if PRNN_XCD_AWARE
     const int xcd = wg & 7, rank = wg >> 3;
-    const int dir = xcd >> 2, slice = rank * 4 + (xcd & 3);
+    const int dir = p.dir0 + (xcd >> 2), slice = rank * 4 + (xcd & 3);    // (ndir = 2 only)
     // arrival counters: two per XCD of the direction
     const int group_size = p.nwg / PRNN_GROUPS, grp = (xcd & 3) * 2 + (rank & 1);
 #else
-    const int dir = wg / p.nwg, slice = wg % p.nwg;
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
 #endif
     const int H = p.H, B = p.B, T = p.T;
@@ -625,7 +627,9 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     constexpr int QA = QW / NT;          // 16-float A chunks per wave
     constexpr int LA = LB / NT;          // A chunks per load batch
     constexpr int CPG = QA / G;          // 16-float chunks per gate within a wave's unit range
-    static_assert(REGW == 0 || !HALF_TILE, "register-resident weights need full tiles");
+    // (register-resident HALF tiles - H = 2048 - spend a register on every lane although lanes
+    // l and l + 8 hold the same value: 8 units x 8192 x 4 B = 256 KB per workgroup is 128 KB of
+    // LDS + 256 registers per lane, which a one-wave-per-SIMD kernel can afford)
     static_assert(!TWO_TILES || (G == 1 && REGW > 0), "two tiles: plain RNN, static slot map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *frag = reinterpret_cast<float4 *>(smem);
@@ -637,7 +641,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     // workgroups (each tile on its own CUs, nothing shared but the launch)
     const int chain =
         CHAINS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PRNN_THREADS)
-                   : (int)blockIdx.x / (2 * p.nwg);
+                   : p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
     const int row0 = chain * 16;
     const int lchain = CHAINS > 1 ? chain : 0;      // chain index WITHIN the workgroup (LDS carve)
     float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * SLOTS * sizeof(float4)) +
@@ -660,14 +664,14 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     // the Infinity Cache is then used by twice as many workgroups of that XCD.  Measured: no
     // difference at B = 16 or 32, forward or backward (4.5 / 7.2 / 6.1 / 11.3 us per step either
     // way), so the plain mapping stays.
-    const int wg = blockIdx.x % (2 * p.nwg);
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
 #if PRNN_XCD_AWARE
     const int xcd = wg & 7, rank = wg >> 3;
-    const int dir = xcd >> 2, slice = rank * 4 + (xcd & 3);
+    const int dir = p.dir0 + (xcd >> 2), slice = rank * 4 + (xcd & 3);    // (ndir = 2 only)
     // arrival counters: two per XCD of the direction
     const int group_size = p.nwg / PRNN_GROUPS, grp = (xcd & 3) * 2 + (rank & 1);
 #else
-    const int dir = wg / p.nwg, slice = wg % p.nwg;
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
 #endif
     const int H = p.H, B = p.B, T = p.T, GH = G * p.H;
@@ -677,7 +681,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     const int half = HALF_TILE ? (lane >> 4) * 8 + (lane & 7) : lane;
 
     float4 wreg[REGW > 0 ? REGW : 1];
-    if (!HALF_TILE || (lane & 15) < 8) {
+    if (!HALF_TILE || (lane & 15) < 8 || REGW > 0) {
         // slot i of this wave: A chunk i / NT of tile i % NT
         const float *wrow = p.w + ((size_t)dir * H + u0 + (lane & (UPB / NT - 1))) * GH +
                             wave * (H / 4) + kq;
@@ -963,7 +967,7 @@ int launch_persistent(K kernel, const PArgs &p, size_t lds, hipStream_t s, int c
                         hipEventCreate(&timed.start) == hipSuccess &&
                         hipEventCreate(&timed.stop) == hipSuccess;
     if (record) (void)hipEventRecord(timed.start, s);
-    kernel<<<2 * p.nwg * tile_groups, PRNN_THREADS * chains, lds, s>>>(p);
+    kernel<<<p.ndir * p.nwg * tile_groups, PRNN_THREADS * chains, lds, s>>>(p);
     if (record) {
         (void)hipEventRecord(timed.stop, s);
         timed.backward = p.dxw != nullptr;
@@ -1003,7 +1007,10 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
     // shapes whose weight slice is 128 KB per CU: LSTM H=1024 (BASELINE configs) and the plain
     // ReLU / tanh RNN at H=2048 (the reference's default model).  B <= 32: two batch tiles keep
     // the reduction scratch next to the weight slice.
-    const bool lstm = cell == CTCASR_CELL_LSTM && H == 1024;
+    // ... and the LSTM at H = 2048 (the reference's best published models, testruns.md): 67 MB of
+    // recurrent weights per direction fit the chip's LDS + registers only one direction at a time,
+    // so its two directions run as two launches of 256 workgroups each.
+    const bool lstm = cell == CTCASR_CELL_LSTM && (H == 1024 || H == 2048);
     const bool rnn = (cell == CTCASR_CELL_RNN_RELU || cell == CTCASR_CELL_RNN_TANH) && H == 2048;
     if (!(lstm || rnn) || B < 1 || B > 32 || T < 1) return 0;
     // the exchange buffer is addressed through a 32-bit buffer descriptor
@@ -1037,6 +1044,7 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
     p.bias = xw_bias;
+    p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H;
     p.s_lo = step_begin; p.s_hi = step_end;
@@ -1051,6 +1059,21 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
                              (size_t)NT_ * 4 * QW_ * 64 * 16 +                                 \
                                  (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 32, s)
     p.nwg = 128;
+    if (cell == CTCASR_CELL_LSTM && H == 2048) {
+        // 8 units = 2 N tiles per workgroup, 256 workgroups = the whole chip for ONE direction:
+        // 32 x 2048 x 4 B = 256 KB per workgroup, half in LDS, half in registers.  Directions (and
+        // 16-row batch tiles) one after the other, each launch with its own counters.
+        p.nwg = 256; p.ndir = 1;
+        for (int tile = 0; tile < mt; ++tile)
+            for (int dir = 0; dir < 2; ++dir) {
+                p.chain0 = tile; p.dir0 = dir;
+                const int rc = launch_persistent(
+                    prnn_fwd_kernel<CTCASR_CELL_LSTM, 2, 32, 1, 32>, p,
+                    (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 + 32, s);
+                if (rc != CTCASR_OK) return rc;
+            }
+        return CTCASR_OK;
+    }
     // LSTM on 64 workgroups per direction: 16 units = 4 N tiles each, 256 KB of weights - half in
     // LDS, half in registers.  Two uses: (1) B <= 16 with CTCASR_RNN_HALF_CHIP (128 CUs stay free
     // for the next layer's input projection); (2) B = 17..32: the two 16-row batch tiles are
@@ -1091,6 +1114,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     // without GEMMs beside it)
     const bool half_chip = (flags & CTCASR_RNN_WHOLE_CHIP) == 0;
     p.T = T; p.B = B; p.H = H;
+    p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     if (seq_len && step_end == T &&
@@ -1109,6 +1133,21 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                              (size_t)4 * (QW_ - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +          \
                                  (size_t)CH_ * (4 * (UPB_ == 32 ? 2 : 1) * MT_ * 16 * 17 * 4 + \
                                                 16) + 16, s, CH_, TG_)
+    if (cell == CTCASR_CELL_LSTM && H == 2048) {
+        // 8 units per workgroup (half MFMA tiles: 16 units would be 512 KB of weights), 256
+        // workgroups = the whole chip for ONE direction; 8 x 8192 x 4 B = 256 KB per workgroup =
+        // 128 KB LDS + 256 registers per lane.  Directions / batch tiles one after the other.
+        p.nwg = 256; p.ndir = 1;
+        for (int tile = 0; tile < mt; ++tile)
+            for (int dir = 0; dir < 2; ++dir) {
+                p.chain0 = tile; p.dir0 = dir;
+                const int rc = launch_persistent(
+                    prnn_bwd_kernel<CTCASR_CELL_LSTM, 128, 1, 8, 8, 64>, p,
+                    (size_t)4 * 64 * 32 * 16 + (size_t)4 * 16 * 17 * 4 + 32, s);
+                if (rc != CTCASR_OK) return rc;
+            }
+        return CTCASR_OK;
+    }
     if (cell == CTCASR_CELL_LSTM) {
         if (chains && !half_chip) {
             p.nwg = H / 16;

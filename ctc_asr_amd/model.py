@@ -517,7 +517,8 @@ class CTCModel:
         with the NEXT layer's input projection on the other half: pays when that projection is a
         big GEMM (another LSTM layer follows), the steps map to the same time index for every row
         and nothing (dropout) sits between the layers."""
-        return (self.fwd_chunks > 1 and cell == 'lstm' and batch <= 16 and rnn_len is None and
+        return (self.fwd_chunks > 1 and cell == 'lstm' and hidden == 1024 and batch <= 16 and
+                rnn_len is None and
                 rnn_rate == 0.0 and layer + 1 < self.cfg.num_layers_rnn and
                 t_out >= 8 * self.fwd_chunks and
                 hip.rnn_persistent_supported(cell, t_out, batch, hidden))

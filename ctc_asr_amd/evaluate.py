@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-from ctc_asr_amd import storage
+from ctc_asr_amd import storage, summaries
 from ctc_asr_amd.input_functions import input_fn_generator
 from ctc_asr_amd.model import CTCModel, ModelConfig
 from ctc_asr_amd.params import FLAGS
@@ -66,7 +66,11 @@ def main(argv=None):
     storage.restore_checkpoint(latest, model)
     target = 'dev' if FLAGS.dev else 'test'
     print('Evaluating checkpoint {} on the {} set.'.format(latest, target))
-    print('Evaluation result: {}'.format(evaluate_dataset(model, target)))
+    result = evaluate_dataset(model, target)
+    writer = summaries.SummaryWriter(FLAGS.train_dir, 'eval_' + target)
+    for tag in ('loss', 'mean_edit_distance', 'word_error_rate'):       # eval_metric_ops + loss
+        writer.scalar(tag, result[tag], model.step_count)
+    print('Evaluation result: {}'.format(result))
     return 0
 
 

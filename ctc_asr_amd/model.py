@@ -488,7 +488,9 @@ class CTCModel:
         hip.bias_act_fwd(logits, p['logits/bias'], 0.0)
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
         self._acts = acts
-        return logits.view(t_out, batch, cfg.num_classes), seq_length
+        logits = logits.view(t_out, batch, cfg.num_classes)
+        self.last_logits, self.last_seq_length = logits, seq_length     # for logging / summaries
+        return logits, seq_length
 
     def _rnn_workspace(self, cell, t_out, batch, hidden):
         """The recurrence workspace shared by every layer and pass of this model: zero-filled

@@ -14,9 +14,10 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
-from ctc_asr_amd import storage, tf_bundle
+from ctc_asr_amd import storage, summaries, tf_bundle
 from ctc_asr_amd.engine import Trainer, init_distributed
 from ctc_asr_amd.evaluate import evaluate_dataset
 from ctc_asr_amd.input_functions import input_fn_generator
@@ -28,28 +29,48 @@ class NanLossDuringTrainingError(RuntimeError):
     """Raised when the training loss is NaN or infinite."""
 
 
-def train_epoch(trainer, target, epoch, rank, world):
+def train_epoch(trainer, target, epoch, rank, world, writer=None):
+    """One pass over ``target``.  Every ``FLAGS.log_frequency`` steps (and at the first step)
+    rank 0 prints the reference's LoggerHook line and records the summaries the reference
+    records: loss, learning rate, and - from a beam-search decode of the batch just trained on -
+    mean edit distance, word error rate and ``num_samples_to_report`` decoded / original texts."""
     model = trainer.model
     input_fn = input_fn_generator(target, device=model.device, rank=rank, world_size=world,
                                   seed=(FLAGS.random_seed or 1) * 1000 + epoch if world > 1
                                   else None)
-    window_loss, window_audio, window_start = 0.0, 0.0, time.perf_counter()
-    steps = 0
+    logger = summaries.ThroughputLogger(FLAGS.log_frequency, FLAGS.batch_size * world)
+    window_loss, steps = 0.0, 0
     for batch in input_fn():
         features, labels = batch
         loss = trainer.train_step(features['spectrogram'], features['spectrogram_length'],
                                   labels)
         steps += 1
-        window_audio += batch.audio_seconds * world
+        logger.add_audio(batch.audio_seconds * world)
         if model.step_count % FLAGS.log_frequency == 0 or steps == 1:
             value = float(trainer.global_mean(loss))
             if not math.isfinite(value):
                 raise NanLossDuringTrainingError('NaN loss during training.')
-            elapsed = time.perf_counter() - window_start
+            window_loss = value
             if rank == 0:
-                print('epoch {} step {:,d}: loss = {:.4f} ({:.1f} audio-s/s)'.format(
-                    epoch, model.step_count, value, window_audio / max(elapsed, 1e-9)))
-            window_loss, window_audio, window_start = value, 0.0, time.perf_counter()
+                line, examples_per_sec, audio_per_sec = logger.line(model.step_count, value)
+                print('epoch {} '.format(epoch) + line)
+                if writer is not None:
+                    decoded, plaintext, summary = model.decode_fn(
+                        model.last_logits, model.last_seq_length,
+                        np.array([t.encode('utf-8') for t in features['label_plaintext']],
+                                 dtype=object))
+                    _, mean_ed, _, wer = model.error_rates_fn(
+                        labels, features['label_plaintext'], decoded, plaintext)
+                    step = model.step_count
+                    writer.scalar('loss', value, step)
+                    writer.scalar('learning_rate', trainer.lr, step)
+                    writer.scalar('Metrics/mean_edit_distance', mean_ed, step)
+                    writer.scalar('Metrics/word_error_rate', wer, step)
+                    writer.scalar('examples_per_sec', examples_per_sec, step)
+                    writer.scalar('audio_seconds_per_sec', audio_per_sec, step)
+                    writer.text('decoded_text', summary[:, :FLAGS.num_samples_to_report], step)
+            else:
+                logger.line(model.step_count, value)
     return steps, window_loss
 
 
@@ -92,17 +113,21 @@ def main(argv=None):
                   'start from its variables.  Starting from a fresh initialisation.'
                   .format(FLAGS.train_dir))
 
+    writer = summaries.SummaryWriter(FLAGS.train_dir, 'train') if rank == 0 else None
+    eval_writer = summaries.SummaryWriter(FLAGS.train_dir, 'eval_dev') if rank == 0 else None
     for epoch in range(start_epoch, FLAGS.max_epochs + 1):
         target = 'train_batch' if epoch == 1 else 'train_bucket'
         if rank == 0:
             print('Starting epoch {} on {}.'.format(epoch, target))
-        train_epoch(trainer, target, epoch, rank, world)
+        train_epoch(trainer, target, epoch, rank, world, writer)
         if rank == 0:
             storage.save_checkpoint(FLAGS.train_dir, model, epoch)
             if os.environ.get('CTCASR_EXPORT_TF_CHECKPOINT') == '1':
                 storage.export_tf_checkpoint(FLAGS.train_dir, model.arena, cfg, model.step_count)
         result = evaluate_dataset(model, 'dev', rank, world)
         if rank == 0:
+            for tag in ('loss', 'mean_edit_distance', 'word_error_rate'):
+                eval_writer.scalar(tag, result[tag], model.step_count)
             print('Evaluation result after epoch {}: {}'.format(epoch, result))
     if rank == 0:
         print('Completed all epochs.')

@@ -79,6 +79,7 @@ def test_train_resume_and_evaluate(corpus, capsys):
     assert train.main([]) == 0
     out = capsys.readouterr().out
     assert 'Starting epoch 1 on train_batch' in out and 'Starting epoch 2 on train_bucket' in out
+    assert 'examples/sec' in out and 'sec/batch' in out and 'audio-s/s' in out
     assert 'Completed all epochs.' in out
     ckpts = storage.checkpoint_paths(FLAGS.train_dir)
     assert len(ckpts) == 2
@@ -90,6 +91,17 @@ def test_train_resume_and_evaluate(corpus, capsys):
     assert evaluate.main(['--dev']) == 0
     out = capsys.readouterr().out
     assert 'word_error_rate' in out and 'mean_edit_distance' in out
+    # summaries: what the reference records with tf.summary / eval_metric_ops, as JSON lines
+    from ctc_asr_amd import summaries
+    train_records = summaries.read_summaries(FLAGS.train_dir, 'train')
+    tags = {r['tag'] for r in train_records}
+    assert {'loss', 'learning_rate', 'Metrics/mean_edit_distance', 'Metrics/word_error_rate',
+            'audio_seconds_per_sec', 'decoded_text'} <= tags
+    text = [r for r in train_records if r['tag'] == 'decoded_text'][0]['text']
+    assert len(text) == 2 and 1 <= len(text[0]) <= FLAGS.num_samples_to_report
+    dev = summaries.read_summaries(FLAGS.train_dir, 'eval_dev')
+    assert {r['tag'] for r in dev} == {'loss', 'mean_edit_distance', 'word_error_rate'}
+    assert len(dev) == 3 * 4              # 3 epochs by train.main + one evaluate.main --dev
     # --delete starts from scratch
     FLAGS.max_epochs = 1
     assert train.main(['--delete']) == 0

@@ -1,10 +1,12 @@
 // K8 / K9 / K10(greedy): log-softmax, CTC loss + gradient, greedy decode for gfx950.
 //
-// CTC alpha/beta is a dependency chain of T' steps per utterance with almost no bytes to move
-// (SURVEY.md 8d): one workgroup per utterance keeps the whole per-utterance log-softmax table
-// (T' x C floats, 58 KB at T'=500) and the extended-label lattice in LDS, so a step costs one
-// s_barrier and a handful of LDS reads; alpha goes to HBM once (for the gradient sweep) and is
-// prefetched one step ahead on the way back.
+// CTC alpha / beta are dependency chains of T' steps per utterance with almost no bytes to move
+// (SURVEY.md 8d).  Two launches: ctc_sweep_kernel, grid (B, 2) - workgroup (b, 0) runs the alpha
+// recursion of utterance b, workgroup (b, 1) its beta recursion, concurrently; each keeps the
+// per-utterance log-softmax table (T' x C floats, 58 KB at T'=500) and the extended-label
+// lattice in LDS, so a step costs one s_barrier and a handful of LDS reads, and writes its
+// lattice (fp64) to HBM once - and ctc_grad_kernel, one wave per (t, b), which combines alpha
+// and beta into the per-class occupancies and the gradient row.
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------

@@ -83,7 +83,8 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, float *__restrict_
 template <int COUT, int FI>
 __global__ void __launch_bounds__(256)
 conv_fwd_kernel(const float *__restrict__ x, const float4 *__restrict__ wp,
-                const float *__restrict__ bias, float *__restrict__ y, int T) {
+                const float *__restrict__ bias, float *__restrict__ y, int T, float cutoff,
+                int y_time_major) {
     using G = Geometry<COUT, FI>;
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) float patch[];   // [PT][PF][CV_PITCH]
@@ -166,9 +167,17 @@ conv_fwd_kernel(const float *__restrict__ x, const float4 *__restrict__ wp,
             const int row = ti * 16 + 4 * kg + r, tt = row / G::FO, fo = row % G::FO;
             const int t = t0 + (G::TT / 4) * wave + tt;
             if (t < T) {
-                float *out = y + ((size_t)(b * T + t) * G::FO + fo) * COUT + n;
+                // epilogue: bias, then min(max(., 0), cutoff) (tf_contrib.conv_layers' ReLU +
+                // tf.minimum) when cutoff > 0; the last layer of the stack writes time-major
+                // [T, B, FO, COUT] - the layout the recurrent stack reads - instead of NHWC
+                const size_t cell = y_time_major ? (size_t)t * gridDim.y + b : (size_t)b * T + t;
+                float *out = y + (cell * G::FO + fo) * COUT + n;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) out[nt * 16] = acc[ti][nt][r] + bias_v[nt];
+                for (int nt = 0; nt < NT; ++nt) {
+                    float v = acc[ti][nt][r] + bias_v[nt];
+                    if (cutoff > 0.f) v = fminf(fmaxf(v, 0.f), cutoff);
+                    out[nt * 16] = v;
+                }
             }
         }
 }
@@ -179,7 +188,7 @@ conv_fwd_kernel(const float *__restrict__ x, const float4 *__restrict__ wp,
 template <int COUT, int FI>
 __global__ void __launch_bounds__(256)
 conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp,
-                     float *__restrict__ dx, int T) {
+                     float *__restrict__ dx, int T, int dz_time_major) {
     using G = Geometry<COUT, FI>;
     constexpr int PASSES = COUT / 32;           // 32 dz channels staged at a time
     extern __shared__ __attribute__((aligned(16))) float patch[];   // [PT][PF][CV_PITCH]
@@ -210,9 +219,12 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
             const int c4 = i & 7, pos = (i >> 3) % G::PF, pr = i / (8 * G::PF);
             const int ts = t0 - 5 + pr, fo = pos - 5;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ts >= 0 && ts < T && fo >= 0 && fo < G::FO)
-                v = reinterpret_cast<const float4 *>(dz)[((size_t)(b * T + ts) * G::FO + fo) *
-                                                             (COUT / 4) + pass * 8 + c4];
+            if (ts >= 0 && ts < T && fo >= 0 && fo < G::FO) {
+                const size_t cell = dz_time_major ? (size_t)ts * gridDim.y + b
+                                                  : (size_t)b * T + ts;
+                v = reinterpret_cast<const float4 *>(dz)[(cell * G::FO + fo) * (COUT / 4) +
+                                                         pass * 8 + c4];
+            }
             patch4[((pr * G::PF + pos) * CV_PITCH) / 4 + c4] = v;
         }
         __syncthreads();
@@ -267,7 +279,7 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
 
 template <int COUT, int FI>
 int launch_fwd(const float *x, const float *packed, const float *bias, float *y, int B, int T,
-               hipStream_t s) {
+               float cutoff, int y_time_major, hipStream_t s) {
     using G = Geometry<COUT, FI>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fwd_kernel<COUT, FI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
@@ -275,19 +287,20 @@ int launch_fwd(const float *x, const float *packed, const float *bias, float *y,
     dim3 grid((T + G::TT - 1) / G::TT, B);
     const size_t per_order = (size_t)CV_KT * CV_KF * CV_CIN * COUT;
     conv_fwd_kernel<COUT, FI><<<grid, 256, G::LDS, s>>>(
-        x, reinterpret_cast<const float4 *>(packed + per_order), bias, y, T);
+        x, reinterpret_cast<const float4 *>(packed + per_order), bias, y, T, cutoff, y_time_major);
     return ctcasr_launch_status();
 }
 
 template <int COUT, int FI>
-int launch_bwd(const float *dz, const float *packed, float *dx, int B, int T, hipStream_t s) {
+int launch_bwd(const float *dz, const float *packed, float *dx, int B, int T, int dz_time_major,
+               hipStream_t s) {
     using G = Geometry<COUT, FI>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bwd_data_kernel<COUT, FI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     dim3 grid((T + G::TT - 1) / G::TT, B);
     conv_bwd_data_kernel<COUT, FI><<<grid, 256, G::LDS, s>>>(
-        dz, reinterpret_cast<const float4 *>(packed), dx, T);
+        dz, reinterpret_cast<const float4 *>(packed), dx, T, dz_time_major);
     return ctcasr_launch_status();
 }
 
@@ -295,7 +308,192 @@ bool covered(int freq_in, int cout) {
     return (freq_in == 40 && cout == 32) || (freq_in == 20 && cout == 96);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel gradient of the 11 x 21, stride (1, 2) layers:
+//   dw[co, ci, kt, kf] = sum_{b,t,fo} dz[b, t, fo, co] * x[b, t + kt - 5, 2 fo + kf - 9, ci]
+// Per tap a GEMM  [co x rows] x [rows x ci]  with rows = (b, t, fo) as the K axis; 231 taps.
+// grid = (splits of the K axis, 11 kt, cout / 32): a workgroup owns ONE kt row (for a fixed kt
+// the x frames a tile of output frames needs are just that tile shifted - no time halo) and one
+// group of 32 output channels, and walks its share of the (b, frame-tile) list.  Per tile of 80
+// rows it stages dz [80][32 (+16: pitch 48)] and the x rows [frames][FI + 20 positions][32 (+8:
+// pitch 40)] in LDS - the pitches make the scalar fragment reads of 4 consecutive rows x 16
+// channels conflict-free.  Operands are fed with one ds_read_b32 per lane (16-byte fragments would
+// need the rows of a tap contiguous and aligned, which the kf shift rules out); a wave owns one
+// of the four 16 x 16 (co, ci) tiles for ALL 21 kf taps: per group of 4 rows it reads its A value
+// (dz) once and 21 B values (x, one immediate offset per tap) for 21 MFMAs - balanced over the
+// waves, 84 accumulator registers.  The next tile's global loads are issued before the MFMAs of
+// the current one.  Partial results go to a workspace [split][cout/32][kt][kf][32 co][32 ci];
+// conv_wrw_reduce_kernel sums the splits in a fixed order (deterministic) into
+// dw [cout, 32, 11, 21].  MIOpen's kernel for this reaches 61-73 TFLOP/s.
+// ---------------------------------------------------------------------------------------------
+constexpr int WR_DZP = 48;          // dz pitch in LDS (floats)
+constexpr int WR_XP = 40;           // x pitch per (frame, position) cell
+constexpr int WR_ROWS = 80;         // rows (frame, fo) per tile
+constexpr int WR_TAP = CV_CIN * 32; // floats per tap and channel group in the partial layout
+
+template <int FI>
+struct WrwGeometry {
+    static constexpr int FO = FI / 2;
+    static constexpr int TT = WR_ROWS / FO;          // output frames per tile (4 or 8)
+    static constexpr int PF = FI + 20;               // positions 2 fo + kf in [0, FI + 18]
+    static constexpr int DZ4 = WR_ROWS * 8;          // float4 loads per dz tile
+    static constexpr int X4 = TT * PF * 8;           // float4 slots per x tile
+    static constexpr int DZ_PER = (DZ4 + 255) / 256, X_PER = (X4 + 255) / 256;
+    static constexpr size_t LDS =
+        ((size_t)WR_ROWS * WR_DZP + (size_t)TT * PF * WR_XP) * sizeof(float);
+};
+
+template <int FI>
+__global__ void __launch_bounds__(256, 2)
+conv_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
+                float *__restrict__ partial, int B, int T, int cout, int dz_time_major) {
+    using G = WrwGeometry<FI>;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *dzs = wsm;                                   // [WR_ROWS][WR_DZP]
+    float *xs = wsm + WR_ROWS * WR_DZP;                 // [TT][PF][WR_XP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, nsplit = gridDim.x, kt = blockIdx.y, cg = blockIdx.z;
+    const int g = lane >> 4, n = lane & 15;
+    const int co_tile = wave >> 1, ci_tile = wave & 1;
+    const int tiles_per_b = (T + G::TT - 1) / G::TT, tiles = B * tiles_per_b;
+
+    f32x4 acc[CV_KF];
+#pragma unroll
+    for (int kf = 0; kf < CV_KF; ++kf) acc[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 rdz[G::DZ_PER], rx[G::X_PER];
+    auto fetch = [&](int tile) {                 // global -> registers (zeros outside the tensor)
+        const int b = tile / tiles_per_b, t0 = (tile % tiles_per_b) * G::TT;
+#pragma unroll
+        for (int j = 0; j < G::DZ_PER; ++j) {
+            const int i = tid + j * 256, c4 = i & 7, row = i >> 3;
+            const int t = t0 + row / G::FO, fo = row % G::FO;
+            rdz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < G::DZ4 && t < T) {
+                const size_t cell = dz_time_major ? (size_t)t * B + b : (size_t)b * T + t;
+                rdz[j] = *reinterpret_cast<const float4 *>(
+                    dz + (cell * G::FO + fo) * cout + cg * 32 + 4 * c4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G::X_PER; ++j) {
+            const int i = tid + j * 256, c4 = i & 7, pos = (i >> 3) % G::PF, tl = i / (8 * G::PF);
+            const int ts = t0 + tl + kt - 5, f = pos - 9;
+            rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < G::X4 && ts >= 0 && ts < T && f >= 0 && f < FI)
+                rx[j] = *reinterpret_cast<const float4 *>(
+                    x + ((size_t)(b * T + ts) * FI + f) * CV_CIN + 4 * c4);
+        }
+    };
+    auto stage = [&]() {                         // registers -> LDS
+#pragma unroll
+        for (int j = 0; j < G::DZ_PER; ++j) {
+            const int i = tid + j * 256;
+            if (i < G::DZ4)
+                *reinterpret_cast<float4 *>(dzs + (i >> 3) * WR_DZP + 4 * (i & 7)) = rdz[j];
+        }
+#pragma unroll
+        for (int j = 0; j < G::X_PER; ++j) {
+            const int i = tid + j * 256;
+            if (i < G::X4)
+                *reinterpret_cast<float4 *>(xs + (i >> 3) * WR_XP + 4 * (i & 7)) = rx[j];
+        }
+    };
+
+    int tile = split;
+    if (tile < tiles) fetch(tile);
+    for (; tile < tiles; tile += nsplit) {
+        __syncthreads();                         // everyone is done reading the previous tile
+        stage();
+        __syncthreads();
+        if (tile + nsplit < tiles) fetch(tile + nsplit);
+        // lane (m = n, k = g) of A: dz[row = 4 q + g][co_tile * 16 + n]
+        // lane (k = g, n) of B: x[frame(row)][2 fo(row) + kf][ci_tile * 16 + n]
+#pragma unroll 2
+        for (int q = 0; q < WR_ROWS / 4; ++q) {
+            const int row = 4 * q + g, tl = row / G::FO, fo = row % G::FO;
+            const float a = dzs[row * WR_DZP + co_tile * 16 + n];
+            const float *xb = xs + (tl * G::PF + 2 * fo) * WR_XP + ci_tile * 16 + n;
+#pragma unroll
+            for (int kf = 0; kf < CV_KF; ++kf)
+                acc[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[kf * WR_XP], acc[kf], 0, 0, 0);
+        }
+    }
+    // D[m = 4 g + r][n]: co = co_tile * 16 + 4 g + r, ci = ci_tile * 16 + n
+    float *out = partial + (((size_t)split * gridDim.z + cg) * CV_KT + kt) * CV_KF * WR_TAP;
+#pragma unroll
+    for (int kf = 0; kf < CV_KF; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            out[(size_t)kf * WR_TAP + (co_tile * 16 + 4 * g + r) * CV_CIN + ci_tile * 16 + n] =
+                acc[kf][r];
+}
+
+// dw[co][ci][kt][kf] = sum over splits of partial[split][co / 32][kt][kf][co % 32][ci]
+__global__ void conv_wrw_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw,
+                                       int nsplit, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * CV_CIN * CV_KT * CV_KF;
+    if (i >= total) return;
+    const int kf = i % CV_KF, kt = (i / CV_KF) % CV_KT, ci = (i / (CV_KF * CV_KT)) % CV_CIN;
+    const int co = i / (CV_KF * CV_KT * CV_CIN);
+    const int groups = cout / 32;
+    const size_t per_split = (size_t)groups * CV_KT * CV_KF * WR_TAP;
+    const size_t off = (((size_t)(co / 32) * CV_KT + kt) * CV_KF + kf) * WR_TAP +
+                       (size_t)(co % 32) * CV_CIN + ci;
+    float sum = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) sum += partial[sp * per_split + off];
+    dw[i] = sum;
+}
+
+int wrw_splits(int B, int T, int freq_in, int cout) {
+    // two workgroups per CU and not one more (a second round of workgroups would double the
+    // kernel's duration: 528 workgroups took 1.05 ms, 506 take 0.6); never more splits than tiles
+    const int tt = WR_ROWS / (freq_in / 2);
+    const int tiles = B * ((T + tt - 1) / tt);
+    const int want = 512 / (CV_KT * (cout / 32));
+    return tiles < want ? tiles : want;
+}
+
 }  // namespace
+
+extern "C" size_t ctcasr_conv_s12_wrw_workspace_bytes(int B, int T, int freq_in, int cout) {
+    if (B <= 0 || T <= 0 || !covered(freq_in, cout)) return 0;
+    return (size_t)wrw_splits(B, T, freq_in, cout) * cout * CV_CIN * CV_KT * CV_KF * sizeof(float);
+}
+
+// dz [B, T, freq_in / 2, cout], x [B, T, freq_in, 32] (both NHWC) -> dw [cout, 32, 11, 21]
+// (overwritten); deterministic (fixed summation order).
+extern "C" int ctcasr_conv_s12_wrw(const float *dz, const float *x, float *dw, int B, int T,
+                                   int freq_in, int cout, int dz_time_major, void *workspace,
+                                   size_t workspace_bytes, ctcasr_stream_t stream) {
+    if (!dz || !x || !dw || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!covered(freq_in, cout)) return CTCASR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ctcasr_conv_s12_wrw_workspace_bytes(B, T, freq_in, cout))
+        return CTCASR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nsplit = wrw_splits(B, T, freq_in, cout);
+    float *partial = reinterpret_cast<float *>(workspace);
+    dim3 grid(nsplit, CV_KT, cout / 32);
+    if (freq_in == 40) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wrw_kernel<40>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)WrwGeometry<40>::LDS) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+        conv_wrw_kernel<40><<<grid, 256, WrwGeometry<40>::LDS, s>>>(dz, x, partial, B, T, cout,
+                                                                    dz_time_major);
+    } else {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wrw_kernel<20>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)WrwGeometry<20>::LDS) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+        conv_wrw_kernel<20><<<grid, 256, WrwGeometry<20>::LDS, s>>>(dz, x, partial, B, T, cout,
+                                                                    dz_time_major);
+    }
+    const int total = cout * CV_CIN * CV_KT * CV_KF;
+    conv_wrw_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, dw, nsplit, cout);
+    return ctcasr_launch_status();
+}
 
 // 1 for the (input frequencies, output channels) pairs the kernels are instantiated for: the
 // second (40, 32) and third (20, 96) convolution of the reference's stack.
@@ -313,23 +511,25 @@ extern "C" int ctcasr_conv_s12_pack_weights(const float *w, float *packed, int c
 
 // x [B, T, freq_in, 32] (NHWC) -> y [B, T, freq_in / 2, cout] = conv(x) + bias (bias may be NULL).
 extern "C" int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y,
-                                   int B, int T, int freq_in, int cout, ctcasr_stream_t stream) {
+                                   int B, int T, int freq_in, int cout, float relu_cutoff,
+                                   int y_time_major, ctcasr_stream_t stream) {
     if (!x || !packed || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
     if (!covered(freq_in, cout) || B > 65535) return CTCASR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (cout == 32) return launch_fwd<32, 40>(x, packed, bias, y, B, T, s);
-    return launch_fwd<96, 20>(x, packed, bias, y, B, T, s);
+    if (cout == 32) return launch_fwd<32, 40>(x, packed, bias, y, B, T, relu_cutoff, y_time_major, s);
+    return launch_fwd<96, 20>(x, packed, bias, y, B, T, relu_cutoff, y_time_major, s);
 }
 
 // dz [B, T, freq_in / 2, cout] (NHWC, gradient w.r.t. the layer's pre-activation output)
 // -> dx [B, T, freq_in, 32].
 extern "C" int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B,
-                                        int T, int freq_in, int cout, ctcasr_stream_t stream) {
+                                        int T, int freq_in, int cout, int dz_time_major,
+                                        ctcasr_stream_t stream) {
     if (!dz || !packed || !dx || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
     if (!covered(freq_in, cout) || B > 65535) return CTCASR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (cout == 32) return launch_bwd<32, 40>(dz, packed, dx, B, T, s);
-    return launch_bwd<96, 20>(dz, packed, dx, B, T, s);
+    if (cout == 32) return launch_bwd<32, 40>(dz, packed, dx, B, T, dz_time_major, s);
+    return launch_bwd<96, 20>(dz, packed, dx, B, T, dz_time_major, s);
 }
 
 // =============================================================================================
@@ -351,7 +551,8 @@ constexpr size_t C0_LDS = ((size_t)C0_PT * C0_PW + (size_t)C0_KT * C0_KFP * C0_C
 
 __global__ void __launch_bounds__(256)
 conv0_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                 const float *__restrict__ bias, float *__restrict__ y, int T, int t_out, int pt0) {
+                 const float *__restrict__ bias, float *__restrict__ y, int T, int t_out, int pt0,
+                 float cutoff) {
     extern __shared__ __attribute__((aligned(16))) float smem0[];
     float *patch = smem0;                               // [C0_PT][C0_PW]
     float *wl = smem0 + C0_PT * C0_PW;                  // [kt][kf padded][co]
@@ -408,8 +609,13 @@ conv0_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
             const int t = t0 + 4 * wave + tt;
             if (t < t_out) {
                 float *out = y + ((size_t)(b * t_out + t) * C0_FO + fo) * C0_CO + n;
-                out[0] = acc[ti][0][r] + bias0;
-                out[16] = acc[ti][1][r] + bias1;
+                float v0 = acc[ti][0][r] + bias0, v1 = acc[ti][1][r] + bias1;
+                if (cutoff > 0.f) {          // ReLU + tf.minimum(., relu_cutoff) of conv_layers
+                    v0 = fminf(fmaxf(v0, 0.f), cutoff);
+                    v1 = fminf(fmaxf(v1, 0.f), cutoff);
+                }
+                out[0] = v0;
+                out[16] = v1;
             }
         }
 }
@@ -419,7 +625,7 @@ conv0_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
 // x [B, T, 80] (one channel) -> y [B, ceil(T / 2), 40, 32] (NHWC) = conv(x) + bias (bias may be
 // NULL); w [32, 1, 11, 41].
 extern "C" int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y, int B,
-                                int T, ctcasr_stream_t stream) {
+                                int T, float relu_cutoff, ctcasr_stream_t stream) {
     if (!x || !w || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
     if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
     const int t_out = (T + 1) / 2;
@@ -429,7 +635,8 @@ extern "C" int ctcasr_conv0_fwd(const float *x, const float *w, const float *bia
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C0_LDS) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     dim3 grid((t_out + C0_TT - 1) / C0_TT, B);
-    conv0_fwd_kernel<<<grid, 256, C0_LDS, (hipStream_t)stream>>>(x, w, bias, y, T, t_out, pt0);
+    conv0_fwd_kernel<<<grid, 256, C0_LDS, (hipStream_t)stream>>>(x, w, bias, y, T, t_out, pt0,
+                                                                 relu_cutoff);
     return ctcasr_launch_status();
 }
 

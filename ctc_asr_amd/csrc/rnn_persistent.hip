@@ -32,6 +32,9 @@
 #define PRNN_GROUPS 8
 #endif
 #define PRNN_SPIN_LIMIT (1u << 22)
+#ifndef PRNN_PROBE_HALF_LOADS
+#define PRNN_PROBE_HALF_LOADS 0
+#endif
 #ifndef PRNN_XCD_AWARE
 #define PRNN_XCD_AWARE 0
 #endif
@@ -802,6 +805,10 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                         // chunk index in n-space: gate * (H / 16) + unit chunk
                         const unsigned off = (unsigned)(((size_t)(c / CPG) * (H / 16) + (c % CPG)) *
                                                         B * 16 * sizeof(float));
+#if PRNN_PROBE_HALF_LOADS     // timing probe only (wrong results): half of the A bytes
+                        if (i & 1) dst[mt][i] = dst[mt][i - 1];
+                        else
+#endif
                         dst[mt][i] = load16_sc1(x_rsrc, aoff[mt] + off);
                     }
             };

@@ -117,11 +117,10 @@ class Trainer:
     """Owns a `CTCModel` replica on this rank's GPU and runs synchronous data-parallel steps."""
 
     def __init__(self, cfg, flags=None, device=None, seed=0, params=None, world_size=1, rank=0,
-                 bucket_bytes=64 << 20, conv_autotune=None, conv_mode=None):
+                 bucket_bytes=64 << 20, conv_autotune=None):
         self.world, self.rank = world_size, rank
         device = device or 'cuda:{}'.format(torch.cuda.current_device())
-        self.model = CTCModel(cfg, device, seed=seed, params=params, conv_autotune=conv_autotune,
-                              conv_mode=conv_mode)
+        self.model = CTCModel(cfg, device, seed=seed, params=params, conv_autotune=conv_autotune)
         self.lr = getattr(flags, 'learning_rate', 1e-5) if flags is not None else 1e-5
         self.beta1 = getattr(flags, 'adam_beta1', 0.9) if flags is not None else 0.9
         self.beta2 = getattr(flags, 'adam_beta2', 0.999) if flags is not None else 0.999

@@ -58,8 +58,7 @@ def main(argv=None):
     FLAGS.parse(sys.argv[1:] if argv is None else argv)
     if not torch.cuda.is_available():
         raise SystemExit('ctc_asr_amd.evaluate needs an MI355X; no GPU is visible.')
-    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=FLAGS.random_seed or 1,
-                     conv_mode=os.environ.get('CTCASR_CONV_MODE', 'tiled'))
+    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=FLAGS.random_seed or 1)
     latest = storage.latest_checkpoint(FLAGS.train_dir)
     if latest is None:
         raise SystemExit('No checkpoint found in {}.'.format(FLAGS.train_dir))

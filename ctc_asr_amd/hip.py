@@ -53,9 +53,11 @@ SIGNATURES = {
     'ctcasr_colsum_accumulate': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p]),
     'ctcasr_conv_s12_supported': (_c_int, [_c_int, _c_int]),
     'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
-    'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
-    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p]),
-    'ctcasr_conv0_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_f, _c_int, _c_p]),
+    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p]),
+    'ctcasr_conv_s12_wrw_workspace_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_conv_s12_wrw': (_c_int, [_c_p] * 3 + [_c_int] * 5 + [_c_p, _c_sz, _c_p]),
+    'ctcasr_conv0_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     'ctcasr_conv0_wrw_workspace_bytes': (_c_sz, [_c_int, _c_int]),
     'ctcasr_conv0_wrw': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_sz, _c_p]),
     'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
@@ -434,26 +436,31 @@ def conv_s12_pack_weights(weight, packed=None):
 
 
 @_on_tensor_device
-def conv_s12_fwd(x, packed, cout, bias=None, out=None):
+def conv_s12_fwd(x, packed, cout, bias=None, out=None, relu_cutoff=0.0, time_major=False):
     """x f32[B,T,F,32] (NHWC) -> conv(x) + bias, f32[B,T,F/2,cout]; 11x21 taps, stride (1,2),
-    TensorFlow SAME padding.  ``packed`` from `conv_s12_pack_weights`."""
+    TensorFlow SAME padding.  ``packed`` from `conv_s12_pack_weights`.  ``relu_cutoff`` > 0 fuses
+    min(max(., 0), cutoff) into the epilogue; ``time_major`` writes [T,B,F/2,cout] instead."""
     batch, frames, freq = x.shape[0], x.shape[1], x.shape[2]
     if x.shape[3] != 32 or not conv_s12_supported(freq, cout):
         raise CtcAsrError('conv_s12_fwd: unsupported layer shape {} -> {} channels'.format(
             tuple(x.shape), cout))
-    out = torch.empty((batch, frames, freq // 2, cout), dtype=torch.float32, device=x.device) \
-        if out is None else out
+    shape = (frames, batch, freq // 2, cout) if time_major else (batch, frames, freq // 2, cout)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
     with _Timed('conv_s12_fwd'):
         _check(load().ctcasr_conv_s12_fwd(_dev(x, name='x'), _dev(packed, name='packed'),
                                           _dev(bias, name='bias'), _dev(out, name='y'), batch,
-                                          frames, freq, cout, _stream()), 'conv_s12_fwd')
+                                          frames, freq, cout, float(relu_cutoff),
+                                          1 if time_major else 0, _stream()), 'conv_s12_fwd')
     return out
 
 
 @_on_tensor_device
-def conv_s12_bwd_data(dz, packed, out=None):
-    """dz f32[B,T,F/2,cout] (NHWC) -> dx f32[B,T,F,32] of the same layer."""
-    batch, frames, freq_out, cout = dz.shape
+def conv_s12_bwd_data(dz, packed, out=None, time_major=False):
+    """dz f32[B,T,F/2,cout] (NHWC; ``time_major``: [T,B,F/2,cout]) -> dx f32[B,T,F,32]."""
+    if time_major:
+        frames, batch, freq_out, cout = dz.shape
+    else:
+        batch, frames, freq_out, cout = dz.shape
     if not conv_s12_supported(2 * freq_out, cout):
         raise CtcAsrError('conv_s12_bwd_data: unsupported layer shape {}'.format(tuple(dz.shape)))
     out = torch.empty((batch, frames, 2 * freq_out, 32), dtype=torch.float32, device=dz.device) \
@@ -461,14 +468,42 @@ def conv_s12_bwd_data(dz, packed, out=None):
     with _Timed('conv_s12_bwd_data'):
         _check(load().ctcasr_conv_s12_bwd_data(_dev(dz, name='dz'), _dev(packed, name='packed'),
                                                _dev(out, name='dx'), batch, frames,
-                                               2 * freq_out, cout, _stream()), 'conv_s12_bwd_data')
+                                               2 * freq_out, cout, 1 if time_major else 0,
+                                               _stream()), 'conv_s12_bwd_data')
     return out
 
 
 @_on_tensor_device
-def conv0_fwd(x, weight, bias=None, out=None):
+def conv_s12_wrw(dz, x, out=None, time_major=False):
+    """Kernel gradient of the same layer: dz f32[B,T,F/2,cout] (``time_major``: [T,B,F/2,cout]),
+    x f32[B,T,F,32] (NHWC) -> dw f32[cout,32,11,21]."""
+    if time_major:
+        frames, batch, freq_out, cout = dz.shape
+    else:
+        batch, frames, freq_out, cout = dz.shape
+    if tuple(x.shape) != (batch, frames, 2 * freq_out, 32) or \
+            not conv_s12_supported(2 * freq_out, cout):
+        raise CtcAsrError('conv_s12_wrw: unsupported layer shape {} / {}'.format(
+            tuple(dz.shape), tuple(x.shape)))
+    out = torch.empty((cout, 32, 11, 21), dtype=torch.float32, device=x.device) if out is None \
+        else out
+    workspace = _workspace(load().ctcasr_conv_s12_wrw_workspace_bytes(batch, frames,
+                                                                      2 * freq_out, cout),
+                           x.device)
+    with _Timed('conv_s12_wrw'):
+        _check(load().ctcasr_conv_s12_wrw(_dev(dz, name='dz'), _dev(x, name='x'),
+                                          _dev(out, name='dw'), batch, frames, 2 * freq_out, cout,
+                                          1 if time_major else 0,
+                                          _dev(workspace, torch.uint8, 'workspace'),
+                                          workspace.numel(), _stream()), 'conv_s12_wrw')
+    return out
+
+
+@_on_tensor_device
+def conv0_fwd(x, weight, bias=None, out=None, relu_cutoff=0.0):
     """First DS2 convolution: x f32[B,T,80] -> f32[B,ceil(T/2),40,32] (NHWC); weight
-    f32[32,1,11,41], stride (2,2), TensorFlow SAME padding."""
+    f32[32,1,11,41], stride (2,2), TensorFlow SAME padding; ``relu_cutoff`` > 0 fuses
+    min(max(., 0), cutoff) into the epilogue."""
     batch, frames = x.shape[0], x.shape[1]
     if x.shape[2] != 80 or tuple(weight.shape) != (32, 1, 11, 41):
         raise CtcAsrError('conv0_fwd covers x [B,T,80] and w [32,1,11,41] only.')
@@ -477,7 +512,7 @@ def conv0_fwd(x, weight, bias=None, out=None):
     with _Timed('conv0_fwd'):
         _check(load().ctcasr_conv0_fwd(_dev(x, name='x'), _dev(weight, name='weight'),
                                        _dev(bias, name='bias'), _dev(out, name='y'), batch,
-                                       frames, _stream()), 'conv0_fwd')
+                                       frames, float(relu_cutoff), _stream()), 'conv0_fwd')
     return out
 
 

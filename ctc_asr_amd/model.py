@@ -287,34 +287,17 @@ class CTCModel:
     ``CTCModel`` with torch tensors in place of TensorFlow tensors; ``forward_backward`` /
     ``apply_gradients`` are the explicit counterparts of ``optimizer.minimize``."""
 
-    def __init__(self, cfg, device='cuda', seed=0, params=None, conv_autotune=None,
-                 conv_mode=None):
+    def __init__(self, cfg, device='cuda', seed=0, params=None, conv_autotune=None):
         hip.load()
-        # MIOpen convolution selection.  Its default "find" benchmarks every solver the first
-        # time a shape is seen: 3-6 s per new padded length (measured), which is fatal for
-        # bucketed batches whose time extent changes every step - so the default here is the
-        # immediate (heuristic) mode.  Fixed-shape runs (bench.py) opt into autotuning, which
-        # picks ~35 % faster kernels for the 11x21 stride-(1,2) layers:
-        # `conv_autotune=True` or CTCASR_CONV_AUTOTUNE=1.
-        #
-        # `conv_mode='tiled'` (CTCASR_CONV_MODE) makes autotuning usable for variable-length
-        # batches: every convolution runs as calls of ONE fixed shape - the time axis is cut
-        # into tiles of `conv_tile_frames` output frames (+ the kernel's halo of input frames),
-        # tiles of all utterances are stacked on the batch axis and processed
-        # `conv_tile_batch` at a time (the last call zero-filled).  MIOpen then sees three
-        # shapes per layer for the whole run, whatever the padded length of a batch is.  With
-        # immediate mode on ever-changing shapes MIOpen falls back to im2col + batched GEMM
-        # (5 ms per call): 75 ms of convolutions per step instead of 4.
-        if conv_mode is None:
-            conv_mode = os.environ.get('CTCASR_CONV_MODE', 'direct')
-        if conv_mode not in ('direct', 'tiled'):
-            raise ValueError('conv_mode must be "direct" or "tiled"')
-        self.conv_mode = conv_mode
-        self.conv_tile_frames = int(os.environ.get('CTCASR_CONV_TILE_FRAMES', '128'))
-        self.conv_tile_batch = int(os.environ.get('CTCASR_CONV_TILE_BATCH', '32'))
+        # The reference's convolution stack (1 -> 32 -> 32 [-> 96] channels) runs entirely on this
+        # package's own kernels - forward, data gradient and kernel gradient, any number of
+        # frames, no padded copies - so variable-length batches cost nothing extra.  Other channel
+        # counts (the small models of the tests) go through MIOpen on explicitly SAME-padded
+        # inputs.  Its default "find" benchmarks every solver the first time a shape is seen (3-6 s
+        # per new padded length), so the default there is the immediate (heuristic) mode;
+        # `conv_autotune=True` / CTCASR_CONV_AUTOTUNE=1 opts fixed-shape runs into autotuning.
         if conv_autotune is None:
-            conv_autotune = os.environ.get('CTCASR_CONV_AUTOTUNE',
-                                           '1' if conv_mode == 'tiled' else '0') == '1'
+            conv_autotune = os.environ.get('CTCASR_CONV_AUTOTUNE', '0') == '1'
         if conv_autotune:
             torch.backends.cudnn.benchmark = True
         else:
@@ -330,9 +313,8 @@ class CTCModel:
         # weight-gradient GEMMs run on a low-priority side stream so that they fill the half of
         # the chip the latency-bound backward recurrence of the layer below leaves free
         self.overlap_wgrad = True
-        # the 11x21 / stride (1,2) convolutions over 32 input channels (layers 2 and 3 of the
-        # reference's stack) run on this package's own implicit-GEMM kernels (forward and data
-        # gradient; any T, no padded intermediates)
+        # the reference's convolution stack runs on this package's own implicit-GEMM kernels
+        # (forward, data gradient, kernel gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
         self._conv_packed = {}          # layer -> fragment-ordered weight copies
         self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
@@ -382,17 +364,25 @@ class CTCModel:
             # implicit-GEMM convolution kernels are NHWC-native, no transposes around them
             x = sequences.unsqueeze(1).contiguous(memory_format=torch.channels_last)
             conv_in, conv_out, pads, own_kind = [], [], [], []
-            for i in range(len(cfg.conv_filters)):
+            layers = len(cfg.conv_filters)
+            # The own kernels apply ReLU + min(., relu_cutoff) in their epilogue, and the LAST
+            # layer then writes time-major [T', B, F', C] - what the recurrent stack reads -
+            # instead of NHWC: no elementwise pass and no transpose between the stacks.  (With
+            # conv dropout the epilogue kernel still runs: it owns the mask generator.)
+            fused = cfg.conv_dropout_rate == 0.0
+            last_time_major = False
+            for i in range(layers):
                 k_t, k_f = CONV_KERNEL_SIZES[i]
                 s_t, s_f = CONV_STRIDES[i]
                 _, pt0, pt1 = same_padding(x.shape[2], k_t, s_t)
                 _, pf0, pf1 = same_padding(x.shape[3], k_f, s_f)
                 own_kind.append('conv0' if self._own_conv0_layer(i, x.shape[3]) else
                                 's12' if self._own_conv_layer(i, x.shape[3]) else None)
+                cutoff = cfg.relu_cutoff if fused else 0.0
                 if own_kind[i] == 'conv0':
                     # first layer: straight from the [B, T, 80] features, no padded copy
-                    y = hip.conv0_fwd(sequences, p['conv0/kernel'],
-                                      p['conv0/bias']).permute(0, 3, 1, 2)
+                    y = hip.conv0_fwd(sequences, p['conv0/kernel'], p['conv0/bias'],
+                                      relu_cutoff=cutoff).permute(0, 3, 1, 2)
                     conv_in.append(None)
                     acts['features'] = sequences
                 elif own_kind[i] == 's12':
@@ -400,13 +390,13 @@ class CTCModel:
                     kernel = p['conv{}/kernel'.format(i)]
                     self._conv_packed[i] = hip.conv_s12_pack_weights(kernel,
                                                                      self._conv_packed.get(i))
-                    x_phys = x.permute(0, 2, 3, 1)
-                    y = hip.conv_s12_fwd(x_phys, self._conv_packed[i], kernel.shape[0],
-                                         p['conv{}/bias'.format(i)]).permute(0, 3, 1, 2)
-                    conv_in.append(x)      # padded / tiled for the kernel gradient on demand
-                elif self.conv_mode == 'tiled':
-                    y, ctx = self._conv_fwd_tiled(i, x, (pt0, pt1, pf0, pf1))
-                    conv_in.append(ctx)
+                    last_time_major = fused and i == layers - 1
+                    y = hip.conv_s12_fwd(x.permute(0, 2, 3, 1), self._conv_packed[i],
+                                         kernel.shape[0], p['conv{}/bias'.format(i)],
+                                         relu_cutoff=cutoff, time_major=last_time_major)
+                    if not last_time_major:
+                        y = y.permute(0, 3, 1, 2)
+                    conv_in.append(x)      # the own kernel gradient reads the plain input
                 else:
                     xp = torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1)) \
                         .contiguous(memory_format=torch.channels_last)
@@ -415,17 +405,23 @@ class CTCModel:
                                                    [0, 0], [1, 1], False, [0, 0], 1)
                     y = y.contiguous(memory_format=torch.channels_last)
                     conv_in.append(xp)
-                # elementwise epilogue on the NHWC storage ([B, T, F, C] view of the same memory)
-                hip.bias_act_fwd(y.permute(0, 2, 3, 1), None, cfg.relu_cutoff,
-                                 cfg.conv_dropout_rate, self._next_seed())
+                if own_kind[i] is None or not fused:
+                    # elementwise epilogue on the NHWC storage ([B, T, F, C] view of the memory)
+                    hip.bias_act_fwd(y.permute(0, 2, 3, 1), None, cfg.relu_cutoff,
+                                     cfg.conv_dropout_rate, self._next_seed())
                 conv_out.append(y)
                 pads.append((pt0, pt1, pf0, pf1))
                 x = y
-            t_out = x.shape[2]
-            # [B, C, T', F'] -> time-major [T', B, F'*C] (freq-major, channel-minor like NHWC)
-            rnn_in = x.permute(2, 0, 3, 1).reshape(t_out, batch, -1)
+            if last_time_major:            # y is [T', B, F', C] already
+                t_out = x.shape[0]
+                rnn_in = x.view(t_out, batch, -1)
+            else:
+                t_out = x.shape[2]
+                # [B, C, T', F'] -> time-major [T', B, F'*C] (freq-major, channel-minor like NHWC)
+                rnn_in = x.permute(2, 0, 3, 1).reshape(t_out, batch, -1)
             # (which layers ran on the own kernels is decided HERE, once: backward reads it back)
-            acts.update(conv_in=conv_in, conv_out=conv_out, pads=pads, conv_own=own_kind)
+            acts.update(conv_in=conv_in, conv_out=conv_out, pads=pads, conv_own=own_kind,
+                        last_time_major=last_time_major)
             seq_length = torch.full((batch,), t_out, dtype=torch.int32, device=self.device)
         else:
             t_out = frames
@@ -585,112 +581,6 @@ class CTCModel:
         return (self.own_conv and tuple(kernel.shape[1:]) == (32, 11, 21) and
                 CONV_STRIDES[layer] == (1, 2) and
                 hip.conv_s12_supported(freq_in, kernel.shape[0]))
-
-    def _conv_wrw_input(self, layer, x, pads):
-        """What the (library) kernel-gradient pass of a layer that ran on the own forward kernel
-        needs to keep: the padded input (direct mode) or its tiles (tiled mode)."""
-        pt0, pt1, pf0, pf1 = pads
-        if self.conv_mode == 'tiled':
-            return self._conv_tiles(layer, x, pads)
-        return torch.nn.functional.pad(x, (pf0, pf1, pt0, pt1)) \
-            .contiguous(memory_format=torch.channels_last)
-
-    def _conv_tiling(self, layer, frames_in, pad_t):
-        """Tile geometry of conv ``layer`` for ``frames_in`` input frames: output frames,
-        tiles per utterance, input frames per tile (window), tile step, padded input length."""
-        k_t, s_t = CONV_KERNEL_SIZES[layer][0], CONV_STRIDES[layer][0]
-        t_out = (frames_in + pad_t[0] + pad_t[1] - k_t) // s_t + 1
-        tile = self.conv_tile_frames
-        n_tiles = -(-t_out // tile)
-        window = (tile - 1) * s_t + k_t
-        step = tile * s_t
-        assert window <= 2 * step, 'tiles of equal parity must not overlap'
-        need = (n_tiles * tile - 1) * s_t + k_t
-        return t_out, n_tiles, window, step, need
-
-    def _conv_tiles(self, layer, x, pads):
-        """The zero-padded input of a layer cut into fixed-shape tiles (context of the tiled
-        convolution calls)."""
-        pt0, pt1, pf0, pf1 = pads
-        s_t, s_f = CONV_STRIDES[layer]
-        batch, c_in, frames, freq = x.shape
-        t_out, n_tiles, window, step, need = self._conv_tiling(layer, frames, (pt0, pt1))
-        fp = freq + pf0 + pf1
-        nfix = self.conv_tile_batch
-        total = batch * n_tiles
-        calls = -(-total // nfix)
-        # zero-padded input, physical NHWC, long enough for the last (partial) tile
-        xp = torch.zeros((batch, need, fp, c_in), dtype=torch.float32, device=x.device)
-        xp[:, pt0:pt0 + frames, pf0:pf0 + freq, :] = x.permute(0, 2, 3, 1)
-        tiles = torch.zeros((calls * nfix, window, fp, c_in), dtype=torch.float32,
-                            device=x.device)
-        tiles[:total].view(batch, n_tiles, window, fp, c_in).copy_(
-            xp.as_strided((batch, n_tiles, window, fp, c_in),
-                          (need * fp * c_in, step * fp * c_in, fp * c_in, c_in, 1)))
-        return {'tiles': tiles, 'geometry': (batch, c_in, frames, freq, t_out, n_tiles, window,
-                                             step, need, fp, calls)}
-
-    def _conv_fwd_tiled(self, layer, x, pads):
-        """SAME convolution + bias of one layer as fixed-shape calls (see ``conv_mode``).
-        ``x`` logical NCHW / physical NHWC.  Returns (y like the direct path, context)."""
-        p = self.arena.p
-        s_t, s_f = CONV_STRIDES[layer]
-        ctx = self._conv_tiles(layer, x, pads)
-        tiles, nfix = ctx['tiles'], self.conv_tile_batch
-        batch, _, _, _, t_out, n_tiles, _, _, _, _, calls = ctx['geometry']
-        total = batch * n_tiles
-        weight, bias = self._conv_kernel_cl(layer), p['conv{}/bias'.format(layer)]
-        out = None
-        for call in range(calls):
-            yc = torch.ops.aten.convolution(
-                tiles[call * nfix:(call + 1) * nfix].permute(0, 3, 1, 2), weight, bias,
-                [s_t, s_f], [0, 0], [1, 1], False, [0, 0], 1)
-            if out is None:
-                out = torch.empty((calls * nfix,) + (yc.shape[2], yc.shape[3], yc.shape[1]),
-                                  dtype=torch.float32, device=x.device)
-            out[call * nfix:(call + 1) * nfix] = yc.permute(0, 2, 3, 1)
-        f_out, c_out = out.shape[2], out.shape[3]
-        y = out[:total].view(batch, n_tiles * self.conv_tile_frames, f_out, c_out)[:, :t_out] \
-            .contiguous().permute(0, 3, 1, 2)
-        return y, ctx
-
-    def _conv_bwd_tiled(self, layer, dz_phys, ctx, pads, need_dx):
-        """Backward of `_conv_fwd_tiled`: dz physical NHWC [B, T', F', Cout] -> (gradient w.r.t.
-        the layer input, physical NHWC, or None; kernel gradient [Cout, Cin, kt, kf])."""
-        pt0, _, pf0, _ = pads
-        s_t, s_f = CONV_STRIDES[layer]
-        batch, c_in, frames, freq, t_out, n_tiles, window, step, need, fp, calls = ctx['geometry']
-        f_out, c_out = dz_phys.shape[2], dz_phys.shape[3]
-        tiles, nfix, tile = ctx['tiles'], self.conv_tile_batch, self.conv_tile_frames
-        total = batch * n_tiles
-        dz_tiles = torch.zeros((calls * nfix, tile, f_out, c_out), dtype=torch.float32,
-                               device=dz_phys.device)
-        dz_tiles[:total].view(batch, n_tiles * tile, f_out, c_out)[:, :t_out] = dz_phys
-        weight = self._conv_kernel_cl(layer)
-        dw_sum, dx_tiles = None, None
-        if need_dx:
-            dx_tiles = torch.empty_like(tiles)
-        for call in range(calls):
-            sel = slice(call * nfix, (call + 1) * nfix)
-            dxc, dwc, _ = torch.ops.aten.convolution_backward(
-                dz_tiles[sel].permute(0, 3, 1, 2), tiles[sel].permute(0, 3, 1, 2), weight,
-                [c_out], [s_t, s_f], [0, 0], [1, 1], False, [0, 0], 1, [need_dx, True, False])
-            dw_sum = dwc if dw_sum is None else dw_sum.add_(dwc)
-            if need_dx:
-                dx_tiles[sel] = dxc.permute(0, 2, 3, 1)
-        if not need_dx:
-            return None, dw_sum
-        # overlap-add of the input-gradient windows: tiles of equal parity do not overlap
-        dxp = torch.zeros((batch, need, fp, c_in), dtype=torch.float32, device=dz_phys.device)
-        windows = dx_tiles[:total].view(batch, n_tiles, window, fp, c_in)
-        row = fp * c_in
-        for parity in (0, 1):
-            count = (n_tiles - parity + 1) // 2
-            if count > 0:
-                dxp.as_strided((batch, count, window, fp, c_in),
-                               (need * row, 2 * step * row, row, c_in, 1),
-                               parity * step * row).add_(windows[:, parity::2])
-        return dxp[:, pt0:pt0 + frames, pf0:pf0 + freq, :].contiguous(), dw_sum
 
     def _conv_kernel_cl(self, layer):
         """Conv kernel [Cout, Cin, kt, kf] in channels_last memory (scratch copy per call).  The
@@ -932,17 +822,23 @@ class CTCModel:
         if cfg.used_model == 'ds2':
             conv_out = acts['conv_out']
             last = conv_out[-1]
-            b_, c_, tt, ff = last.shape
-            # [T', B, F'*C] -> NCHW [B, C, T', F']
-            # NHWC storage [B, T', F', C] for the gradient as well
-            dact = dy.view(tt, b_, ff, c_).permute(1, 0, 2, 3).contiguous()
+            if acts['last_time_major']:
+                # the last layer's output - and so its gradient - is time-major [T', B, F', C]
+                dact = dy.contiguous().view(last.shape)
+            else:
+                b_, c_, tt, ff = last.shape
+                # [T', B, F'*C] -> NHWC storage [B, T', F', C] for the gradient as well
+                dact = dy.view(tt, b_, ff, c_).permute(1, 0, 2, 3).contiguous()
             for i in range(len(cfg.conv_filters) - 1, -1, -1):
                 name = 'conv{}'.format(i)
+                tm = acts['last_time_major'] and i == len(cfg.conv_filters) - 1
                 # the bias gradient (sum of dz over batch, time and frequency) falls out of the
-                # epilogue's backward pass: channels are the columns of the NHWC view
-                dz = hip.bias_act_bwd(conv_out[i].permute(0, 2, 3, 1), dact, cfg.relu_cutoff,
+                # epilogue's backward pass: channels are the columns of the [.., F, C] view
+                out_phys = conv_out[i] if tm else conv_out[i].permute(0, 2, 3, 1)
+                dz = hip.bias_act_bwd(out_phys, dact, cfg.relu_cutoff,
                                       cfg.conv_dropout_rate, g[name + '/bias'])
-                dz = dz.permute(0, 3, 1, 2)        # logical NCHW view of the NHWC storage
+                if not tm:
+                    dz = dz.permute(0, 3, 1, 2)    # logical NCHW view of the NHWC storage
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 # the 11x21 / stride (1,2) / 32->32 layer has its own data-gradient kernel
                 # (implicit GEMM, any T, no padded intermediates: 0.62 ms vs 1.6 ms at C2)
@@ -952,30 +848,28 @@ class CTCModel:
                                   out=g[name + '/kernel'])
                     done(name)
                     continue
-                own = acts['conv_own'][i] == 's12'
-                own_dx = i > 0 and own
-                need_dx = i > 0 and not own_dx
                 conv_in = acts['conv_in'][i]
-                if own:         # forward kept the plain input only
-                    conv_in = self._conv_wrw_input(i, conv_in, acts['pads'][i])
-                if own_dx:      # (packed by the forward pass of this step)
-                    dact = hip.conv_s12_bwd_data(dz.permute(0, 2, 3, 1), self._conv_packed[i])
-                if self.conv_mode == 'tiled':
-                    dx_phys, dw = self._conv_bwd_tiled(i, dz.permute(0, 2, 3, 1), conv_in,
-                                                       acts['pads'][i], need_dx)
-                    g[name + '/kernel'].copy_(dw)
-                    if need_dx:
-                        dact = dx_phys
-                else:
-                    xp = conv_in
-                    dxp, dw, _ = torch.ops.aten.convolution_backward(
-                        dz, xp, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
-                        list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
-                        [need_dx, True, False])
-                    g[name + '/kernel'].copy_(dw)
-                    if need_dx:
-                        dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1] \
-                            .permute(0, 2, 3, 1).contiguous()
+                if acts['conv_own'][i] == 's12':
+                    # own kernels: kernel gradient straight from the unpadded NHWC input
+                    # (deterministic two-stage reduction), then the data gradient (weights were
+                    # packed by the forward pass of this step)
+                    dz_phys = dz if tm else dz.permute(0, 2, 3, 1)
+                    hip.conv_s12_wrw(dz_phys, conv_in.permute(0, 2, 3, 1), out=g[name + '/kernel'],
+                                     time_major=tm)
+                    if i > 0:
+                        dact = hip.conv_s12_bwd_data(dz_phys, self._conv_packed[i],
+                                                     time_major=tm)
+                    done(name)
+                    continue
+                need_dx = i > 0
+                dxp, dw, _ = torch.ops.aten.convolution_backward(
+                    dz, conv_in, self._conv_kernel_cl(i), [p[name + '/bias'].shape[0]],
+                    list(CONV_STRIDES[i]), [0, 0], [1, 1], False, [0, 0], 1,
+                    [need_dx, True, False])
+                g[name + '/kernel'].copy_(dw)
+                if need_dx:
+                    dact = dxp[:, :, pt0:dxp.shape[2] - pt1, pf0:dxp.shape[3] - pf1] \
+                        .permute(0, 2, 3, 1).contiguous()
                 done(name)
         else:
             dact = dy.reshape(rows, -1)

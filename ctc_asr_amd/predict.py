@@ -27,8 +27,7 @@ def main(argv=None):
         raise ValueError('The input file "{}" does not exist.'.format(FLAGS.input))
     if not torch.cuda.is_available():
         raise SystemExit('ctc_asr_amd.predict needs an MI355X; no GPU is visible.')
-    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=FLAGS.random_seed or 1,
-                     conv_mode=os.environ.get('CTCASR_CONV_MODE', 'tiled'))
+    model = CTCModel(ModelConfig.from_flags(FLAGS), 'cuda', seed=FLAGS.random_seed or 1)
     latest = storage.latest_checkpoint(FLAGS.train_dir)
     if latest is None:
         raise SystemExit('No checkpoint found in {}.'.format(FLAGS.train_dir))

@@ -88,10 +88,8 @@ def main(argv=None):
     if world > 1:
         torch.distributed.barrier()
     cfg = ModelConfig.from_flags(FLAGS)
-    # corpora have utterances of every length: convolutions as fixed-shape tiles, autotuned once
     trainer = Trainer(cfg, flags=FLAGS, device='cuda:{}'.format(local_rank), seed=seed,
-                      world_size=world, rank=rank,
-                      conv_mode=os.environ.get('CTCASR_CONV_MODE', 'tiled'))
+                      world_size=world, rank=rank)
     model = trainer.model
     start_epoch = 1
     latest = storage.latest_checkpoint(FLAGS.train_dir)

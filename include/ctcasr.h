@@ -211,24 +211,37 @@ int ctcasr_colsum_accumulate(const float *dz, float *dbias, int64_t rows, int co
 
 /* ---- the 11 x 21, stride (1, 2) convolutions over 32 input channels of the DS2 stack (layers 2
  * and 3 of conv_layers, asr/util/tf_contrib.py:64-146; TensorFlow SAME padding): forward pass and
- * data gradient as implicit GEMMs on the fp32 MFMA units, NHWC, any number of frames, no padded
+ * data gradient and kernel gradient as implicit GEMMs on the fp32 MFMA units, NHWC, any number of frames, no padded
  * intermediates.  Covered (ctcasr_conv_s12_supported): freq_in = 40, cout = 32 and freq_in = 20,
  * cout = 96.
  *   fwd:       x  [B, T, freq_in, 32]       -> y  [B, T, freq_in/2, cout] = conv(x) + bias|NULL
  *   bwd_data:  dz [B, T, freq_in/2, cout]   -> dx [B, T, freq_in, 32]
+ *   wrw:       dz, x                        -> dw [cout, 32, 11, 21]
  * `packed`: fragment-ordered copies of the kernel w [cout, 32, 11, 21] made by
  * ctcasr_conv_s12_pack_weights, 2 * 11*21*32*cout floats (backward order, then forward order). */
 int ctcasr_conv_s12_supported(int freq_in, int cout);
 int ctcasr_conv_s12_pack_weights(const float *w, float *packed, int cout, ctcasr_stream_t stream);
+/* relu_cutoff > 0: the epilogue also applies min(max(., 0), relu_cutoff) (the ReLU + tf.minimum of
+ * conv_layers; 0 = convolution + bias only).  y_time_major / dz_time_major != 0: that tensor is
+ * laid out [T, B, F, C] instead of [B, T, F, C] - the last layer of the stack hands its output
+ * to the recurrent stack (and takes its gradient back) without a transpose. */
 int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
-                        int T, int freq_in, int cout, ctcasr_stream_t stream);
+                        int T, int freq_in, int cout, float relu_cutoff, int y_time_major,
+                        ctcasr_stream_t stream);
 int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B, int T,
-                             int freq_in, int cout, ctcasr_stream_t stream);
+                             int freq_in, int cout, int dz_time_major, ctcasr_stream_t stream);
+/*   wrw: dz [B, T, freq_in/2, cout], x [B, T, freq_in, 32] -> dw [cout, 32, 11, 21] (overwritten):
+ *        the kernel gradient, split over (b, t) tiles with a deterministic two-stage reduction;
+ *        workspace: per-split partial sums, ctcasr_conv_s12_wrw_workspace_bytes(B, T, freq_in, cout) */
+size_t ctcasr_conv_s12_wrw_workspace_bytes(int B, int T, int freq_in, int cout);
+int ctcasr_conv_s12_wrw(const float *dz, const float *x, float *dw, int B, int T, int freq_in,
+                        int cout, int dz_time_major, void *workspace, size_t workspace_bytes,
+                        ctcasr_stream_t stream);
 
 /* ---- the first DS2 convolution: 1 -> 32 channels, 11 x 41 taps, stride (2, 2), SAME padding ----
  *   fwd: x [B, T, 80] -> y [B, ceil(T/2), 40, 32] (NHWC) = conv(x) + bias|NULL; w [32, 1, 11, 41] */
 int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y, int B, int T,
-                     ctcasr_stream_t stream);
+                     float relu_cutoff, ctcasr_stream_t stream);
 /*   wrw: dz [B, ceil(T/2), 40, 32] (NHWC), x [B, T, 80] -> dw [32, 1, 11, 41] (overwritten);
  *        workspace: per-workgroup partial sums, ctcasr_conv0_wrw_workspace_bytes(B, T) */
 size_t ctcasr_conv0_wrw_workspace_bytes(int B, int T);

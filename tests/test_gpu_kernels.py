@@ -423,7 +423,7 @@ def test_dropout_kernel(hip):
 @pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
 @pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (3, 65), (1, 500)])
 def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
-    """Implicit-GEMM forward and data gradient of the 11x21 / stride (1,2) layers (32 -> 32 channels
+    """Implicit-GEMM forward, data gradient and kernel gradient of the 11x21 / stride (1,2) layers (32 -> 32 channels
     on 40 frequencies, 32 -> 96 on 20) against torch's convolution on the explicitly SAME-padded
     input (pad 5/5 in time, 9/10 in frequency), fp64 on the CPU."""
     batch, frames = shape
@@ -447,10 +447,30 @@ def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
     ref_y = y.detach().permute(0, 2, 3, 1).numpy()
     assert np.abs(y_gpu - ref_y).max() < 2e-4 * max(1.0, np.abs(ref_y).max())
     assert np.abs(y_nobias + bias - ref_y).max() < 2e-4 * max(1.0, np.abs(ref_y).max())
+    w64 = torch.tensor(weight, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w64, torch.tensor(bias, dtype=torch.float64), stride=(1, 2))
     y.backward(torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
     ref = x.grad[:, :, 5:5 + frames, 9:9 + freq].permute(0, 2, 3, 1).numpy()
     assert dx.shape == ref.shape
     assert np.abs(dx - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    # fused epilogue (ReLU + min(., cutoff)) and the time-major variants the last layer of the
+    # stack uses: same numbers, other layout
+    y_act = hip.conv_s12_fwd(_t(x_np), packed, cout, _t(bias), relu_cutoff=1.5).cpu().numpy()
+    assert np.abs(y_act - np.minimum(np.maximum(y_gpu, 0.0), 1.5)).max() < 1e-6
+    y_tm = hip.conv_s12_fwd(_t(x_np), packed, cout, _t(bias), time_major=True)
+    assert tuple(y_tm.shape) == (frames, batch, freq // 2, cout)
+    assert np.array_equal(y_tm.permute(1, 0, 2, 3).cpu().numpy(), y_gpu)
+    dz_tm = _t(dz).permute(1, 0, 2, 3).contiguous()
+    assert np.array_equal(hip.conv_s12_bwd_data(dz_tm, packed, time_major=True).cpu().numpy(), dx)
+    assert torch.equal(hip.conv_s12_wrw(dz_tm, _t(x_np), time_major=True),
+                       hip.conv_s12_wrw(_t(dz), _t(x_np)))
+    # kernel gradient (split over (b, t) tiles, two-stage reduction): deterministic
+    dw = hip.conv_s12_wrw(_t(dz), _t(x_np))
+    dw_again = hip.conv_s12_wrw(_t(dz), _t(x_np))
+    assert torch.equal(dw, dw_again)
+    ref_w = w64.grad.numpy()
+    assert tuple(dw.shape) == ref_w.shape
+    assert np.abs(dw.cpu().numpy() - ref_w).max() < 2e-4 * max(1.0, np.abs(ref_w).max())
 
 
 @pytest.mark.parametrize('shape', [(1, 1), (2, 9), (2, 10), (3, 64), (2, 131), (1, 999), (1, 1000)])
@@ -464,6 +484,8 @@ def test_conv0_fwd_matches_the_library_convolution(hip, shape):
     weight = (rng.normal(size=(32, 1, 11, 41)) * 0.1).astype(np.float32)
     bias = rng.normal(size=32).astype(np.float32)
     y_gpu = hip.conv0_fwd(_t(x_np), _t(weight), _t(bias)).cpu().numpy()
+    y_act = hip.conv0_fwd(_t(x_np), _t(weight), _t(bias), relu_cutoff=0.7).cpu().numpy()
+    assert np.abs(y_act - np.minimum(np.maximum(y_gpu, 0.0), 0.7)).max() < 1e-6
     t_out, pt0, pt1 = same_padding(frames, 11, 2)
     f_out, pf0, pf1 = same_padding(80, 41, 2)
     assert (f_out, pf0, pf1) == (40, 19, 20)

@@ -62,32 +62,6 @@ def test_gradients_through_the_persistent_recurrence(chunks):
     hip.rnn_poll_error('lstm', model._acts['rnn_ws'], 48, 2, 1024)
 
 
-@pytest.mark.parametrize('case,frames,tile,per_call', [('ds2_lstm_3conv', 61, 16, 3),
-                                                       ('ds2_lstm_2conv', 200, 16, 5),
-                                                       ('ds2_lstm_2conv', 95, 128, 32)])
-def test_tiled_convolutions_equal_direct_convolutions(case, frames, tile, per_call):
-    """conv_mode='tiled' (fixed-shape calls over time tiles, for variable-length batches) against
-    the direct convolutions: same logits, loss and gradients; and against the oracle."""
-    cfg, flat, feats, flen, labels = _setup(case, frames=frames)
-    results = {}
-    for mode in ('direct', 'tiled'):
-        model = CTCModel(cfg, 'cuda', params=flat, conv_mode=mode, conv_autotune=False)
-        model.conv_tile_frames, model.conv_tile_batch = tile, per_call
-        logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen),
-                                             training=True)
-        loss = model.loss_fn(logits, seq_len, labels)
-        model.backward()
-        results[mode] = (logits.cpu().numpy(), float(loss), model.arena.export('grad'))
-    assert results['tiled'][0].shape == results['direct'][0].shape
-    assert np.abs(results['tiled'][0] - results['direct'][0]).max() < 1e-4
-    assert abs(results['tiled'][1] - results['direct'][1]) < 1e-3
-    for name, ref_g in results['direct'][2].items():
-        err = np.abs(results['tiled'][2][name] - ref_g).max()
-        assert err < 1e-4 * max(1.0, np.abs(ref_g).max()), (name, err)
-    _check_logits_loss_and_gradients(case, conv_mode='tiled', conv_tile=(tile, per_call),
-                                     frames=frames)
-
-
 @pytest.mark.parametrize('frames,pipelined', [(131, 4), (129, 4), (97, 2), (141, 3)])
 def test_pipelined_forward_equals_single_launch_forward(frames, pipelined):
     """fwd_chunks > 1 (layer 1's forward recurrence on half of the chip in step ranges, layer
@@ -121,15 +95,11 @@ def test_pipelined_forward_equals_single_launch_forward(frames, pipelined):
         assert err < 1e-5 * max(1.0, np.abs(ref_g).max()), (name, err)
 
 
-def _check_logits_loss_and_gradients(case, bwd_chunks=None, conv_mode=None, conv_tile=None,
-                                     **setup):
+def _check_logits_loss_and_gradients(case, bwd_chunks=None, **setup):
     cfg, flat, feats, flen, labels = _setup(case, **setup)
-    model = CTCModel(cfg, 'cuda', params=flat, conv_mode=conv_mode,
-                     conv_autotune=False if conv_mode else None)
+    model = CTCModel(cfg, 'cuda', params=flat)
     if bwd_chunks is not None:
         model.bwd_chunks = bwd_chunks
-    if conv_tile is not None:
-        model.conv_tile_frames, model.conv_tile_batch = conv_tile
     logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
     loss = model.loss_fn(logits, seq_len, labels)
     model.backward()

@@ -42,6 +42,9 @@ def main():
     print('conv_s12_fwd: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     ms = timed(lambda: hip.conv_s12_bwd_data(dz, packed, out))
     print('conv_s12_bwd_data: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    dw = torch.empty(32, 32, 11, 21, device='cuda')
+    ms = timed(lambda: hip.conv_s12_wrw(dz, x, dw))
+    print('conv_s12_wrw: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     xp = torch.zeros(batch, 32, frames + 10, 59, device='cuda') \
         .contiguous(memory_format=torch.channels_last)
     w_cl = weight.contiguous(memory_format=torch.channels_last)
@@ -68,6 +71,15 @@ def main():
     print('MIOpen fwd incl. padding copy: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
     print('fwd max |diff| {:.2e}'.format(
         float((library_fwd().permute(0, 2, 3, 1) - y).abs().max())))
+    def library_wrw():
+        _, dwl, _ = torch.ops.aten.convolution_backward(
+            dz_nchw, xpad, w_cl, [32], [1, 2], [0, 0], [1, 1], False, [0, 0], 1,
+            [False, True, False])
+        return dwl
+    ms = timed(library_wrw)
+    print('MIOpen wrw (padded input given): {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    print('wrw max |diff| {:.2e} of {:.2e}'.format(float((library_wrw() - dw).abs().max()),
+                                                    float(dw.abs().max())))
     # first layer: 1 -> 32 channels, 11x41, stride (2, 2)
     feats = torch.randn(batch, 2 * frames - 1, 80, device='cuda', generator=gen)
     w0 = torch.randn(32, 1, 11, 41, device='cuda', generator=gen) * 0.1

@@ -3,7 +3,7 @@ set -x
 W=${1:-c3}; O=$GRAFT_REPO_ROOT/gpurun_out/${2:-r02/kt_$W}; R=$GRAFT_REPO_ROOT
 mkdir -p $O; cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pf_$W
-rocprofv3 --kernel-trace --stats -d /tmp/pf_$W/kt -o $W -- python $R/bench.py --workload $W --steps 4 --warmup 2 --no-cpu-baseline > $O/kt_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/pf_$W/kt -o $W -- python $R/bench.py --workload $W --steps 4 --warmup 2 --no-cpu-baseline --no-other-workloads > $O/kt_bench.json 2>/dev/null
 DB=$(find /tmp/pf_$W/kt -name "*.db" | head -1)
 python $R/tools/prof_summary.py $DB 45 3 > $O/kt.md
 python $R/tools/prof_summary.py --timeline $DB > $O/timeline.txt

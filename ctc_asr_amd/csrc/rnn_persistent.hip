@@ -75,6 +75,8 @@ struct PArgs {
     SyncWords *sync;
     float *xchg;           // exchange buffer [T steps][2][K/16 chunks][B][16] (see below)
     const float *bias;     // forward: [2, G*H] added to xw (NULL: none)
+    const float *b_hh;     // GRU forward: recurrent bias [2, 3H] (its candidate-gate third is read)
+    float *drec;           // GRU backward: d(recurrent pre-activations) [T, B, 2, 3H]
     int T, B, H, nwg;      // nwg = workgroups per direction (and chain)
     int ndir, dir0;        // directions in this launch (2, or 1 when they run one after the other)
     int chain0;            // first batch tile of this launch
@@ -266,7 +268,12 @@ __device__ __forceinline__ void counters_done(SyncWords *sy, int dir, int chain,
 template <int CELL, int NT, int QW, int MT, int REGW = 0, int CHAINS = 1>
 __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p) {
     static_assert(CHAINS == 1 || (MT == 1 && REGW == 0), "two chains: one batch tile each");
-    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    // G = gate slots in the column layout, GR = gates that exist: the GRU's three gates use the
+    // LSTM's four-slot layout with an all-zero fourth slot (24 real columns per 8 units do not
+    // tile into 16-column MFMA tiles; a quarter of the MFMAs and of the weight slice is padding)
+    constexpr bool GRU = CELL == CTCASR_CELL_GRU;
+    constexpr int G = (CELL == CTCASR_CELL_LSTM || GRU) ? 4 : 1;
+    constexpr int GR = GRU ? 3 : G;
     constexpr int COLS = 16 * NT;
     constexpr int UPB = COLS / G;
     constexpr int QS = QW * NT;          // B-fragment slots per wave
@@ -325,8 +332,9 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     {
         auto slot = [&](int sl) -> float4 {
             const int i = sl / NT, c = (sl % NT) * 16 + (lane & 15);
+            if (GRU && c / UPB >= GR) return make_float4(0.f, 0.f, 0.f, 0.f);
             const float *wrow =
-                p.w + ((size_t)dir * G * H + (c / UPB) * H + u0 + (c % UPB)) * H + kq;
+                p.w + ((size_t)dir * GR * H + (c / UPB) * H + u0 + (c % UPB)) * H + kq;
             return ldg4(wrow + 16 * (wave * QW + i));
         };
         // (two chains share the LDS copy: each stages every other slot)
@@ -345,22 +353,23 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     // per lane quad) was still texture-addresser bound at ~37 GB/s per CU.
     // The buffer starts with an all-zero block of 2*B*G*H floats that no kernel ever writes (rows
     // that are not running read it; zero-filled once with the workspace), the steps follow.
-    const size_t x_base = (size_t)2 * B * G * H;      // floats of the all-zero block
+    const size_t x_base = (size_t)2 * B * GR * H;     // floats of the all-zero block
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         p.xchg, 0, (int)((x_base + (size_t)T * 2 * B * H) * sizeof(float)), 0x00020000);
     const size_t x_step = (size_t)2 * B * H;          // floats per step
     // every workgroup of a direction reads the same rows: start each one at a different chunk so
     // that the 16 workgroups sharing an XCD's L2 do not all hit the same channel at once
     // (register-resident fragments need a static chunk -> register map: no rotation then)
-    const int rot = REGW == 0 ? (slice & (QW - 1)) : 0;
+    const int rot = REGW == 0 ? (slice % QW) : 0;
 
     // ---- per-item state ----------------------------------------------------------------------
     float c_state[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         c_state[it] = 0.f;
-        if constexpr (CELL == CTCASR_CELL_LSTM) {
-            // continuing a pass that an earlier launch started: pick up its cell state
+        if constexpr (CELL == CTCASR_CELL_LSTM || GRU) {
+            // continuing a pass that an earlier launch started: pick up its cell state (LSTM) /
+            // hidden state (GRU: h_{t-1} of the units this thread owns enters z * h_{t-1})
             const int item = tid + it * PRNN_THREADS;
             if (p.s_lo > 0 && item < 16 * MT * UPB && row0 + item / UPB < B)
                 c_state[it] = p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB];
@@ -375,14 +384,17 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     }
     // the input projection's bias: an item's unit is the same in every step, so its G bias
     // values live in registers (saves the bias epilogue of the xw GEMM: 0.23 ms of 4.16 at C3)
-    float xb[ITEMS][G];
+    float xb[ITEMS][GR], bq[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = tid + it * PRNN_THREADS;
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int g = 0; g < GR; ++g)
             xb[it][g] = p.bias && item < 16 * MT * UPB
-                            ? p.bias[(size_t)dir * G * H + (size_t)g * H + u0 + item % UPB] : 0.f;
+                            ? p.bias[(size_t)dir * GR * H + (size_t)g * H + u0 + item % UPB] : 0.f;
+        // GRU: the candidate gate's recurrent bias stays inside r * (R_n h + b_Rn)
+        bq[it] = GRU && item < 16 * MT * UPB
+                     ? p.b_hh[(size_t)dir * 3 * H + 2 * H + u0 + item % UPB] : 0.f;
     }
 
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
@@ -392,7 +404,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
         unsigned long long c0 = prof ? wall_clock64() : 0;
         // gate pre-activations from the input projection: independent of the recurrence, so
         // they are requested before waiting for the other workgroups
-        float xw[ITEMS][G];
+        float xw[ITEMS][GR];
         int it_t[ITEMS];
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -405,9 +417,9 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
                     if (s < steps) {
                         const int t = row_time(dir, s, steps);
                         it_t[it] = t;
-                        const float *x = p.xw + (((size_t)t * B + b) * 2 + dir) * G * H + u0 + u;
+                        const float *x = p.xw + (((size_t)t * B + b) * 2 + dir) * GR * H + u0 + u;
 #pragma unroll
-                        for (int g = 0; g < G; ++g) xw[it][g] = x[(size_t)g * H] + xb[it][g];
+                        for (int g = 0; g < GR; ++g) xw[it][g] = x[(size_t)g * H] + xb[it][g];
                     }
                 }
             }
@@ -444,7 +456,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
                                                  sizeof(float));
 #pragma unroll
                 for (int i = 0; i < QW; ++i)
-                    a[mt][i] = load16_sc1(x_rsrc, aoff + (unsigned)(((i + rot) & (QW - 1)) *
+                    a[mt][i] = load16_sc1(x_rsrc, aoff + (unsigned)(((i + rot) % QW) *
                                                                     B * 64));
             }
             // keep every exchange load above the MFMA loop: hipcc otherwise sinks each load next to
@@ -453,7 +465,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
             // B fragments one chunk ahead of the MFMAs that consume them (see the backward kernel)
             auto bfrag = [&](int i, int nt) -> float4 {     // compile-time slot when REGW > 0
                 if constexpr (REGW == 0) {
-                    return frag[(wave * QL + ((i + rot) & (QW - 1)) * NT + nt) * 64 + lane];
+                    return frag[(wave * QL + ((i + rot) % QW) * NT + nt) * 64 + lane];
                 } else {
                     const int sl = i * NT + nt;
                     return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
@@ -515,9 +527,9 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
             if (it_t[it] >= 0) {
                 const int item = tid + it * PRNN_THREADS;
                 const int b = item / UPB, u = item % UPB;      // row within the tile
-                float rec[G];
+                float rec[GR];
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
+                for (int g = 0; g < GR; ++g) {
                     const int c = g * UPB + u;
                     float sum = 0.f;
 #pragma unroll
@@ -535,6 +547,15 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
                     hv[it] = go * tanhf_(c);
                     rsv[it][0] = gi; rsv[it][1] = gf; rsv[it][2] = gg; rsv[it][3] = go;
                     rsv[it][4] = c;
+                } else if constexpr (GRU) {
+                    // cuDNN GRU: n = tanh(W_n x + b_Wn + r * (R_n h + b_Rn)); h = (1-z) n + z h'
+                    const float gr_ = sigmoidf_(xw[it][0] + rec[0]);
+                    const float gz = sigmoidf_(xw[it][1] + rec[1]);
+                    const float q = rec[2] + bq[it];
+                    const float gn = tanhf_(xw[it][2] + gr_ * q);
+                    hv[it] = (1.f - gz) * gn + gz * c_state[it];
+                    c_state[it] = hv[it];
+                    rsv[it][0] = gr_; rsv[it][1] = gz; rsv[it][2] = gn; rsv[it][3] = q;
                 } else {
                     const float pre = xw[it][0] + rec[0];
                     hv[it] = CELL == CTCASR_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf_(pre);
@@ -563,7 +584,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
             const int b = row0 + item / UPB, unit = u0 + item % UPB;
             p.y[((size_t)it_t[it] * B + b) * 2 * H + dir * H + unit] = hv[it];
         }
-        if constexpr (CELL == CTCASR_CELL_LSTM) {
+        if constexpr (CELL == CTCASR_CELL_LSTM || GRU) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 if (it_t[it] < 0) continue;
@@ -572,12 +593,13 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
                 float *gr = p.gates + (((size_t)it_t[it] * B + b) * 2 + dir) * 4 * H + unit;
                 gr[0] = rsv[it][0]; gr[H] = rsv[it][1]; gr[2 * H] = rsv[it][2];
                 gr[3 * H] = rsv[it][3];
-                p.cells[(((size_t)it_t[it] * B + b) * 2 + dir) * H + unit] = rsv[it][4];
+                if constexpr (!GRU)
+                    p.cells[(((size_t)it_t[it] * B + b) * 2 + dir) * H + unit] = rsv[it][4];
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
     }
-    if constexpr (CELL == CTCASR_CELL_LSTM) {
+    if constexpr (CELL == CTCASR_CELL_LSTM || GRU) {
         if (p.s_hi < T) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -616,7 +638,8 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
 template <int CELL, int QW, int MT, int LB, int UPB, int REGW, int CHAINS = 1>
 __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p) {
     static_assert(CHAINS == 1 || MT == 1, "two chains: one batch tile each");
-    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : 1;
+    constexpr bool GRU = CELL == CTCASR_CELL_GRU;
+    constexpr int G = CELL == CTCASR_CELL_LSTM ? 4 : (GRU ? 3 : 1);
     constexpr bool HALF_TILE = UPB == 8;
     // UPB = 32: TWO N tiles per workgroup.  The B-fragment slots of a wave then alternate
     // (tile 0, chunk c), (tile 1, chunk c): QW counts slots, every A chunk feeds a pair of them,
@@ -708,13 +731,14 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     const size_t x_base = x_step;
     // de-synchronise the workgroups' walk over the chunks (LDS-only variant; register-resident
     // fragments need a static chunk -> register map)
-    const int rot = REGW == 0 ? (slice & (QW - 1)) : 0;
+    const int rot = REGW == 0 ? (slice % QW) : 0;
     float dc_state[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         dc_state[it] = 0.f;
-        if constexpr (CELL == CTCASR_CELL_LSTM) {
+        if constexpr (CELL == CTCASR_CELL_LSTM || GRU) {
             // continuing a pass that an earlier launch started: pick up its cell-state gradient
+            // (LSTM) / the dh * z term of the step above (GRU)
             const int item = tid + it * PRNN_THREADS;
             if (p.s_hi < T && item < 16 * MT * UPB && row0 + item / UPB < B)
                 dc_state[it] = p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB];
@@ -756,6 +780,16 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                             if (s > 0) {
                                 const int tp = row_time(dir, s - 1, steps);
                                 cpv[it] = p.cells[(((size_t)tp * B + b) * 2 + dir) * H + unit];
+                            }
+                        } else if constexpr (GRU) {
+                            // r, z, n, q = R_n h + b_Rn of this step; h of the step before
+                            const float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+                            gv[it][0] = gr[0]; gv[it][1] = gr[H];
+                            gv[it][2] = gr[2 * H]; gv[it][3] = gr[3 * H];
+                            hv[it] = 0.f;
+                            if (s > 0) {
+                                const int tp = row_time(dir, s - 1, steps);
+                                hv[it] = p.y[((size_t)tp * B + b) * 2 * H + dir * H + unit];
                             }
                         } else {
                             hv[it] = p.y[((size_t)t * B + b) * 2 * H + dir * H + unit];
@@ -801,7 +835,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < LA; ++i) {
-                        const int c = (nb * LA + i + rot) & (QA - 1);
+                        const int c = (nb * LA + i + rot) % QA;
                         // chunk index in n-space: gate * (H / 16) + unit chunk
                         const unsigned off = (unsigned)(((size_t)(c / CPG) * (H / 16) + (c % CPG)) *
                                                         B * 16 * sizeof(float));
@@ -819,7 +853,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
             // order - hipcc otherwise sinks each read next to its first use.
             auto bfrag = [&](int c) -> float4 {      // c: chunk index, compile-time after unrolling
                 if constexpr (REGW == 0) {
-                    return frag[(wave * QL + ((c + rot) & (QW - 1))) * SLOTS + half];
+                    return frag[(wave * QL + ((c + rot) % QW)) * SLOTS + half];
                 } else {
                     return c < QL ? frag[(wave * QL + c) * SLOTS + half] : wreg[c - QL];
                 }
@@ -872,7 +906,9 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
 
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            float dg[G];
+            // dg: what is published for the recurrence (GRU: drec, the candidate gate scaled by
+            // r); dxn: the GRU's dxw entry of the candidate gate (not scaled)
+            float dg[G], dxn = 0.f;
 #pragma unroll
             for (int g = 0; g < G; ++g) dg[g] = 0.f;
             const int item = tid + it * PRNN_THREADS;
@@ -891,6 +927,14 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                     dg[2] = dc * gi * (1.f - gg * gg);
                     dg[3] = dh * tc * go * (1.f - go);
                     dc_state[it] = dc * gf;
+                } else if constexpr (GRU) {
+                    const float gr_ = gv[it][0], gz = gv[it][1], gn = gv[it][2], q = gv[it][3];
+                    const float dht = dh + dc_state[it];          // + dh_{s+1} * z_{s+1}
+                    dxn = dht * (1.f - gz) * (1.f - gn * gn);
+                    dg[1] = dht * (hv[it] - gn) * gz * (1.f - gz);
+                    dg[0] = dxn * q * gr_ * (1.f - gr_);
+                    dg[2] = dxn * gr_;
+                    dc_state[it] = dht * gz;
                 } else {
                     const float h = hv[it];
                     dg[0] = CELL == CTCASR_CELL_RNN_RELU ? (h > 0.f ? dh : 0.f)
@@ -916,14 +960,19 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
             if (it_t[it] >= 0) {      // dxw in its GEMM layout: read after the launch only
                 float *dx = p.dxw + (((size_t)it_t[it] * B + row0 + b) * 2 + dir) * GH + u0 + u;
 #pragma unroll
-                for (int g = 0; g < G; ++g) dx[(size_t)g * H] = dg[g];
+                for (int g = 0; g < G; ++g) dx[(size_t)g * H] = GRU && g == 2 ? dxn : dg[g];
+                if constexpr (GRU) {  // drec: dW_hh and db_hh are GEMMs / column sums of it
+                    float *dr = p.drec + (((size_t)it_t[it] * B + row0 + b) * 2 + dir) * GH + u0 + u;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) dr[(size_t)g * H] = dg[g];
+                }
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
         if (s > p.s_lo) dir_arrive<CHAINS>(p.sync, cs, dir, chain, grp, tid, arrivals);
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
     }
-    if constexpr (CELL == CTCASR_CELL_LSTM) {
+    if constexpr (CELL == CTCASR_CELL_LSTM || GRU) {
         if (p.s_lo > 0) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -1018,10 +1067,13 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
     // recurrent weights per direction fit the chip's LDS + registers only one direction at a time,
     // so its two directions run as two launches of 256 workgroups each.
     const bool lstm = cell == CTCASR_CELL_LSTM && (H == 1024 || H == 2048);
+    // the GRU rides on the LSTM kernels' four-gate column layout (fourth slot empty)
+    const bool gru = cell == CTCASR_CELL_GRU && (H == 1024 || H == 2048);
     const bool rnn = (cell == CTCASR_CELL_RNN_RELU || cell == CTCASR_CELL_RNN_TANH) && H == 2048;
-    if (!(lstm || rnn) || B < 1 || B > 32 || T < 1) return 0;
+    if (!(lstm || gru || rnn) || B < 1 || B > 32 || T < 1) return 0;
     // the exchange buffer is addressed through a 32-bit buffer descriptor
-    if ((size_t)(T + 1) * 2 * B * (lstm ? 4 : 1) * H * sizeof(float) >= (1ull << 31)) return 0;
+    if ((size_t)(T + 1) * 2 * B * (lstm ? 4 : (gru ? 3 : 1)) * H * sizeof(float) >= (1ull << 31))
+        return 0;
     const char *mode = getenv("CTCASR_RNN_MODE");   // "stream" forces the per-step kernels
     if (mode && mode[0] == 's') return 0;
     return device_cu_count() >= 256 ? 1 : 0;
@@ -1042,15 +1094,16 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
 }
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
-             const int32_t *seq_len, int T, int B, int H, float *y, float *gates, float *cells,
-             void *sync, float *carry, int step_begin, int step_end, int flags, hipStream_t s) {
+             const float *b_hh_n, const int32_t *seq_len, int T, int B, int H, float *y,
+             float *gates, float *cells, void *sync, float *carry, int step_begin, int step_end,
+             int flags, hipStream_t s) {
     // forward default: the whole chip (nothing of the same layer can overlap it)
     const bool fwd_half_chip = (flags & CTCASR_RNN_HALF_CHIP) != 0;
     PArgs p = {};
     p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
-    p.bias = xw_bias;
+    p.bias = xw_bias; p.b_hh = b_hh_n;
     p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.sync = reinterpret_cast<SyncWords *>(sync);
     p.T = T; p.B = B; p.H = H;
@@ -1066,7 +1119,7 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
                              (size_t)NT_ * 4 * QW_ * 64 * 16 +                                 \
                                  (size_t)4 * NT_ * MT_ * 16 * 17 * 4 + 32, s)
     p.nwg = 128;
-    if (cell == CTCASR_CELL_LSTM && H == 2048) {
+    if ((cell == CTCASR_CELL_LSTM || cell == CTCASR_CELL_GRU) && H == 2048) {
         // 8 units = 2 N tiles per workgroup, 256 workgroups = the whole chip for ONE direction:
         // 32 x 2048 x 4 B = 256 KB per workgroup, half in LDS, half in registers.  Directions (and
         // 16-row batch tiles) one after the other, each launch with its own counters.
@@ -1074,12 +1127,25 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
         for (int tile = 0; tile < mt; ++tile)
             for (int dir = 0; dir < 2; ++dir) {
                 p.chain0 = tile; p.dir0 = dir;
-                const int rc = launch_persistent(
-                    prnn_fwd_kernel<CTCASR_CELL_LSTM, 2, 32, 1, 32>, p,
-                    (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 + 32, s);
+                const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 + 32;
+                const int rc = cell == CTCASR_CELL_LSTM
+                    ? launch_persistent(prnn_fwd_kernel<CTCASR_CELL_LSTM, 2, 32, 1, 32>, p, lds, s)
+                    : launch_persistent(prnn_fwd_kernel<CTCASR_CELL_GRU, 2, 32, 1, 32>, p, lds, s);
                 if (rc != CTCASR_OK) return rc;
             }
         return CTCASR_OK;
+    }
+    if (cell == CTCASR_CELL_GRU) {
+        // H = 1024: the LSTM's geometry (8 units per workgroup, 128 per direction; B > 16: one
+        // group of 2 x 64 sixteen-unit workgroups per batch tile)
+        if (mt == 2 && !one_barrier) {
+            p.nwg = 64;
+            return launch_persistent(prnn_fwd_kernel<CTCASR_CELL_GRU, 4, 16, 1, 32>, p,
+                                     (size_t)4 * 32 * 64 * 16 + (size_t)4 * 4 * 16 * 17 * 4 + 32,
+                                     s, 1, mt);
+        }
+        if (mt == 1) { PRNN_FWD(CTCASR_CELL_GRU, 2, 16, 1); }
+        PRNN_FWD(CTCASR_CELL_GRU, 2, 16, 2);
     }
     // LSTM on 64 workgroups per direction: 16 units = 4 N tiles each, 256 KB of weights - half in
     // LDS, half in registers.  Two uses: (1) B <= 16 with CTCASR_RNN_HALF_CHIP (128 CUs stay free
@@ -1109,12 +1175,13 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
 
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, void *sync, float *carry, int step_begin, int step_end, int flags,
-             hipStream_t s) {
+             float *dxw, float *drec, void *sync, float *carry, int step_begin, int step_end,
+             int flags, hipStream_t s) {
     PArgs p = {};
     p.s_lo = step_begin; p.s_hi = step_end; p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;
+    p.drec = drec;
     p.gates = const_cast<float *>(gates); p.cells = const_cast<float *>(cells);
     p.sync = reinterpret_cast<SyncWords *>(sync);
     // backward default: half of the chip (measured faster than the whole-chip variant even
@@ -1124,9 +1191,12 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
+    const int gates_k = cell == CTCASR_CELL_LSTM ? 4 : (cell == CTCASR_CELL_GRU ? 3 : 1);
     if (seq_len && step_end == T &&
-        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * (cell == CTCASR_CELL_LSTM ? 4 : 1) * H *
-                                   sizeof(float), s) != hipSuccess)
+        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * gates_k * H * sizeof(float), s) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    if (seq_len && step_end == T && cell == CTCASR_CELL_GRU &&
+        hipMemsetAsync(drec, 0, (size_t)T * B * 2 * 3 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
     // batches of 17..32 rows = two independent 16-row tiles (see ChainSync):
@@ -1140,6 +1210,30 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                              (size_t)4 * (QW_ - REGW_) * (UPB_ == 8 ? 32 : 64) * 16 +          \
                                  (size_t)CH_ * (4 * (UPB_ == 32 ? 2 : 1) * MT_ * 16 * 17 * 4 + \
                                                 16) + 16, s, CH_, TG_)
+    if (cell == CTCASR_CELL_GRU && H == 2048) {
+        // like the LSTM at H = 2048: 8 units x 6144 x 4 B = 192 KB per workgroup = 128 KB LDS +
+        // 128 registers per lane (half tiles), one direction per launch
+        p.nwg = 256; p.ndir = 1;
+        for (int tile = 0; tile < mt; ++tile)
+            for (int dir = 0; dir < 2; ++dir) {
+                p.chain0 = tile; p.dir0 = dir;
+                const int rc = launch_persistent(
+                    prnn_bwd_kernel<CTCASR_CELL_GRU, 96, 1, 8, 8, 32>, p,
+                    (size_t)4 * 64 * 32 * 16 + (size_t)4 * 16 * 17 * 4 + 32, s);
+                if (rc != CTCASR_OK) return rc;
+            }
+        return CTCASR_OK;
+    }
+    if (cell == CTCASR_CELL_GRU) {
+        // H = 1024, 16 units x 3072 x 4 B = 192 KB per workgroup (128 KB LDS + 64 registers),
+        // 64 workgroups per direction; B > 16: two chains per workgroup (half of the chip) or one
+        // group of workgroups per batch tile (whole chip)
+        p.nwg = H / 16;
+        if (chains && !half_chip) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 16, 16, 16, 1, 2); }
+        if (mt == 1) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 16, 16, 16, 1, 1); }
+        if (chains) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 8, 16, 16, 2, 1); }
+        PRNN_BWD(CTCASR_CELL_GRU, 48, 2, 8, 16, 16, 1, 1);
+    }
     if (cell == CTCASR_CELL_LSTM && H == 2048) {
         // 8 units per workgroup (half MFMA tiles: 16 units would be 512 KB of weights), 256
         // workgroups = the whole chip for ONE direction; 8 x 8192 x 4 B = 256 KB per workgroup =

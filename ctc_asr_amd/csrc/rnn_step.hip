@@ -284,12 +284,13 @@ size_t prnn_sync_bytes();
 size_t prnn_error_offset();
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
-             const int32_t *seq_len, int T, int B, int H, float *y, float *gates, float *cells,
-             void *sync, float *carry, int step_begin, int step_end, int flags, hipStream_t s);
+             const float *b_hh_n, const int32_t *seq_len, int T, int B, int H, float *y,
+             float *gates, float *cells, void *sync, float *carry, int step_begin, int step_end,
+             int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, void *sync, float *carry, int step_begin, int step_end, int flags,
-             hipStream_t s);
+             float *dxw, float *drec, void *sync, float *carry, int step_begin, int step_end,
+             int flags, hipStream_t s);
 
 static size_t rnn_state_bytes(int B, int H) {
     return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256);
@@ -348,7 +349,7 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_b
     p.cbuf = p.hbuf + (size_t)4 * B * H;
     p.T = T; p.B = B; p.H = H; p.b_hh = b_hh_n; p.xw_bias = xw_bias;
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
-        return prnn_fwd(cell, xw, xw_bias, w_hh, seq_len, T, B, H, y, p.gates, p.cells,
+        return prnn_fwd(cell, xw, xw_bias, w_hh, b_hh_n, seq_len, T, B, H, y, p.gates, p.cells,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
                         step_begin, step_end, flags, s);
     if (seq_len && step_begin == 0 &&
@@ -410,7 +411,7 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     p.T = T; p.B = B; p.H = H;
     p.drec = p.gates + (size_t)T * B * 2 * 4 * H;      // GRU: behind r, z, n, q in the reserve
     if (ctcasr_rnn_persistent_supported(cell, T, B, H))
-        return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw,
+        return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw, p.drec,
                         reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
                         step_begin, step_end, flags, s);
     if (seq_len && step_end == T &&

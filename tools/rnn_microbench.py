@@ -31,11 +31,12 @@ def main():
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
     dy = torch.randn(T, B, 2 * H, device='cuda', generator=g)
     wt = hip.transpose_batched(w)
-    y, reserve, ws = hip.rnn_fwd(cell, xw, w, flags=fwd_flags)
+    b_hh = torch.randn(2, G * H, device='cuda', generator=g) * 0.3 if cell == 'gru' else None
+    y, reserve, ws = hip.rnn_fwd(cell, xw, w, flags=fwd_flags, b_hh_n=b_hh)
     dxw = hip.rnn_bwd(cell, dy, y, wt, reserve, workspace=ws, flags=bwd_flags)
     hip.rnn_poll_error(cell, ws, T, B, H)
     for name, fn in (('fwd', lambda: hip.rnn_fwd(cell, xw, w, y=y, reserve=reserve, workspace=ws,
-                                              flags=fwd_flags)),
+                                              flags=fwd_flags, b_hh_n=b_hh)),
                      ('bwd', lambda: hip.rnn_bwd(cell, dy, y, wt, reserve, dxw=dxw, workspace=ws,
                                               flags=bwd_flags))):
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

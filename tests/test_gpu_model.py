@@ -62,6 +62,20 @@ def test_gradients_through_the_persistent_recurrence(chunks):
     hip.rnn_poll_error('lstm', model._acts['rnn_ws'], 48, 2, 1024)
 
 
+@pytest.mark.parametrize('case,hidden,batch', [('ds2_gru', 1024, 2), ('ds2_gru', 2048, 3),
+                                               ('ds2_lstm_2conv', 2048, 2),
+                                               ('ds2_lstm_2conv', 1024, 19)])
+def test_gradients_through_the_other_persistent_kernels(case, hidden, batch):
+    """Whole-model parity (logits, loss, every gradient) for the shapes that take the round-2
+    persistent kernels: GRU at H = 1024 / 2048, the LSTM at H = 2048 (one direction per launch),
+    and a batch of 19 rows (two 16-row tiles with their own barriers)."""
+    from ctc_asr_amd import hip
+    cell = 'gru' if 'gru' in case else 'lstm'
+    assert hip.rnn_persistent_supported(cell, 40, batch, hidden)
+    model = _check_logits_loss_and_gradients(case, hidden=hidden, frames=79, batch=batch)
+    model.check_rnn_error()
+
+
 @pytest.mark.parametrize('frames,pipelined', [(131, 4), (129, 4), (97, 2), (141, 3)])
 def test_pipelined_forward_equals_single_launch_forward(frames, pipelined):
     """fwd_chunks > 1 (layer 1's forward recurrence on half of the chip in step ranges, layer

@@ -120,7 +120,8 @@ def _cpu_baseline_worker(spec):
         t0 = time.perf_counter()
         proxy()
         sweep[threads] = time.perf_counter() - t0
-        if time.perf_counter() > deadline:
+        # more threads only get slower from here (oversubscribed LSTM steps): stop sweeping
+        if time.perf_counter() > deadline or sweep[threads] > 1.5 * min(sweep.values()):
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)

@@ -184,3 +184,64 @@ def test_adam_full_size_against_plain_torch(hip):
     assert float((param - p_ref).abs().max()) < 6e-8    # 2 ulp at |param| ~ 0.25
     # "checksum of checksums": the update moved the parameters by the expected total amount
     assert abs(float(param.double().sum()) - float(p_ref.double().sum())) < 1e-3
+
+
+@pytest.mark.parametrize('layer,batch', [((40, 32), 32), ((20, 96), 16)])
+def test_convolution_kernels_are_adjoint_at_full_size(hip, layer, batch):
+    """C3-sized convolution (batch 32, T' = 500): forward, data gradient and kernel gradient are
+    three views of one bilinear form, so  <dz, conv(x; w)> = <x, bwd_data(dz; w)> =
+    <w, wrw(dz, x)>  ties the three own kernels together without any reference (fp64 sums of
+    fp32 results: relative 1e-4); the kernel gradient is deterministic and linear in dz, and the
+    time-major variants of the last layer give the same numbers."""
+    freq, cout = layer
+    frames = 500
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(batch, frames, freq, 32, device=DEV, generator=gen)
+    dz = torch.randn(batch, frames, freq // 2, cout, device=DEV, generator=gen)
+    w = torch.randn(cout, 32, 11, 21, device=DEV, generator=gen) * 0.05
+    packed = hip.conv_s12_pack_weights(w)
+    y = hip.conv_s12_fwd(x, packed, cout)
+    dx = hip.conv_s12_bwd_data(dz, packed)
+    dw = hip.conv_s12_wrw(dz, x)
+    form_y = float((dz.double() * y.double()).sum())
+    form_x = float((x.double() * dx.double()).sum())
+    form_w = float((w.double() * dw.double()).sum())
+    scale = max(abs(form_y), 1.0)
+    assert abs(form_x - form_y) < 1e-4 * scale and abs(form_w - form_y) < 1e-4 * scale
+    assert torch.equal(hip.conv_s12_wrw(dz, x), dw)                       # deterministic
+    dw2 = hip.conv_s12_wrw(2.0 * dz, x)
+    assert float((dw2 - 2.0 * dw).abs().max()) <= 1e-3 * float(dw.abs().max())   # linear in dz
+    dz_tm = dz.permute(1, 0, 2, 3).contiguous()
+    assert torch.equal(hip.conv_s12_wrw(dz_tm, x, time_major=True), dw)
+    assert torch.equal(hip.conv_s12_bwd_data(dz_tm, packed, time_major=True), dx)
+    assert torch.equal(hip.conv_s12_fwd(x, packed, cout, time_major=True).permute(1, 0, 2, 3), y)
+
+
+@pytest.mark.parametrize('batch', [32, 24])
+def test_two_tile_recurrences_equal_the_single_barrier_kernels_at_full_size(hip, batch):
+    """C3 shape (T' = 500, H = 1024, batch 32; and a ragged second tile, batch 24): the round-2
+    kernels that run the two 16-row batch tiles as independent recurrences - forward and
+    whole-chip backward as groups of workgroups per tile, half-chip backward as two chains per
+    workgroup - against the kernels that walk both tiles behind one barrier (same arithmetic
+    per tile: 1e-6 / 1e-5), and every one of them is deterministic."""
+    num_steps, hidden = 500, 1024
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    xw = torch.randn(num_steps, batch, 2, 4 * hidden, device=DEV, generator=gen) * 0.5
+    w_hh = torch.randn(2, 4 * hidden, hidden, device=DEV, generator=gen) / 32
+    bias = torch.randn(2 * 4 * hidden, device=DEV, generator=gen) * 0.1
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=gen)
+    w_hh_t = hip.transpose_batched(w_hh)
+    y_ref, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh, xw_bias=bias, flags=hip.RNN_ONE_BARRIER)
+    y_new, reserve_new, _ = hip.rnn_fwd('lstm', xw, w_hh, xw_bias=bias, workspace=ws)
+    y_again, _, _ = hip.rnn_fwd('lstm', xw, w_hh, xw_bias=bias, workspace=ws)
+    assert torch.equal(y_new, y_again)
+    assert float((y_new - y_ref).abs().max()) < 1e-6
+    assert float((reserve_new.view(torch.float32) - reserve.view(torch.float32)).abs().max()) < 1e-5
+    dxw_ref = hip.rnn_bwd('lstm', dy, y_ref, w_hh_t, reserve, workspace=ws,
+                          flags=hip.RNN_ONE_BARRIER)
+    for flags in (hip.RNN_DEFAULT, hip.RNN_WHOLE_CHIP, hip.RNN_WHOLE_CHIP | hip.RNN_ONE_BARRIER):
+        dxw = hip.rnn_bwd('lstm', dy, y_ref, w_hh_t, reserve, workspace=ws, flags=flags)
+        again = hip.rnn_bwd('lstm', dy, y_ref, w_hh_t, reserve, workspace=ws, flags=flags)
+        assert torch.equal(dxw, again), flags
+        assert float((dxw - dxw_ref).abs().max()) < 1e-5 * max(1.0, float(dxw_ref.abs().max()))
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)

@@ -735,8 +735,11 @@ class CTCModel:
             # utterance (no per-row lengths: the cuDNN-semantics path) - dxw of a finished range
             # of steps is final, so its share of dW_ih / dW_hh starts on the side stream while the
             # next launch carries the recurrence on.
+            # (Not for the LSTM at H = 2048: its backward kernel occupies the whole chip one
+            # direction at a time, nothing could run beside it.)
             chunks = 1
             if (side is not main and acts['rnn_len'] is None and cell != 'gru' and
+                    not (cell == 'lstm' and hidden == 2048) and
                     t_out >= 8 * self.bwd_chunks and
                     hip.rnn_persistent_supported(cell, t_out, batch, hidden)):
                 chunks = self.bwd_chunks

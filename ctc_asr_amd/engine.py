@@ -13,7 +13,6 @@ import os
 import torch
 import torch.distributed as dist
 
-from ctc_asr_amd import hip
 from ctc_asr_amd.model import CTCModel
 
 

@@ -6,7 +6,6 @@ model in evaluation mode; reports the CTC loss and the two ``eval_metric_ops`` o
 batches of the per-batch mean.  Decoding is the CTC beam search of width ``FLAGS.beam_width``.
 """
 
-import os
 import sys
 
 import numpy as np

@@ -21,7 +21,7 @@ from ctc_asr_amd import storage, summaries, tf_bundle
 from ctc_asr_amd.engine import Trainer, init_distributed
 from ctc_asr_amd.evaluate import evaluate_dataset
 from ctc_asr_amd.input_functions import input_fn_generator
-from ctc_asr_amd.model import CTCModel, ModelConfig
+from ctc_asr_amd.model import ModelConfig
 from ctc_asr_amd.params import FLAGS, get_parameters
 
 

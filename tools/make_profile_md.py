@@ -8,7 +8,6 @@ file bench.py reads ``roofline.traffic`` from), keyed by workload, pass and step
 """
 import json
 import os
-import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -11,13 +11,13 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ctc_asr_amd import synth, train  # noqa: E402
-from ctc_asr_amd.params import FLAGS  # noqa: E402
 
 
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 96
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    log_frequency = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     rng = np.random.default_rng(0)
     with tempfile.TemporaryDirectory() as tmp:
         corpus = os.path.join(tmp, 'corpus')
@@ -32,7 +32,7 @@ def main():
                     '--feature_type=mel', '--used_model=ds2', '--conv_filters=32',
                     '--conv_filters=32', '--num_layers_rnn=2', '--num_units_rnn=1024',
                     '--rnn_cell=lstm', '--num_units_dense=2048', '--max_epochs={}'.format(epochs),
-                    '--beam_width=64', '--log_frequency=4', '--random_seed=5'])
+                    '--beam_width=64', '--log_frequency={}'.format(log_frequency), '--random_seed=5'])
         print('total wall time {:.1f} s'.format(time.perf_counter() - t0))
 
 

@@ -323,6 +323,14 @@ def measure(name, args, rank, local_rank, world):
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
                 roofline.update(pmc_traffic(name, dom, round(launch_steps)))
+                # the H=1024 backward kernel runs on half the chip by default: the weight-gradient
+                # GEMMs of the steps it has finished fill the other 128 CUs
+                cus = 128 if (dom == 'rnn_bwd' and hidden == 1024 and
+                              not args.rnn_bwd_whole_chip) else 256
+                roofline.update({
+                    'cus_occupied': cus,
+                    'frac_of_occupied_cus': round(
+                        achieved / (FP32_MFMA_PEAK_TFLOPS * cus / 256.0), 4)})
                 roofline.update({
                     'avg_launch_us': round(avg_s * 1e6, 1), 'launches': calls,
                     'algorithmic_flops_per_launch': flops_per_step * launch_steps,

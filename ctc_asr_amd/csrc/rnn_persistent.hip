@@ -38,6 +38,12 @@
 #ifndef PRNN_XCD_AWARE
 #define PRNN_XCD_AWARE 0
 #endif
+#ifndef PRNN_CHAIN_LB
+#define PRNN_CHAIN_LB 4
+#endif
+#ifndef PRNN_CHAIN_REGW
+#define PRNN_CHAIN_REGW 32
+#endif
 #ifndef PRNN_CHAIN0_PRIO
 #define PRNN_CHAIN0_PRIO 1
 #endif
@@ -1204,6 +1210,11 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     //     against 12.1 for the kernel that walks both tiles behind one barrier;
     //   whole chip: each tile as its own group of half-chip workgroups (2 x 128 in one launch),
     //     7.1 us per step against 14.0.
+    // (The two chains of a workgroup share the CU's in-order vector-memory queue: the bulk
+    // exchange loads of one chain sit in front of the other's latency-critical publish stores,
+    // arrival atomic and poll loads.  More loads in flight per chain - PRNN_CHAIN_LB 8 with
+    // PRNN_CHAIN_REGW 28 to stay spill-free - shorten the load + MFMA phase, 6.8 -> 5.1 us, and
+    // lengthen publish + wait by as much, 4.1 -> 6.1 us: 11.8 us per step against 11.3.)
     const bool chains = mt == 2 && !(flags & CTCASR_RNN_ONE_BARRIER);
 #define PRNN_BWD(CELL_, QW_, MT_, LB_, UPB_, REGW_, CH_, TG_)                                  \
     return launch_persistent(prnn_bwd_kernel<CELL_, QW_, MT_, LB_, UPB_, REGW_, CH_>, p,        \
@@ -1256,7 +1267,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
         }
         if (half_chip) {
             if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 16, 16, 32, 1, 1); }
-            if (chains) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 4, 16, 32, 2, 1); }
+            if (chains) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, PRNN_CHAIN_LB, 16, PRNN_CHAIN_REGW, 2, 1); }
             PRNN_BWD(CTCASR_CELL_LSTM, 64, 2, 8, 16, 32, 1, 1);
         }
         if (mt == 1) { PRNN_BWD(CTCASR_CELL_LSTM, 64, 1, 32, 8, 0, 1, 1); }

@@ -56,10 +56,10 @@ def test_gradients_through_the_persistent_recurrence(chunks):
     recurrence is cut into launches and the weight gradients are accumulated range by range on
     the side stream.  Same bars as the small cases."""
     model = _check_logits_loss_and_gradients('ds2_lstm_2conv', bwd_chunks=chunks, hidden=1024,
-                                             frames=95, batch=2)
+                                             frames=71, batch=2)
     from ctc_asr_amd import hip
-    assert hip.rnn_persistent_supported('lstm', 48, 2, 1024)
-    hip.rnn_poll_error('lstm', model._acts['rnn_ws'], 48, 2, 1024)
+    assert hip.rnn_persistent_supported('lstm', 36, 2, 1024)
+    hip.rnn_poll_error('lstm', model._acts['rnn_ws'], 36, 2, 1024)
 
 
 @pytest.mark.parametrize('case,hidden,batch', [('ds2_gru', 1024, 2), ('ds2_gru', 2048, 3),
@@ -71,8 +71,10 @@ def test_gradients_through_the_other_persistent_kernels(case, hidden, batch):
     and a batch of 19 rows (two 16-row tiles with their own barriers)."""
     from ctc_asr_amd import hip
     cell = 'gru' if 'gru' in case else 'lstm'
-    assert hip.rnn_persistent_supported(cell, 40, batch, hidden)
-    model = _check_logits_loss_and_gradients(case, hidden=hidden, frames=79, batch=batch)
+    # (the fp64 CPU oracle dominates the run time: fewer frames for the H = 2048 models)
+    frames = 39 if hidden == 2048 else 63
+    assert hip.rnn_persistent_supported(cell, (frames + 1) // 2, batch, hidden)
+    model = _check_logits_loss_and_gradients(case, hidden=hidden, frames=frames, batch=batch)
     model.check_rnn_error()
 
 

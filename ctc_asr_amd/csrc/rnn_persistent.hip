@@ -834,7 +834,15 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                                        (size_t)(ok[mt] ? row : 0) * 4) * sizeof(float));
             }
             // chunk i of this wave = gate i / CPG, 16-float unit chunk i % CPG; loads of batch
-            // nb+1 are in flight while batch nb feeds the MFMAs
+            // nb+1 are in flight while batch nb feeds the MFMAs.
+            // (Every variant delivers the A operand at ~50 GB/s per CU - 256 KB in 5.2 us at
+            // B = 16, 512 KB in 11.3 at B = 32 - whatever the batch size.  Two probes of why, both
+            // negative: the register-resident kernels in four unrolled variants that start the
+            // walk over the block a quarter apart, selected per workgroup so that the workgroups
+            // of one XCD do not ask for the same lines at the same time: 7.2 -> 7.7 / 11.4 ->
+            // 12.7 us per step - walking in step is what makes the XCD's L2 merge the misses;
+            // and an L2 warm-up right after the barrier, every workgroup of an XCD touching its
+            // own eighth of the block, one line per thread: 7.2 -> 7.6 / 11.3 -> 11.8.)
             float4 a[2][MT][LA];
             auto issue = [&](int nb, float4 (&dst)[MT][LA]) {
 #pragma unroll

@@ -270,6 +270,7 @@ def measure(name, args, rank, local_rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    issued = time.perf_counter() - t0      # host side done enqueuing (it runs ahead of the GPU)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -375,6 +376,8 @@ def measure(name, args, rank, local_rank, world):
             'frac_of_fp32_mfma_peak': round(value * flops_per_audio_s / 1e12 /
                                             (FP32_MFMA_PEAK_TFLOPS * world), 4),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
+            # time the host needed to enqueue a step; close to ms_per_step = launch-bound
+            'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),
             'roofline': roofline,
         }
         if world > 1:

@@ -267,10 +267,13 @@ def measure(name, args, rank, local_rank, world):
     hip.set_option('rnn_kernel_events', 1)      # event pairs right around the persistent kernels
     hip.rnn_kernel_events()
     trainer.reducer.launched = 0
+    trainer.host_wait_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    issued = time.perf_counter() - t0      # host side done enqueuing (it runs ahead of the GPU)
+    # host side done enqueuing; minus the time it spent waiting for the GPU to come within
+    # Trainer.max_steps_ahead steps = what the host needs to enqueue the steps
+    issued = time.perf_counter() - t0 - trainer.host_wait_s
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -378,6 +381,7 @@ def measure(name, args, rank, local_rank, world):
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),
+            'hbm_reserved_gb': round(torch.cuda.max_memory_reserved(device) / 2.0 ** 30, 2),
             'roofline': roofline,
         }
         if world > 1:

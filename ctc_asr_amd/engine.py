@@ -8,7 +8,9 @@ with RCCL all-reduce over xGMI — per layer slice of the flat gradient arena, l
 as the backward pass has finished that layer so the collective overlaps the rest of backward.
 """
 
+import collections
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -128,12 +130,25 @@ class Trainer:
                                        hold_until='rnn0')
         if world_size > 1:   # identical replicas: rank 0's initial parameters win
             dist.broadcast(self.model.arena.param, src=0)
+        # The host enqueues a step several times faster than the GPU runs it.  Left alone it
+        # runs ahead without bound: every step's activations (5 GB at C3) are then allocated
+        # anew - blocks freed by the host are still in use by steps the GPU has not reached -
+        # until the allocator hits the end of HBM and synchronises.  `max_steps_ahead` bounds
+        # the lead: step N is not enqueued before step N - max_steps_ahead has finished.
+        self.max_steps_ahead = 2
+        self._step_done = collections.deque()
+        self.host_wait_s = 0.0          # time spent waiting there (bench.py reports the rest)
 
     def train_step(self, features, feature_len, labels, check=True):
         """forward + CTC + backward (+ all-reduce) + Adam on this rank's shard of the global
         batch; returns the local mean loss (device scalar).  The global loss is the mean over
         ranks of the local means (equal shard sizes), so gradients are summed and scaled by
         1 / world_size inside the Adam kernel."""
+        if len(self._step_done) >= self.max_steps_ahead:
+            t0 = time.perf_counter()
+            while len(self._step_done) >= self.max_steps_ahead:
+                self._step_done.popleft().synchronize()
+            self.host_wait_s += time.perf_counter() - t0
         loss = self.model.forward_backward(features, feature_len, labels,
                                            reduce_hook=self.reducer, check=check)
         if check:
@@ -144,6 +159,9 @@ class Trainer:
         self.reducer.finish()
         self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
                                    grad_scale=1.0 / self.world)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.model.device))
+        self._step_done.append(done)
         return loss
 
     def global_mean(self, value):

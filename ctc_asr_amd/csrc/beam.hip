@@ -4,12 +4,11 @@
 // One workgroup per utterance; the beam (<= 1024 leaves) lives in LDS.  Per frame:
 //   1. all threads: normalise the frame, copy new -> old, update every leaf from its own and its
 //      parent's old probabilities (TensorFlow's first loop is embarrassingly parallel);
-//   2. all threads: two bitonic sorts - the leaves by OLD total (descending: TensorFlow's branch
-//      order) and by NEW total (ascending: a sorted array is a valid min-heap);
+//   2. all threads: a bitonic sort of the leaves by OLD total (descending: TensorFlow's branch
+//      order);
 //   3. wave 0: TensorFlow's second loop, literally - branches in order, children in symbol order,
-//      a bounded min-heap whose bottom is replaced when a child beats it.  The 28 child values of
-//      a branch are computed by 28 lanes at once and only children that beat the bottom take the
-//      serial heap path, so a branch without insertions costs a few dozen cycles.
+//      a bounded set of the W best leaves whose bottom is replaced when a child beats it
+//      (`beam_expand`: the set's keys live in registers, the bottom is a wave-wide minimum).
 // The serial part is kept because TensorFlow's result is order dependent in one corner: a leaf
 // that is pushed out of the heap and then re-proposed (and rejected) by its still-active parent
 // before its own turn has its old probabilities wiped and does not expand in this frame.  That
@@ -38,10 +37,10 @@ __device__ __forceinline__ unsigned order_key(float v) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ int gload(const int *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void gstore(int *p, int v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 struct BeamLds {
@@ -54,7 +53,7 @@ struct BeamLds {
     int bidx[BEAM_SLOTS], evict_time[BEAM_SLOTS];
     // per beam position
     int heap[BEAM_MAX_WIDTH], branches[BEAM_MAX_WIDTH];
-    unsigned long long sort_a[BEAM_MAX_WIDTH], sort_b[BEAM_MAX_WIDTH];
+    unsigned long long sort_a[BEAM_MAX_WIDTH];
     int freelist[BEAM_SLOTS];
     float x[BEAM_MAX_CLASSES];
     int misc[8];   // 0 nheap, 1 node count, 2 nfree
@@ -64,6 +63,26 @@ struct BeamLds {
 __device__ __forceinline__ bool worse(const BeamLds &L, int a, int b) {
     if (L.n_total[a] != L.n_total[b]) return L.n_total[a] < L.n_total[b];
     return L.node[a] > L.node[b];
+}
+
+// heap-order key of a slot: ascending = worse first (lower total; equal totals: the younger node)
+__device__ __forceinline__ unsigned long long heap_key(float total, int node, int slot) {
+    const unsigned nd = min((unsigned)node, 0x1fffffu);
+    return ((unsigned long long)order_key(total) << 32) | ((0x1fffffu - nd) << 11) | (unsigned)slot;
+}
+__device__ __forceinline__ float key_total(unsigned long long key) {
+    const unsigned k = (unsigned)(key >> 32);
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+        const unsigned lo = __shfl_xor((unsigned)v, off, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
 }
 
 // ascending bitonic sort of n 64-bit keys (n padded to pow2 with ~0ull), all threads
@@ -81,6 +100,136 @@ __device__ void bitonic_sort(unsigned long long *keys, int n_pow2, int tid) {
             __syncthreads();
         }
     }
+}
+
+// TensorFlow's second loop for one frame, run by ONE wave: branches in order, children in symbol
+// order, a bounded set of the W best leaves whose worst member is replaced when a child beats it.
+// TensorFlow keeps that set in a min-heap; only its bottom is ever looked at, so here the set is
+// unordered - position p = k * 64 + lane of L.heap[] belongs to `lane`, which keeps the member's
+// heap key in register k - and the bottom is a wave-wide minimum of the keys, recomputed after
+// every insertion (a serial sift through LDS cost ~1 us per insertion, this ~0.2).  The 28 child
+// values of a branch are computed by 28 lanes at once, their tree nodes are looked up with one
+// coalesced load, and only children that beat the bottom take the insertion path.
+template <int PER>
+__device__ void beam_expand(BeamLds &L, int lane, int W, int C, int blank, int nslots, int nheap0,
+                            int *pool_parent, int *pool_label, int *pool_children,
+                            int nodes_per_utt) {
+    int nheap = nheap0, nfree = 0, nodes = L.misc[1];
+    for (int base = 0; base < nslots; base += 64) {      // free slots, ordered
+        const bool is_free = base + lane < nslots && !L.alive[base + lane];
+        const unsigned long long m = __ballot(is_free);
+        if (is_free)
+            L.freelist[nfree + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
+        nfree += __popcll(m);
+    }
+    unsigned long long hk[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int pos = k * 64 + lane;
+        hk[k] = ~0ull;
+        if (pos < nheap) {
+            const int s = L.heap[pos];
+            hk[k] = heap_key(L.n_total[s], L.node[s], s);
+        }
+    }
+    auto bottom = [&]() {
+        unsigned long long m = hk[0];
+#pragma unroll
+        for (int k = 1; k < PER; ++k) m = hk[k] < m ? hk[k] : m;
+        return wave_min_u64(m);
+    };
+    unsigned long long bkey = bottom();      // the worst leaf of the beam (valid when nheap > 0)
+    float btot = key_total(bkey);
+
+    for (int j = 0; j < nheap0; ++j) {
+        const int s = L.branches[j];
+        const float ot = L.o_total[s];
+        // branches come in descending old total and the bottom only rises: once a branch cannot
+        // beat the bottom of a full beam, no later one can
+        if (nheap == W && !(ot > btot)) break;
+        if (!L.alive[s]) {
+            // pushed out earlier in this frame: wiped if its parent re-proposed it since
+            const int ps = L.pslot[s];
+            if (ps >= 0 && L.expanded[ps] && L.evict_time[s] < L.bidx[ps] * 64 + L.label[s])
+                continue;
+        }
+        if (!(ot > -INFINITY)) continue;
+        if (lane == 0) L.expanded[s] = 1;
+        const int slabel = L.label[s];
+        const unsigned long long active = L.kids_in_beam[s];
+        float v = -INFINITY;
+        if (lane < C && lane != blank && !((active >> lane) & 1ull))
+            v = L.x[lane] + (lane == slabel ? L.o_blank[s] : ot);
+        // children that could enter right now; the bottom only rises while we insert
+        unsigned long long cand = __ballot(v > -INFINITY && (nheap < W || v > btot));
+        if (!cand) continue;
+        const int pnode = L.node[s];
+        int kidv = -1;                       // tree nodes of the children, where they exist
+        if (lane < C) kidv = gload(&pool_children[(size_t)pnode * C + lane]);
+        while (cand) {
+            const int c = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const float vc = __shfl(v, c, 64);
+            if (!(nheap < W || vc > btot)) continue;
+            if (nodes + 1 >= nodes_per_utt) {     // tree pool exhausted
+                if (lane == 0) L.misc[3] = 1;
+                cand = 0ull;
+                continue;
+            }
+            const bool full = nheap == W;
+            if (full) {
+                // the bottom leaves the beam (before a slot is taken: a transient child hands
+                // its slot straight back)
+                const int ev = (int)(bkey & 0x7ffu);
+                const bool recycle = !L.was_alive[ev];
+                if (lane == 0) {
+                    L.alive[ev] = 0;
+                    L.evict_time[ev] = j * 64 + c;
+                    const int eps = L.pslot[ev];
+                    if (eps >= 0) L.kids_in_beam[eps] &= ~(1ull << L.label[ev]);
+                    if (recycle) L.freelist[nfree] = ev;
+                }
+                if (recycle) ++nfree;
+            }
+            // node of child (s, c): reuse or create
+            int kid = __shfl(kidv, c, 64);
+            if (kid < 0) {
+                kid = nodes++;
+                if (lane == 0) {
+                    gstore(&pool_children[(size_t)pnode * C + c], kid);
+                    gstore(&pool_parent[kid], pnode);
+                    gstore(&pool_label[kid], c);
+                }
+                if (lane < C) gstore(&pool_children[(size_t)kid * C + lane], -1);
+            }
+            const int ns = L.freelist[--nfree];      // (LDS runs a wave's accesses in order)
+            if (lane == 0) {
+                L.node[ns] = kid; L.label[ns] = c; L.parent[ns] = pnode; L.pslot[ns] = s;
+                L.n_total[ns] = vc; L.n_label[ns] = vc; L.n_blank[ns] = -INFINITY;
+                L.alive[ns] = 1; L.was_alive[ns] = 0; L.expanded[ns] = 0;
+                L.kids_in_beam[ns] = 0ull;
+                L.kids_in_beam[s] |= 1ull << c;
+            }
+            const unsigned long long nk = heap_key(vc, kid, ns);
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k)
+                    if (hk[k] == bkey) { hk[k] = nk; L.heap[k * 64 + lane] = ns; }
+            } else {
+                if (lane == (nheap & 63)) {
+#pragma unroll
+                    for (int k = 0; k < PER; ++k)
+                        if (k == (nheap >> 6)) hk[k] = nk;
+                    L.heap[nheap] = ns;
+                }
+                ++nheap;
+            }
+            bkey = bottom();
+            btot = key_total(bkey);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) { L.misc[0] = nheap; L.misc[1] = nodes; }
 }
 
 __global__ void __launch_bounds__(BEAM_THREADS)
@@ -156,7 +305,7 @@ beam_decode_kernel(const float *__restrict__ logits, const int *__restrict__ seq
             L.n_total[s] = lse2f(nb, nl);
         }
         __syncthreads();
-        // ---- 2. branch order (old total desc, older node first) and heap (new total asc) --------
+        // ---- 2. branch order (old total desc, older node first) -------------------------------
         int n_pow2 = 1;
         while (n_pow2 < nheap0) n_pow2 <<= 1;
         for (int i = tid; i < n_pow2; i += BEAM_THREADS) {
@@ -166,128 +315,31 @@ beam_decode_kernel(const float *__restrict__ logits, const int *__restrict__ seq
                 // descending old total == ascending ~key; ties: older (smaller id) node first
                 L.sort_a[i] = ((unsigned long long)(~order_key(L.o_total[s])) << 32) |
                               (nd << 11) | (unsigned)s;
-                // ascending new total; ties: the worse (younger = larger id) first
-                L.sort_b[i] = ((unsigned long long)order_key(L.n_total[s]) << 32) |
-                              ((0x1fffffu - nd) << 11) | (unsigned)s;
             } else {
                 L.sort_a[i] = ~0ull;
-                L.sort_b[i] = ~0ull;
             }
         }
         __syncthreads();
         bitonic_sort(L.sort_a, n_pow2, tid);
-        bitonic_sort(L.sort_b, n_pow2, tid);
         for (int i = tid; i < nheap0; i += BEAM_THREADS) {
             const int sa = (int)(L.sort_a[i] & 0x7ffu);
             L.branches[i] = sa;
             L.bidx[sa] = i;
-            L.heap[i] = (int)(L.sort_b[i] & 0x7ffu);
         }
         __syncthreads();
 
         // ---- 3. TensorFlow's second loop, serial over branches, on wave 0 ------------------------
         if (tid < 64) {
-            int nheap = nheap0, nfree = 0, nodes = L.misc[1];
-            for (int base = 0; base < nslots; base += 64) {      // free slots, ordered
-                const bool is_free = base + lane < nslots && !L.alive[base + lane];
-                const unsigned long long m = __ballot(is_free);
-                if (is_free)
-                    L.freelist[nfree + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
-                nfree += __popcll(m);
-            }
-            for (int j = 0; j < nheap0; ++j) {
-                const int s = L.branches[j];
-                const float ot = L.o_total[s];
-                // branches come in descending old total and the heap bottom only rises: once a
-                // branch cannot beat the bottom of a full heap, no later one can
-                if (nheap == W && !(ot > L.n_total[L.heap[0]])) break;
-                if (!L.alive[s]) {
-                    // pushed out earlier in this frame: wiped if its parent re-proposed it since
-                    const int ps = L.pslot[s];
-                    if (ps >= 0 && L.expanded[ps] &&
-                        L.evict_time[s] < L.bidx[ps] * 64 + L.label[s])
-                        continue;
-                }
-                if (!(ot > -INFINITY)) continue;
-                if (!(nheap < W || ot > L.n_total[L.heap[0]])) continue;
-                if (lane == 0) L.expanded[s] = 1;
-                const int slabel = L.label[s];
-                const unsigned long long active = L.kids_in_beam[s];
-                float v = -INFINITY;
-                if (lane < C && lane != blank && !((active >> lane) & 1ull))
-                    v = L.x[lane] + (lane == slabel ? L.o_blank[s] : ot);
-                // children that could enter right now; the bottom only rises while we insert
-                unsigned long long cand =
-                    __ballot(v > -INFINITY && (nheap < W || v > L.n_total[L.heap[0]]));
-                while (cand) {
-                    const int c = __ffsll((long long)cand) - 1;
-                    cand &= cand - 1;
-                    const float vc = __shfl(v, c, 64);
-                    if (!(nheap < W || vc > L.n_total[L.heap[0]])) continue;
-                    if (nodes + 1 >= nodes_per_utt) {     // tree pool exhausted
-                        if (lane == 0) L.misc[3] = 1;
-                        cand = 0ull;
-                        continue;
-                    }
-                    if (lane == 0) {
-                        const bool full = nheap == W;
-                        if (full) {
-                            // the bottom leaves the beam (before a slot is taken: a transient
-                            // child hands its slot straight back)
-                            const int ev = L.heap[0];
-                            L.alive[ev] = 0;
-                            L.evict_time[ev] = j * 64 + c;
-                            const int eps = L.pslot[ev];
-                            if (eps >= 0) L.kids_in_beam[eps] &= ~(1ull << L.label[ev]);
-                            if (!L.was_alive[ev]) L.freelist[nfree++] = ev;
-                        }
-                        // node of child (s, c): reuse or create
-                        const int pnode = L.node[s];
-                        int kid = gload(&pool_children[(size_t)pnode * C + c]);
-                        if (kid < 0) {
-                            kid = nodes++;
-                            gstore(&pool_children[(size_t)pnode * C + c], kid);
-                            gstore(&pool_parent[kid], pnode);
-                            gstore(&pool_label[kid], c);
-                            for (int cc = 0; cc < C; ++cc)
-                                gstore(&pool_children[(size_t)kid * C + cc], -1);
-                        }
-                        const int ns = L.freelist[--nfree];
-                        L.node[ns] = kid; L.label[ns] = c; L.parent[ns] = pnode; L.pslot[ns] = s;
-                        L.n_total[ns] = vc; L.n_label[ns] = vc; L.n_blank[ns] = -INFINITY;
-                        L.alive[ns] = 1; L.was_alive[ns] = 0; L.expanded[ns] = 0;
-                        L.kids_in_beam[ns] = 0ull;
-                        L.kids_in_beam[s] |= 1ull << c;
-                        int pos;
-                        if (full) {
-                            L.heap[0] = ns;
-                            pos = 0;
-                            for (;;) {      // sift down
-                                int l = 2 * pos + 1, r = l + 1, m = pos;
-                                if (l < nheap && worse(L, L.heap[l], L.heap[m])) m = l;
-                                if (r < nheap && worse(L, L.heap[r], L.heap[m])) m = r;
-                                if (m == pos) break;
-                                const int tmp = L.heap[pos]; L.heap[pos] = L.heap[m];
-                                L.heap[m] = tmp; pos = m;
-                            }
-                        } else {
-                            pos = nheap;
-                            L.heap[pos] = ns;
-                            while (pos > 0) {   // sift up
-                                const int p = (pos - 1) / 2;
-                                if (!worse(L, L.heap[pos], L.heap[p])) break;
-                                const int tmp = L.heap[pos]; L.heap[pos] = L.heap[p];
-                                L.heap[p] = tmp; pos = p;
-                            }
-                        }
-                    }
-                    if (nheap < W) ++nheap;
-                    nfree = __shfl(nfree, 0, 64);
-                    nodes = __shfl(nodes, 0, 64);
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            if (lane == 0) { L.misc[0] = nheap; L.misc[1] = nodes; }
+            const int per = (W + 63) / 64;
+            if (per <= 1)
+                beam_expand<1>(L, lane, W, C, blank, nslots, nheap0, pool_parent, pool_label,
+                               pool_children, nodes_per_utt);
+            else if (per <= 4)
+                beam_expand<4>(L, lane, W, C, blank, nslots, nheap0, pool_parent, pool_label,
+                               pool_children, nodes_per_utt);
+            else
+                beam_expand<16>(L, lane, W, C, blank, nslots, nheap0, pool_parent, pool_label,
+                                pool_children, nodes_per_utt);
         }
         __syncthreads();
         // ---- beam slots of the tree nodes for the next frame -----------------------------------

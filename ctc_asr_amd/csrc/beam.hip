@@ -74,6 +74,21 @@ __device__ __forceinline__ float key_total(unsigned long long key) {
     const unsigned k = (unsigned)(key >> 32);
     return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
+// wave-wide minimum of a u32 by DPP: four shifts within the rows of 16 lanes, then the row
+// broadcasts (lane 63 ends up with the minimum of all 64 lanes); a few VALU instructions instead
+// of six LDS-crossbar shuffles
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define BEAM_DPP_MIN(ctrl, row_mask)                                                          \
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, row_mask, 0xf, false))
+    BEAM_DPP_MIN(0x111, 0xf);    // row_shr:1
+    BEAM_DPP_MIN(0x112, 0xf);    // row_shr:2
+    BEAM_DPP_MIN(0x114, 0xf);    // row_shr:4
+    BEAM_DPP_MIN(0x118, 0xf);    // row_shr:8   -> lane 15 of every row holds the row's minimum
+    BEAM_DPP_MIN(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+    BEAM_DPP_MIN(0x143, 0xc);    // row_bcast:31 into rows 2 and 3
+#undef BEAM_DPP_MIN
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -106,10 +121,14 @@ __device__ void bitonic_sort(unsigned long long *keys, int n_pow2, int tid) {
 // order, a bounded set of the W best leaves whose worst member is replaced when a child beats it.
 // TensorFlow keeps that set in a min-heap; only its bottom is ever looked at, so here the set is
 // unordered - position p = k * 64 + lane of L.heap[] belongs to `lane`, which keeps the member's
-// heap key in register k - and the bottom is a wave-wide minimum of the keys, recomputed after
-// every insertion (a serial sift through LDS cost ~1 us per insertion, this ~0.2).  The 28 child
-// values of a branch are computed by 28 lanes at once, their tree nodes are looked up with one
-// coalesced load, and only children that beat the bottom take the insertion path.
+// heap key and what an eviction needs to know about it (parent slot, label, "was in the beam
+// when the frame began") in registers k - and the bottom is a wave-wide minimum of the keys,
+// recomputed after every insertion.  One wave runs a long dependent instruction stream here, so
+// the insertion path avoids LDS round trips: values cross lanes with v_readlane (the lane index
+// is a ballot result), the read-modify-writes of the children masks are LDS atomics without
+// return, an evicted transient hands its slot straight to the child that pushed it out, the next
+// free slot and the next branch's children row (tree nodes, global memory) are fetched one
+// step ahead.  A serial sift through an LDS heap cost ~2 us per insertion; this ~0.4.
 template <int PER>
 __device__ void beam_expand(BeamLds &L, int lane, int W, int C, int blank, int nslots, int nheap0,
                             int *pool_parent, int *pool_label, int *pool_children,
@@ -123,27 +142,52 @@ __device__ void beam_expand(BeamLds &L, int lane, int W, int C, int blank, int n
         nfree += __popcll(m);
     }
     unsigned long long hk[PER];
+    unsigned hm[PER];        // parent slot (0xfff: none) | label << 12 | was_alive << 18
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int pos = k * 64 + lane;
         hk[k] = ~0ull;
+        hm[k] = 0;
         if (pos < nheap) {
             const int s = L.heap[pos];
             hk[k] = heap_key(L.n_total[s], L.node[s], s);
+            hm[k] = ((unsigned)L.pslot[s] & 0xfffu) | (((unsigned)L.label[s] & 0x3fu) << 12) |
+                    ((unsigned)(L.was_alive[s] != 0) << 18);
         }
     }
-    auto bottom = [&]() {
+    // the worst leaf of the beam: key, owning lane (valid when nheap > 0)
+    unsigned long long bkey = ~0ull;
+    int owner = 0;
+    auto find_bottom = [&]() {
         unsigned long long m = hk[0];
 #pragma unroll
         for (int k = 1; k < PER; ++k) m = hk[k] < m ? hk[k] : m;
-        return wave_min_u64(m);
+        // the total's 32 bits decide almost always; exact ties go the long way
+        const unsigned hi = (unsigned)(m >> 32), best = wave_min_u32(hi);
+        unsigned long long tied = __ballot(hi == best);
+        if (tied & (tied - 1)) {
+            bkey = wave_min_u64(m);
+            tied = __ballot(m == bkey);
+        }
+        owner = __ffsll((long long)tied) - 1;
+        bkey = ((unsigned long long)best << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)m, owner);
     };
-    unsigned long long bkey = bottom();      // the worst leaf of the beam (valid when nheap > 0)
+    find_bottom();
     float btot = key_total(bkey);
+    int free_top = nfree > 0 ? L.freelist[nfree - 1] : -1;      // next free slot, read ahead
 
+    // the children rows (tree nodes of a branch's children) are read one branch ahead: the
+    // global-memory round trip would otherwise sit in front of every branch's first insertion
+    int kid_next = -1;
+    if (nheap0 > 0 && lane < C)
+        kid_next = gload(&pool_children[(size_t)L.node[L.branches[0]] * C + lane]);
     for (int j = 0; j < nheap0; ++j) {
         const int s = L.branches[j];
         const float ot = L.o_total[s];
+        const int kidv = kid_next;           // tree nodes of this branch's children (-1: none yet)
+        if (j + 1 < nheap0 && lane < C)
+            kid_next = gload(&pool_children[(size_t)L.node[L.branches[j + 1]] * C + lane]);
         // branches come in descending old total and the bottom only rises: once a branch cannot
         // beat the bottom of a full beam, no later one can
         if (nheap == W && !(ot > btot)) break;
@@ -164,12 +208,10 @@ __device__ void beam_expand(BeamLds &L, int lane, int W, int C, int blank, int n
         unsigned long long cand = __ballot(v > -INFINITY && (nheap < W || v > btot));
         if (!cand) continue;
         const int pnode = L.node[s];
-        int kidv = -1;                       // tree nodes of the children, where they exist
-        if (lane < C) kidv = gload(&pool_children[(size_t)pnode * C + lane]);
         while (cand) {
             const int c = __ffsll((long long)cand) - 1;
             cand &= cand - 1;
-            const float vc = __shfl(v, c, 64);
+            const float vc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
             if (!(nheap < W || vc > btot)) continue;
             if (nodes + 1 >= nodes_per_utt) {     // tree pool exhausted
                 if (lane == 0) L.misc[3] = 1;
@@ -177,22 +219,30 @@ __device__ void beam_expand(BeamLds &L, int lane, int W, int C, int blank, int n
                 continue;
             }
             const bool full = nheap == W;
+            int ns = -1;
             if (full) {
-                // the bottom leaves the beam (before a slot is taken: a transient child hands
-                // its slot straight back)
+                // the bottom leaves the beam; a transient (a child that entered in this frame)
+                // hands its slot straight to the child that pushes it out
+                unsigned meta = 0;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) meta = hk[k] == bkey ? hm[k] : meta;
+                meta = (unsigned)__builtin_amdgcn_readlane((int)meta, owner);
                 const int ev = (int)(bkey & 0x7ffu);
-                const bool recycle = !L.was_alive[ev];
                 if (lane == 0) {
                     L.alive[ev] = 0;
                     L.evict_time[ev] = j * 64 + c;
-                    const int eps = L.pslot[ev];
-                    if (eps >= 0) L.kids_in_beam[eps] &= ~(1ull << L.label[ev]);
-                    if (recycle) L.freelist[nfree] = ev;
+                    if ((meta & 0xfffu) != 0xfffu)
+                        atomicAnd(&L.kids_in_beam[meta & 0xfffu], ~(1ull << ((meta >> 12) & 0x3fu)));
                 }
-                if (recycle) ++nfree;
+                if (!((meta >> 18) & 1u)) ns = ev;
+            }
+            if (ns < 0) {
+                ns = free_top;
+                --nfree;
+                free_top = nfree > 0 ? L.freelist[nfree - 1] : -1;
             }
             // node of child (s, c): reuse or create
-            int kid = __shfl(kidv, c, 64);
+            int kid = __builtin_amdgcn_readlane(kidv, c);
             if (kid < 0) {
                 kid = nodes++;
                 if (lane == 0) {
@@ -202,31 +252,30 @@ __device__ void beam_expand(BeamLds &L, int lane, int W, int C, int blank, int n
                 }
                 if (lane < C) gstore(&pool_children[(size_t)kid * C + lane], -1);
             }
-            const int ns = L.freelist[--nfree];      // (LDS runs a wave's accesses in order)
             if (lane == 0) {
                 L.node[ns] = kid; L.label[ns] = c; L.parent[ns] = pnode; L.pslot[ns] = s;
                 L.n_total[ns] = vc; L.n_label[ns] = vc; L.n_blank[ns] = -INFINITY;
                 L.alive[ns] = 1; L.was_alive[ns] = 0; L.expanded[ns] = 0;
                 L.kids_in_beam[ns] = 0ull;
-                L.kids_in_beam[s] |= 1ull << c;
+                atomicOr(&L.kids_in_beam[s], 1ull << c);
             }
             const unsigned long long nk = heap_key(vc, kid, ns);
+            const unsigned nm = ((unsigned)s & 0xfffu) | ((unsigned)c << 12);
             if (full) {
 #pragma unroll
                 for (int k = 0; k < PER; ++k)
-                    if (hk[k] == bkey) { hk[k] = nk; L.heap[k * 64 + lane] = ns; }
+                    if (hk[k] == bkey) { hk[k] = nk; hm[k] = nm; L.heap[k * 64 + lane] = ns; }
             } else {
                 if (lane == (nheap & 63)) {
 #pragma unroll
                     for (int k = 0; k < PER; ++k)
-                        if (k == (nheap >> 6)) hk[k] = nk;
+                        if (k == (nheap >> 6)) { hk[k] = nk; hm[k] = nm; }
                     L.heap[nheap] = ns;
                 }
                 ++nheap;
             }
-            bkey = bottom();
+            find_bottom();
             btot = key_total(bkey);
-            __builtin_amdgcn_wave_barrier();
         }
     }
     if (lane == 0) { L.misc[0] = nheap; L.misc[1] = nodes; }

@@ -416,9 +416,17 @@ beam_decode_kernel(const float *__restrict__ logits, const int *__restrict__ seq
     }
 }
 
-// tree nodes per utterance: one per successful heap insertion (<= 2^21, the sort key's id field)
-size_t nodes_per_utt(int T, int W) {
-    const size_t n = (size_t)2 * W * T + 1;
+// Tree nodes per utterance.  Every insertion of a child that has no node yet creates one, and
+// a frame can insert up to W * (C - 1) children (each branch proposes all its symbols, each
+// pushing the previous bottom out): T * W * (C - 1) + 1 is the true bound - 14 M nodes of 128 B
+// at width 1024, T' = 500.  Measured on noise logits, the worst case for churn, a frame inserts
+// 0.8-1.5 W children; the pool holds 4 W per frame plus 64 K (never more than the true bound, so
+// small searches cannot exhaust it, and at most 2^21, the id field of the sort key).  Running
+// out is reported (out_len = -1 -> CtcAsrError), never silent.
+size_t nodes_per_utt(int T, int W, int C) {
+    size_t n = (size_t)4 * W * T + 65536;
+    const size_t bound = (size_t)T * W * (C > 1 ? C - 1 : 1) + 2;
+    n = n < bound ? n : bound;
     return n < (1u << 21) ? n : (1u << 21);
 }
 
@@ -426,7 +434,7 @@ size_t nodes_per_utt(int T, int W) {
 
 extern "C" size_t ctcasr_ctc_beam_workspace_bytes(int T, int B, int C, int beam_width) {
     if (T <= 0 || B <= 0 || C <= 0 || beam_width <= 0) return 0;
-    return (size_t)B * nodes_per_utt(T, beam_width) * (3 + (size_t)C) * sizeof(int) + 256;
+    return (size_t)B * nodes_per_utt(T, beam_width, C) * (3 + (size_t)C) * sizeof(int) + 256;
 }
 
 extern "C" int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, int B,
@@ -439,7 +447,7 @@ extern "C" int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_le
     if (beam_width > BEAM_MAX_WIDTH || C > BEAM_MAX_CLASSES) return CTCASR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ctcasr_ctc_beam_workspace_bytes(T, B, C, beam_width))
         return CTCASR_ERR_WORKSPACE;
-    const size_t n = nodes_per_utt(T, beam_width);
+    const size_t n = nodes_per_utt(T, beam_width, C);
     int *pool_parent = reinterpret_cast<int *>(workspace);
     int *pool_label = pool_parent + (size_t)B * n;
     int *pool_slot = pool_label + (size_t)B * n;

@@ -24,6 +24,23 @@ def evaluate_dataset(model, target, rank=0, world=1, max_batches=None, report_sa
     input_fn = input_fn_generator(target, device=model.device, rank=rank, world_size=world,
                                   seed=(FLAGS.random_seed or 1) if world > 1 else None)
     losses, meds, wers = [], [], []
+    # Decoding is deferred: the beam search runs one workgroup per utterance, so the logits of
+    # several batches are decoded in ONE launch (`CTCModel.decode_many`) - same results, and a
+    # group costs about what a single batch does.  The metrics stay per-batch means.
+    pending, group, samples = [], None, None
+
+    def score_pending():
+        nonlocal samples
+        results = model.decode_many([(logits, seq_len, originals)
+                                     for logits, seq_len, originals, _, _ in pending])
+        for (decoded, plaintext, summary), (_, _, _, labels, texts) in zip(results, pending):
+            _, mean_ed, _, wer = model.error_rates_fn(labels, texts, decoded, plaintext)
+            meds.append(float(mean_ed))
+            wers.append(float(wer))
+            if samples is None:
+                samples = summary
+        del pending[:]
+
     for index, batch in enumerate(input_fn()):
         if max_batches is not None and index >= max_batches:
             break
@@ -32,18 +49,20 @@ def evaluate_dataset(model, target, rank=0, world=1, max_batches=None, report_sa
                                              features['spectrogram_length'], training=False)
         loss = model.loss_fn(logits, seq_len, labels)
         model.check_rnn_error()       # a timed-out persistent recurrence would score garbage
-        decoded, plaintext, summary = model.decode_fn(logits, seq_len,
-                                                      np.array([t.encode('utf-8') for t in
-                                                                features['label_plaintext']],
-                                                               dtype=object))
-        _, mean_ed, _, wer = model.error_rates_fn(labels, features['label_plaintext'], decoded,
-                                                  plaintext)
         losses.append(float(loss))
-        meds.append(float(mean_ed))
-        wers.append(float(wer))
-        if report_samples and rank == 0 and index == 0:
-            for dec, orig in list(zip(summary[0], summary[1]))[:FLAGS.num_samples_to_report]:
-                print('  decoded: "{}"\n  original: "{}"'.format(dec, orig))
+        originals = np.array([t.encode('utf-8') for t in features['label_plaintext']],
+                             dtype=object)
+        pending.append((logits, seq_len, originals, labels, features['label_plaintext']))
+        # (the longest utterances bound the prefix-tree pool: size the group on them)
+        group = model.decode_group_size(max(int(item[0].shape[0]) for item in pending),
+                                        int(logits.shape[1]))
+        if len(pending) >= group:
+            score_pending()
+    if pending:
+        score_pending()
+    if report_samples and rank == 0 and samples is not None:
+        for dec, orig in list(zip(samples[0], samples[1]))[:FLAGS.num_samples_to_report]:
+            print('  decoded: "{}"\n  original: "{}"'.format(dec, orig))
     stats = torch.tensor([np.sum(losses), np.sum(meds), np.sum(wers), len(losses)],
                          dtype=torch.float64, device=model.device)
     if world > 1:

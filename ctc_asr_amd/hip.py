@@ -243,6 +243,10 @@ def ctc_greedy_decode(logits, seq_len, blank=None, out=None, out_len=None):
 
 
 @_on_tensor_device
+def ctc_beam_workspace_bytes(num_steps, batch, classes, beam_width):
+    return load().ctcasr_ctc_beam_workspace_bytes(num_steps, batch, classes, int(beam_width))
+
+
 def ctc_beam_decode(logits, seq_len, beam_width, blank=None, normalization='max'):
     num_steps, batch, classes = logits.shape
     blank = classes - 1 if blank is None else blank

@@ -944,7 +944,10 @@ class CTCModel:
             out, out_len = hip.ctc_greedy_decode(logits, seq_len)
         else:
             out, out_len, _ = hip.ctc_beam_decode(logits, seq_len, beam_width)
-        out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+        return self._decoded_to_text(out.cpu().numpy(), out_len.cpu().numpy(), originals)
+
+    @staticmethod
+    def _decoded_to_text(out, out_len, originals):
         decoded = [out[b, :out_len[b]].tolist() for b in range(out.shape[0])]
         width = max([len(d) for d in decoded] + [0])
         dense = np.zeros((len(decoded), width), dtype=np.int32)
@@ -953,6 +956,46 @@ class CTCModel:
         plaintext, summary = metrics.dense_to_text(dense, originals if originals is not None
                                                    else np.array([], dtype=np.int32))
         return decoded, plaintext, summary
+
+    def decode_group_size(self, num_steps, batch, beam_width=None, budget_bytes=48 << 30,
+                          max_utterances=256):
+        """How many batches of ``batch`` utterances `decode_many` should be given at once: the
+        beam search runs one workgroup per utterance, so a single batch occupies 16 or 32 of the
+        256 CUs and a group of batches decodes in about the time of one.  Bounded by the prefix
+        tree pool (256 MB per utterance at width 1024, T' = 500) and ``max_utterances``."""
+        beam_width = self.cfg.beam_width if beam_width is None else beam_width
+        per_utt = max(1, hip.ctc_beam_workspace_bytes(num_steps, 1, self.cfg.num_classes,
+                                                      beam_width))
+        utterances = max(batch, min(max_utterances, budget_bytes // per_utt))
+        return max(1, int(utterances // batch))
+
+    def decode_many(self, batches, beam_width=None):
+        """Beam-search decode of several batches in ONE launch.  ``batches`` is a list of
+        (logits [T'_i, B_i, C], seq_len [B_i], originals or None); returns one `decode_fn` result
+        per batch - identical to decoding the batches one by one (an utterance's search does not
+        depend on its neighbours; frames past its length are never read)."""
+        beam_width = self.cfg.beam_width if beam_width is None else beam_width
+        if not batches:
+            return []
+        steps = max(int(logits.shape[0]) for logits, _, _ in batches)
+        total = sum(int(logits.shape[1]) for logits, _, _ in batches)
+        classes = int(batches[0][0].shape[2])
+        joint = torch.zeros((steps, total, classes), dtype=torch.float32, device=self.device)
+        lengths = torch.empty(total, dtype=torch.int32, device=self.device)
+        start = 0
+        for logits, seq_len, _ in batches:
+            stop = start + int(logits.shape[1])
+            joint[:logits.shape[0], start:stop] = logits
+            lengths[start:stop] = seq_len
+            start = stop
+        out, out_len, _ = hip.ctc_beam_decode(joint, lengths, beam_width)
+        out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+        results, start = [], 0
+        for logits, _, originals in batches:
+            stop = start + int(logits.shape[1])
+            results.append(self._decoded_to_text(out[start:stop], out_len[start:stop], originals))
+            start = stop
+        return results
 
     @staticmethod
     def error_rates_fn(labels, originals, decoded, decoded_texts):

@@ -339,3 +339,32 @@ def test_assembled_reference_default_model():
     _assembled_against_torch_ref(
         cfg, batch=16, frames=79, label_len=12, seed=22,
         grad_names=('conv2/kernel', 'rnn0/w_ih', 'rnn1/w_hh', 'rnn3/w_hh', 'dense4/kernel'))
+
+
+def test_decode_many_equals_batch_by_batch_decoding():
+    """`CTCModel.decode_many` (several batches in one beam-search launch, what
+    `evaluate_dataset` uses) returns exactly what `decode_fn` returns batch by batch: different
+    T', ragged lengths, a final smaller batch."""
+    cfg, flat, _, _, _ = _setup('ds2_lstm_2conv')
+    model = CTCModel(cfg, 'cuda', params=flat)
+    rng = np.random.default_rng(77)
+    batches = []
+    for steps, batch in ((37, 4), (52, 4), (21, 3)):
+        logits = (rng.normal(size=(steps, batch, cfg.num_classes)) * 2).astype(np.float32)
+        logits[:, :, -1] += 1.5
+        seq_len = rng.integers(1, steps + 1, size=batch).astype(np.int32)
+        seq_len[0] = steps
+        originals = np.array(['utt {}'.format(i).encode('utf-8') for i in range(batch)],
+                             dtype=object)
+        batches.append((torch.tensor(logits, device='cuda'),
+                        torch.tensor(seq_len, device='cuda'), originals))
+    for width in (8, 64):
+        joint = model.decode_many(batches, beam_width=width)
+        for (logits, seq_len, originals), got in zip(batches, joint):
+            ref = model.decode_fn(logits, seq_len, originals, beam_width=width)
+            assert got[0] == ref[0]
+            assert list(got[1]) == list(ref[1])
+            assert np.array_equal(got[2], ref[2])
+    assert model.decode_group_size(500, 16, beam_width=1024) == 11
+    assert model.decode_group_size(500, 16, beam_width=64) == 16
+    assert model.decode_group_size(850, 32, beam_width=1024, budget_bytes=8 << 30) == 1

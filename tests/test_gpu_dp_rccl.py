@@ -5,6 +5,7 @@ least two GPUs (the 1-GPU boxes of the build round do not)."""
 
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -72,10 +73,17 @@ def test_two_rccl_ranks_equal_one_rank_full_batch():
     procs = [ctx.Process(target=_worker, args=(rank, 2, port, out)) for rank in range(2)]
     for proc in procs:
         proc.start()
-    for proc in procs:
-        proc.join(300)
-        assert proc.exitcode == 0
+    # read the result BEFORE joining: rank 0 blocks in put() until the pipe is drained (the
+    # parameters are larger than the pipe buffer), and rank 1 waits for it at the barrier
+    deadline = time.time() + 600
+    while out.empty():
+        assert time.time() < deadline and all(p.exitcode in (None, 0) for p in procs), \
+            [p.exitcode for p in procs]
+        time.sleep(0.2)
     mean_loss, gathered, launched, backend = out.get()
+    for proc in procs:
+        proc.join(120)
+        assert proc.exitcode == 0
     assert backend == 'nccl' and launched >= 2
     assert np.array_equal(gathered[0], gathered[1])         # replicas stay identical
     cfg, flat, feats, flen, labels = _setup()

@@ -35,19 +35,22 @@ def _setup(batch=4, frames=61, seed=5):
     return cfg, flat, feats, flen, labels
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend='nccl', share_gpu=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     from ctc_asr_amd.engine import Trainer, init_distributed
-    init_distributed('nccl')
-    torch.cuda.set_device(rank)
+    device = 0 if share_gpu else rank
+    if share_gpu:
+        os.environ['LOCAL_RANK'] = '0'
+    init_distributed(backend)
+    torch.cuda.set_device(device)
     cfg, flat, feats, flen, labels = _setup()
     half = len(labels) // world
     lo, hi = rank * half, (rank + 1) * half
     # tiny buckets: several all-reduces per step, launched from the backward hooks
-    trainer = Trainer(cfg, device='cuda:{}'.format(rank), params=flat, world_size=world,
+    trainer = Trainer(cfg, device='cuda:{}'.format(device), params=flat, world_size=world,
                       rank=rank, bucket_bytes=4096)
     trainer.lr = 1e-3
     loss = trainer.train_step(torch.tensor(feats[lo:hi]), torch.tensor(flen[lo:hi]),
@@ -63,14 +66,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL over xGMI)')
-def test_two_rccl_ranks_equal_one_rank_full_batch():
+def _two_ranks_against_one(backend, share_gpu):
     import torch.multiprocessing as mp
     from ctc_asr_amd.engine import Trainer
     ctx = mp.get_context('spawn')
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rank, 2, port, out)) for rank in range(2)]
+    procs = [ctx.Process(target=_worker, args=(rank, 2, port, out, backend, share_gpu))
+             for rank in range(2)]
     for proc in procs:
         proc.start()
     # read the result BEFORE joining: rank 0 blocks in put() until the pipe is drained (the
@@ -80,11 +83,11 @@ def test_two_rccl_ranks_equal_one_rank_full_batch():
         assert time.time() < deadline and all(p.exitcode in (None, 0) for p in procs), \
             [p.exitcode for p in procs]
         time.sleep(0.2)
-    mean_loss, gathered, launched, backend = out.get()
+    mean_loss, gathered, launched, used = out.get()
     for proc in procs:
         proc.join(120)
         assert proc.exitcode == 0
-    assert backend == 'nccl' and launched >= 2
+    assert used == backend and launched >= 2
     assert np.array_equal(gathered[0], gathered[1])         # replicas stay identical
     cfg, flat, feats, flen, labels = _setup()
     single = Trainer(cfg, device='cuda:0', params=flat)
@@ -93,3 +96,15 @@ def test_two_rccl_ranks_equal_one_rank_full_batch():
     assert abs(float(loss) - mean_loss) < 1e-5
     want = single.model.arena.param.cpu().numpy()
     assert np.abs(gathered[0] - want).max() < 1e-6
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL over xGMI)')
+def test_two_rccl_ranks_equal_one_rank_full_batch():
+    _two_ranks_against_one('nccl', share_gpu=False)
+
+
+def test_two_gloo_ranks_sharing_one_gpu_equal_one_rank_full_batch():
+    """The same check where only one GPU exists: both ranks on cuda:0, collectives through gloo.
+    Everything but the transport is the production path: gradient hooks, buckets launched from
+    the main and the side stream, the held-back release, Adam's 1 / world scaling."""
+    _two_ranks_against_one('gloo', share_gpu=True)

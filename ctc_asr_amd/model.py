@@ -312,7 +312,7 @@ class CTCModel:
         self.step_count = 0
         # weight-gradient GEMMs run on a low-priority side stream so that they fill the half of
         # the chip the latency-bound backward recurrence of the layer below leaves free
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get('CTCASR_OVERLAP_WGRAD', '1') == '1'
         # the reference's convolution stack runs on this package's own implicit-GEMM kernels
         # (forward, data gradient, kernel gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
@@ -685,13 +685,24 @@ class CTCModel:
             side = self._side_stream
         deferred = []          # layer hooks that must wait for the side stream
 
-        def on_side(tensors, fn, head_start_us=0):
+        # The LSTM / GRU at H = 2048 run their backward recurrence on ALL 256 CUs (one direction
+        # per launch): GEMMs on the side stream then only get in its way - every persistent
+        # workgroup needs a CU of its own, the resident ones spin until the last GEMM workgroup
+        # has drained (ref_best: 33.2 instead of 21.4 us per step, 187 instead of 177 ms per
+        # training step).  Their weight gradients stay on the main stream; only the bottom
+        # layer's overlap the front-end backward, where no persistent kernel runs.
+        whole_chip_rnn = (cfg.cell in ('lstm', 'gru') and cfg.num_units_rnn == 2048 and
+                          hip.rnn_persistent_supported(cfg.cell, acts['t_out'], acts['batch'],
+                                                       cfg.num_units_rnn))
+
+        def on_side(tensors, fn, head_start_us=0, beside_recurrence=True):
             """Run ``fn`` (weight-gradient work that nothing downstream in this backward pass
             reads) on the side stream once everything enqueued on the main stream so far is done.
             ``head_start_us`` idles the side stream first so that a persistent recurrence kernel
             enqueued next on the main stream claims its 128 CUs before these GEMMs fill the chip
-            (otherwise it starts only when the first GEMM has drained)."""
-            if side is main:
+            (otherwise it starts only when the first GEMM has drained).  ``beside_recurrence``:
+            the work would run while a recurrence launch is on the main stream."""
+            if side is main or (whole_chip_rnn and beside_recurrence):
                 fn()
                 return
             ready = torch.cuda.Event()
@@ -807,7 +818,8 @@ class CTCModel:
                              y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
                              out=g[name + '/w_hh'][1])
 
-            on_side([dxw], weight_grads, head_start_us=self.side_head_start_us if i > 0 else 0)
+            on_side([dxw], weight_grads, head_start_us=self.side_head_start_us if i > 0 else 0,
+                    beside_recurrence=i > 0)
             deferred.append(name)
             if dy_below is not None:
                 dy = dy_below

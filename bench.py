@@ -389,7 +389,10 @@ def measure(name, args, rank, local_rank, world):
                 'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ''),
                 'bytes_per_step': int(model.arena.size * 4),
                 'launches_per_step': trainer.reducer.launched / float(args.steps),
-                'bucket_bytes': int(trainer.reducer.bucket_elems * 4)}
+                'bucket_bytes': int(trainer.reducer.bucket_elems * 4),
+                'release': 'per layer, behind its weight-gradient GEMMs (CTCASR_ALLREDUCE_EARLY)'
+                           if trainer.reducer.hold_until is None
+                           else 'after the last persistent recurrence launch of the step'}
     del trainer, model
     torch.cuda.empty_cache()
     return result, (cfg, frames, batch, seconds)

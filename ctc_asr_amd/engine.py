@@ -126,8 +126,16 @@ class Trainer:
         self.beta1 = getattr(flags, 'adam_beta1', 0.9) if flags is not None else 0.9
         self.beta2 = getattr(flags, 'adam_beta2', 0.999) if flags is not None else 0.999
         self.eps = getattr(flags, 'adam_epsilon', 1e-8) if flags is not None else 1e-8
+        # CTCASR_ALLREDUCE_EARLY=1 (opt-in until measured on a multi-GPU box): every layer's
+        # bucket is reduced as soon as its weight-gradient GEMMs are done on the side stream,
+        # beside the recurrences of the layers below, instead of after the last persistent
+        # launch.  No deadlock is possible either way - RCCL's workgroups need no CU that a
+        # backward recurrence (128 CUs) must have, and a persistent workgroup that finds its CU
+        # taken waits (spin limit: seconds) - the default only avoids any contention.
+        early = os.environ.get('CTCASR_ALLREDUCE_EARLY', '0') == '1'
+        self.model.early_hooks = early and world_size > 1
         self.reducer = GradientReducer(self.model.arena.grad, world_size, bucket_bytes,
-                                       hold_until='rnn0')
+                                       hold_until=None if early else 'rnn0')
         if world_size > 1:   # identical replicas: rank 0's initial parameters win
             dist.broadcast(self.model.arena.param, src=0)
         # The host enqueues a step several times faster than the GPU runs it.  Left alone it

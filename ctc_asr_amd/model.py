@@ -325,6 +325,7 @@ class CTCModel:
         # pipelined with it on the other half of the chip (1 = off: whole-chip single launch)
         self.fwd_chunks = max(1, int(os.environ.get('CTCASR_FWD_CHUNKS', '4')))
         self._side_stream = None
+        self.early_hooks = False        # see backward(); set by engine.Trainer
         # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
         # other half of the chip runs the weight-gradient GEMMs of the layer above
         self.rnn_bwd_flags = hip.RNN_DEFAULT
@@ -728,9 +729,19 @@ class CTCModel:
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
         dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
-        on_side([dz], lambda: torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel']),
-                head_start_us=self.side_head_start_us)
-        deferred.append('dense4')
+        # `early_hooks` (opt-in, N > 1): a layer's hook - its bucket's all-reduce - fires on the
+        # side stream right behind that layer's weight-gradient GEMMs instead of after the whole
+        # backlog, so the collective hides behind the layers below (engine.Trainer)
+        early = self.early_hooks
+
+        def dense4_weight_grad():
+            torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel'])
+            if early:
+                done('dense4')
+
+        on_side([dz], dense4_weight_grad, head_start_us=self.side_head_start_us)
+        if not early:
+            deferred.append('dense4')
 
         # recurrent stack, top layer first
         need_dx_first = True
@@ -818,9 +829,16 @@ class CTCModel:
                              y[1:, :, hidden:].reshape((t_out - 1) * batch, hidden),
                              out=g[name + '/w_hh'][1])
 
-            on_side([dxw], weight_grads, head_start_us=self.side_head_start_us if i > 0 else 0,
+            def layer_weight_grads(name=name, weight_grads=weight_grads):
+                weight_grads()
+                if early:
+                    done(name)
+
+            on_side([dxw], layer_weight_grads,
+                    head_start_us=self.side_head_start_us if i > 0 else 0,
                     beside_recurrence=i > 0)
-            deferred.append(name)
+            if not early:
+                deferred.append(name)
             if dy_below is not None:
                 dy = dy_below
         # The deferred layers' gradients are final once the side stream has drained.  Their hooks

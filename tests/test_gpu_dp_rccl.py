@@ -103,8 +103,11 @@ def test_two_rccl_ranks_equal_one_rank_full_batch():
     _two_ranks_against_one('nccl', share_gpu=False)
 
 
-def test_two_gloo_ranks_sharing_one_gpu_equal_one_rank_full_batch():
+@pytest.mark.parametrize('early', ['0', '1'])
+def test_two_gloo_ranks_sharing_one_gpu_equal_one_rank_full_batch(early, monkeypatch):
     """The same check where only one GPU exists: both ranks on cuda:0, collectives through gloo.
     Everything but the transport is the production path: gradient hooks, buckets launched from
-    the main and the side stream, the held-back release, Adam's 1 / world scaling."""
+    the main and the side stream, the held-back release (default) or the per-layer early
+    release (CTCASR_ALLREDUCE_EARLY=1), Adam's 1 / world scaling."""
+    monkeypatch.setenv('CTCASR_ALLREDUCE_EARLY', early)      # inherited by the spawned ranks
     _two_ranks_against_one('gloo', share_gpu=True)

@@ -317,10 +317,12 @@ class CTCModel:
         # (forward, data gradient, kernel gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
         self._conv_packed = {}          # layer -> fragment-ordered weight copies
-        self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '100'))
+        self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '70'))
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
-        # launch has finished run beside the next launch instead of queueing up behind the layer
-        self.bwd_chunks = max(1, int(os.environ.get('CTCASR_BWD_CHUNKS', '3')))
+        # launch has finished run beside the next launch instead of queueing up behind the layer.
+        # 0 = by batch: 2 launches up to 16 rows (C2: 22.8 ms per step against 23.1 with 3), 3
+        # above (C3: 97.7 against 102.8 with 2, 99.1 with 4)
+        self.bwd_chunks = max(0, int(os.environ.get('CTCASR_BWD_CHUNKS', '0')))
         # launches per persistent FORWARD recurrence when the next layer's input projection is
         # pipelined with it on the other half of the chip (1 = off: whole-chip single launch)
         self.fwd_chunks = max(1, int(os.environ.get('CTCASR_FWD_CHUNKS', '4')))
@@ -762,9 +764,10 @@ class CTCModel:
             chunks = 1
             if (side is not main and acts['rnn_len'] is None and cell != 'gru' and
                     not (cell == 'lstm' and hidden == 2048) and
-                    t_out >= 8 * self.bwd_chunks and
                     hip.rnn_persistent_supported(cell, t_out, batch, hidden)):
-                chunks = self.bwd_chunks
+                chunks = self.bwd_chunks or (2 if batch <= 16 else 3)
+                if t_out < 8 * chunks:
+                    chunks = 1
             dy = dy.contiguous()
             dxw = torch.empty((t_out, batch, 2, gh), dtype=torch.float32, device=dy.device)
 

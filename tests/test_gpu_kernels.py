@@ -505,3 +505,31 @@ def test_conv0_fwd_matches_the_library_convolution(hip, shape):
     ref_dw = w64.grad.numpy()
     assert dw.shape == ref_dw.shape
     assert np.abs(dw - ref_dw).max() < 2e-4 * max(1.0, np.abs(ref_dw).max())
+
+
+def test_beam_search_random_sweep_against_the_oracle(hip):
+    """The register-resident beam set of round 2 against the C oracle over a sweep of shapes:
+    few and many classes, widths around the 64-lane and 256 / 1024 register-tile boundaries,
+    flat and peaked logits, ragged lengths.  (Continuous random logits: no exact ties.)"""
+    rng = np.random.default_rng(2024)
+    cases = 0
+    for classes in (5, 29, 40):
+        for width in (1, 7, 63, 64, 65, 255, 256, 257, 700):
+            steps = int(rng.integers(8, 40))
+            batch = int(rng.integers(1, 5))
+            scale = float(rng.choice([0.3, 1.0, 3.0]))
+            logits = (rng.normal(size=(steps, batch, classes)) * scale).astype(np.float32)
+            logits[:, :, -1] += float(rng.choice([0.0, 2.0, 4.0]))
+            seq_len = rng.integers(1, steps + 1, size=batch).astype(np.int32)
+            seq_len[0] = steps
+            norm = 'max' if (cases % 2 == 0) else 'log_softmax'
+            out, out_len, logp = hip.ctc_beam_decode(_t(logits), _t(seq_len, torch.int32), width,
+                                                     normalization=norm)
+            ref_paths, ref_logp = cref.beam_search_decode(logits, seq_len, width,
+                                                          normalization=norm)
+            out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+            for b in range(batch):
+                assert out[b, :out_len[b]].tolist() == ref_paths[b], (classes, width, steps, b)
+            assert np.allclose(logp.cpu().numpy(), ref_logp, rtol=1e-5, atol=1e-3)
+            cases += 1
+    assert cases == 27

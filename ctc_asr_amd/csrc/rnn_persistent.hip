@@ -1314,3 +1314,13 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
 }
 
 size_t prnn_error_offset() { return offsetof(SyncWords, error); }
+
+// Which non-default tuning / probe macros this library was compiled with (include/ctcasr.h).
+extern "C" unsigned ctcasr_build_flags(void) {
+    unsigned flags = 0;
+    if (PRNN_PROBE_HALF_LOADS) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
+    if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
+        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1)
+        flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
+    return flags;
+}

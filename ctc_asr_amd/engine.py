@@ -50,9 +50,19 @@ class GradientReducer:
     first launch."""
 
     def __init__(self, grad_arena, world_size, bucket_bytes=64 << 20, group=None,
-                 hold_until=None):
+                 hold_until=None, force=False, max_bucket_bytes=None):
         self.grad, self.world, self.group = grad_arena, world_size, group
+        # `force`: run the collectives even with a single rank (a world-size-1 process group is
+        # legal): tests use it to put the real backend (RCCL) under the real backward pass on a
+        # one-GPU box
+        self.active = world_size > 1 or force
         self.bucket_elems = max(1, bucket_bytes // 4)
+        # slices are merged until a bucket holds at least `bucket_bytes`; a pending range larger
+        # than `max_bucket_bytes` (a held-back release: everything at once; or one big layer) is
+        # cut into equal pieces no larger than that, so that the first piece's ring steps start
+        # while the later ones are still being enqueued and no single collective is hundreds of MB
+        self.max_bucket_elems = max(self.bucket_elems,
+                                    (max_bucket_bytes or max(bucket_bytes, 64 << 20)) // 4)
         self.pending_start = None
         self.pending_stop = None
         self.works = []
@@ -75,11 +85,11 @@ class GradientReducer:
         produced by side-stream GEMMs, so their all-reduce must be enqueued while that stream is
         still the current one - never merged into a bucket that is launched later from the main
         stream, which is not ordered after them."""
-        if self.world > 1 and self.released:
+        if self.active and self.released:
             self._flush()
 
     def hook(self, layer, start, stop):
-        if self.world <= 1:
+        if not self.active:
             return
         if layer == self.hold_until:
             self.released = True
@@ -98,14 +108,21 @@ class GradientReducer:
     def _flush(self):
         if self.pending_stop is None:
             return
-        view = self.grad[self.pending_start:self.pending_stop]
-        self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
-                                          async_op=True))
-        self.launched += 1
+        start, stop = self.pending_start, self.pending_stop
+        pieces = -(-(stop - start) // self.max_bucket_elems)
+        piece = -(-(stop - start) // pieces)
+        piece = (piece + 3) // 4 * 4                 # keep 16-byte alignment of every view
+        hi = stop
+        while hi > start:                            # from the end: the order backward made them
+            lo = max(start, hi - piece)
+            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM,
+                                              group=self.group, async_op=True))
+            self.launched += 1
+            hi = lo
         self.pending_start = self.pending_stop = None
 
     def finish(self):
-        if self.world <= 1:
+        if not self.active:
             return
         self.released = self.hold_until is None
         self._flush()
@@ -118,7 +135,8 @@ class Trainer:
     """Owns a `CTCModel` replica on this rank's GPU and runs synchronous data-parallel steps."""
 
     def __init__(self, cfg, flags=None, device=None, seed=0, params=None, world_size=1, rank=0,
-                 bucket_bytes=64 << 20, conv_autotune=None):
+                 bucket_bytes=64 << 20, conv_autotune=None, allreduce_early=None,
+                 force_reducer=False, reduce=True):
         self.world, self.rank = world_size, rank
         device = device or 'cuda:{}'.format(torch.cuda.current_device())
         self.model = CTCModel(cfg, device, seed=seed, params=params, conv_autotune=conv_autotune)
@@ -126,16 +144,30 @@ class Trainer:
         self.beta1 = getattr(flags, 'adam_beta1', 0.9) if flags is not None else 0.9
         self.beta2 = getattr(flags, 'adam_beta2', 0.999) if flags is not None else 0.999
         self.eps = getattr(flags, 'adam_epsilon', 1e-8) if flags is not None else 1e-8
-        # CTCASR_ALLREDUCE_EARLY=1 (opt-in until measured on a multi-GPU box): every layer's
-        # bucket is reduced as soon as its weight-gradient GEMMs are done on the side stream,
-        # beside the recurrences of the layers below, instead of after the last persistent
-        # launch.  No deadlock is possible either way - RCCL's workgroups need no CU that a
-        # backward recurrence (128 CUs) must have, and a persistent workgroup that finds its CU
-        # taken waits (spin limit: seconds) - the default only avoids any contention.
-        early = os.environ.get('CTCASR_ALLREDUCE_EARLY', '0') == '1'
-        self.model.early_hooks = early and world_size > 1
-        self.reducer = GradientReducer(self.model.arena.grad, world_size, bucket_bytes,
-                                       hold_until=None if early else 'rnn0')
+        # Release of the gradient buckets (``allreduce_early``; None = CTCASR_ALLREDUCE_EARLY):
+        #   held (default)  nothing is reduced before the last persistent recurrence launch of
+        #                   the backward pass has been issued (`hold_until='rnn0'`);
+        #   early           every layer's bucket is reduced as soon as its weight-gradient GEMMs
+        #                   are done on the side stream, beside the recurrences of the layers
+        #                   below.  RCCL's workgroups occupy CUs for as long as a collective runs;
+        #                   the H = 1024 backward recurrence needs 128 of the 256 CUs, so both
+        #                   fit - a persistent workgroup that finds its CU taken waits (spin
+        #                   limit: seconds).  bench.py measures both modes at N > 1.
+        # Models whose recurrence takes ALL 256 CUs (LSTM / GRU at H = 2048) always hold: there
+        # the hooks run on the main stream right in front of whole-chip persistent launches,
+        # whose resident workgroups would spin until the collective has drained.
+        if allreduce_early is None:
+            allreduce_early = os.environ.get('CTCASR_ALLREDUCE_EARLY', '0') == '1'
+        whole_chip = cfg.cell in ('lstm', 'gru') and cfg.num_units_rnn == 2048
+        early = bool(allreduce_early) and not whole_chip
+        active = (world_size > 1 or force_reducer) and reduce
+        self.model.early_hooks = early and active
+        # ``reduce=False`` (bench.py's "stubbed" leg): the same step without any collective, to
+        # price what the all-reduce adds to it; replicas drift apart - timing only
+        self.reducer = GradientReducer(self.model.arena.grad, world_size if reduce else 1,
+                                       bucket_bytes, hold_until=None if early else 'rnn0',
+                                       force=force_reducer and reduce)
+        self.release = 'early' if early else 'held'
         if world_size > 1:   # identical replicas: rank 0's initial parameters win
             dist.broadcast(self.model.arena.param, src=0)
         # The host enqueues a step several times faster than the GPU runs it.  Left alone it
@@ -146,24 +178,70 @@ class Trainer:
         self.max_steps_ahead = 2
         self._step_done = collections.deque()
         self.host_wait_s = 0.0          # time spent waiting there (bench.py reports the rest)
+        # Deferred error checks (``train_step(check=True)``): a step's CTC status words travel to
+        # pinned host memory with an asynchronous copy and are looked at when that step is known
+        # to have finished - at the wait above, `max_steps_ahead` steps later - and the sticky
+        # time-out word of the persistent recurrence kernels (no launch clears it) is polled
+        # every `rnn_poll_every` steps and by `drain_checks()`.  Neither stalls the host, so the
+        # run-ahead above also holds for real training, not only for the benchmark.
+        self.rnn_poll_every = 50
+        self._pending_status = collections.deque()
+        self._steps_since_poll = 0
+
+    def _check_finished_steps(self, wait=False):
+        """Raise for any finished step whose CTC status reported an infeasible alignment /
+        bad labels (``wait``: block until every pending step has finished)."""
+        while self._pending_status:
+            event, host, step = self._pending_status[0]
+            if not wait and not event.query():
+                break
+            event.synchronize()
+            self._pending_status.popleft()
+            try:
+                CTCModel.check_status(host)
+            except ValueError as err:
+                raise type(err)('{} [training step {}]'.format(err, step)) from None
+
+    def drain_checks(self):
+        """Wait for the steps in flight and raise what they have to report: CTC status of every
+        pending step, then the persistent kernels' time-out word.  `train.train_epoch` calls
+        this where it reads the loss anyway, at the end of an epoch and before a checkpoint."""
+        self._check_finished_steps(wait=True)
+        self.model.check_rnn_error()
+        self._steps_since_poll = 0
 
     def train_step(self, features, feature_len, labels, check=True):
         """forward + CTC + backward (+ all-reduce) + Adam on this rank's shard of the global
         batch; returns the local mean loss (device scalar).  The global loss is the mean over
         ranks of the local means (equal shard sizes), so gradients are summed and scaled by
-        1 / world_size inside the Adam kernel."""
+        1 / world_size inside the Adam kernel.
+
+        ``check=True``: errors are raised without stalling the host - an infeasible alignment
+        (where ``tf.nn.ctc_loss`` raises) surfaces at most `max_steps_ahead` steps after the
+        step that hit it, a timed-out persistent kernel at most `rnn_poll_every` steps later or
+        at the next `drain_checks()`; in both cases before a checkpoint is written."""
         if len(self._step_done) >= self.max_steps_ahead:
             t0 = time.perf_counter()
             while len(self._step_done) >= self.max_steps_ahead:
                 self._step_done.popleft().synchronize()
             self.host_wait_s += time.perf_counter() - t0
-        loss = self.model.forward_backward(features, feature_len, labels,
-                                           reduce_hook=self.reducer, check=check)
         if check:
-            # a persistent recurrence kernel that gave up at a grid barrier (e.g. starved of
-            # co-residency by another process on the GPU) produced garbage: stop before Adam
-            # consumes it.  (check=False callers poll `model.check_rnn_error()` themselves.)
-            self.model.check_rnn_error()
+            self._check_finished_steps()
+            self._steps_since_poll += 1
+            if self._steps_since_poll >= self.rnn_poll_every:
+                # (synchronises: once per `rnn_poll_every` steps)
+                self._check_finished_steps(wait=True)
+                self.model.check_rnn_error()
+                self._steps_since_poll = 0
+        loss = self.model.forward_backward(features, feature_len, labels,
+                                           reduce_hook=self.reducer, check=False)
+        if check:
+            status = self.model.last_status
+            host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+            host.copy_(status, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(torch.cuda.current_stream(self.model.device))
+            self._pending_status.append((copied, host, self.model.step_count + 1))
         self.reducer.finish()
         self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
                                    grad_scale=1.0 / self.world)

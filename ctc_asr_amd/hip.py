@@ -15,6 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libctcasr.so')
 
 ABI_VERSION = 2
+BUILD_PROBE_WRONG_RESULTS, BUILD_NONDEFAULT_TUNING = 1, 2      # ctcasr_build_flags() bits
 RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP, RNN_ONE_BARRIER = 0, 1, 2, 4   # rnn_fwd/bwd `flags`
 CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
 CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}
@@ -25,6 +26,7 @@ _c_f, _c_p, _c_sz = ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 # name -> (restype, argtypes); doubles as the list of symbols the ABI must export
 SIGNATURES = {
     'ctcasr_abi_version': (_c_int, []),
+    'ctcasr_build_flags': (ctypes.c_uint, []),
     'ctcasr_error_string': (ctypes.c_char_p, [_c_int]),
     'ctcasr_set_option': (_c_int, [ctypes.c_char_p, _c_int]),
     'ctcasr_rnn_kernel_events': (_c_int, [_c_p, _c_p]),
@@ -127,6 +129,13 @@ def load(path=None):
         fn.restype, fn.argtypes = restype, argtypes
     if lib.ctcasr_abi_version() != ABI_VERSION:
         raise CtcAsrError('libctcasr ABI version mismatch')
+    # probe builds of the kernels (tools/build_alt.sh -DPRNN_PROBE_...) compute wrong results on
+    # purpose: never let one stand in for the product library by accident
+    if lib.ctcasr_build_flags() & BUILD_PROBE_WRONG_RESULTS and \
+            os.environ.get('CTCASR_ALLOW_PROBE_BUILD') != '1':
+        raise CtcAsrError('{} is a timing-probe build (ctcasr_build_flags() = {:#x}: results are '
+                          'wrong on purpose); set CTCASR_ALLOW_PROBE_BUILD=1 to load it anyway.'
+                          .format(path, lib.ctcasr_build_flags()))
     _lib = lib
     return lib
 
@@ -242,11 +251,11 @@ def ctc_greedy_decode(logits, seq_len, blank=None, out=None, out_len=None):
     return out, out_len
 
 
-@_on_tensor_device
 def ctc_beam_workspace_bytes(num_steps, batch, classes, beam_width):
     return load().ctcasr_ctc_beam_workspace_bytes(num_steps, batch, classes, int(beam_width))
 
 
+@_on_tensor_device
 def ctc_beam_decode(logits, seq_len, beam_width, blank=None, normalization='max'):
     num_steps, batch, classes = logits.shape
     blank = classes - 1 if blank is None else blank

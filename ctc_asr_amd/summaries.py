@@ -51,21 +51,29 @@ class ThroughputLogger:
 
     def __init__(self, log_frequency, batch_size):
         self.log_frequency, self.batch_size = int(log_frequency), int(batch_size)
-        self._start, self._audio = time.time(), 0.0
+        self._start, self._audio, self._steps = time.time(), 0.0, 0
 
     def add_audio(self, seconds):
+        """One training step over ``seconds`` of audio went into the current window."""
         self._audio += float(seconds)
+        self._steps += 1
+
+    def restart(self):
+        """Start the window now (after work that is not training: summaries, decoding)."""
+        self._start = time.time()
 
     def line(self, global_step, loss_value):
         """Returns (text line, examples/sec, audio-s/s) and starts the next window."""
         now = time.time()
         duration = max(now - self._start, 1e-9)
-        examples_per_sec = self.log_frequency * self.batch_size / duration
+        # the steps actually taken in this window (the reference's hook assumes log_frequency of
+        # them, which overstates the first line of an epoch, logged after ONE step)
+        steps = max(self._steps, 1)
+        examples_per_sec = steps * self.batch_size / duration
         audio_per_sec = self._audio / duration
         text = ('{:%Y-%m-%d %H:%M:%S}: (step={:,d}); loss={:.4f}; {:.1f} examples/sec '
                 '({:.3f} sec/batch) ({:.2f} batch/sec); {:.1f} audio-s/s'.format(
                     datetime.now(), global_step, loss_value, examples_per_sec,
-                    duration / float(self.log_frequency), self.log_frequency / duration,
-                    audio_per_sec))
-        self._start, self._audio = now, 0.0
+                    duration / float(steps), steps / duration, audio_per_sec))
+        self._start, self._audio, self._steps = now, 0.0, 0
         return text, examples_per_sec, audio_per_sec

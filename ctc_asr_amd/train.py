@@ -48,6 +48,7 @@ def train_epoch(trainer, target, epoch, rank, world, writer=None):
         logger.add_audio(batch.audio_seconds * world)
         if model.step_count % FLAGS.log_frequency == 0 or steps == 1:
             value = float(trainer.global_mean(loss))
+            trainer.drain_checks()      # the loss read above synchronised anyway
             if not math.isfinite(value):
                 raise NanLossDuringTrainingError('NaN loss during training.')
             window_loss = value
@@ -71,6 +72,9 @@ def train_epoch(trainer, target, epoch, rank, world, writer=None):
                     writer.text('decoded_text', summary[:, :FLAGS.num_samples_to_report], step)
             else:
                 logger.line(model.step_count, value)
+            # the decode and the summary records above are not training time
+            logger.restart()
+    trainer.drain_checks()              # nothing unchecked reaches the checkpoint
     return steps, window_loss
 
 

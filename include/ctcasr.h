@@ -49,6 +49,14 @@ enum {
 typedef void *ctcasr_stream_t;
 
 int ctcasr_abi_version(void);
+/* Bit mask of the non-default compile-time macros this library was built with.  A/B and probe
+ * builds of the recurrence kernels (tools/build_alt.sh) come out of the same sources as the
+ * product; a loader must refuse a library whose CTCASR_BUILD_PROBE_WRONG_RESULTS bit is set
+ * (a timing probe that skips part of the arithmetic ON PURPOSE) unless it was asked for one -
+ * ctc_asr_amd/hip.py does (CTCASR_ALLOW_PROBE_BUILD=1 to override).  0 = the product build. */
+#define CTCASR_BUILD_PROBE_WRONG_RESULTS 1u   /* e.g. -DPRNN_PROBE_HALF_LOADS=1               */
+#define CTCASR_BUILD_NONDEFAULT_TUNING   2u   /* PRNN_GROUPS / _XCD_AWARE / _CHAIN_* / ...     */
+unsigned ctcasr_build_flags(void);
 /* Process-wide PROFILING switch (no option changes what a call computes or which kernel variant
  * it runs - that is the per-call `flags` argument of ctcasr_rnn_fwd_steps / _bwd_steps):
  * "rnn_kernel_events" (0/1, default 0): record a HIP event pair on the launch stream around every

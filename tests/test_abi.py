@@ -82,6 +82,39 @@ def test_host_wrappers_refuse_cpu_tensors(lib):
         CTCModel(ModelConfig(num_units_rnn=64, num_layers_rnn=1, num_units_dense=32), 'cpu')
 
 
+def test_probe_builds_cannot_stand_in_for_the_product(lib, monkeypatch):
+    """The product library reports build flags 0.  A timing-probe build of the recurrence
+    kernels (tools/build_alt.sh ... -DPRNN_PROBE_HALF_LOADS=1: skips half of the operand loads,
+    results wrong on purpose) comes out of the same sources; `hip.load` must refuse it unless
+    CTCASR_ALLOW_PROBE_BUILD=1 says that a probe is what the caller wants."""
+    import subprocess
+    from ctc_asr_amd import hip
+    assert lib.ctcasr_build_flags() == 0
+    out = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'build_alt.sh'), 'abitest',
+                          '-DPRNN_PROBE_HALF_LOADS=1', '-DPRNN_CHAIN_LB=8',
+                          '-DPRNN_CHAIN_REGW=28'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    path = os.path.join(ROOT, out.stdout.strip().splitlines()[-1])
+    product = hip._lib
+    try:
+        monkeypatch.delenv('CTCASR_ALLOW_PROBE_BUILD', raising=False)
+        with pytest.raises(hip.CtcAsrError, match='probe'):
+            hip.load(path)
+        assert hip._lib is product           # the refused library did not replace the product
+        monkeypatch.setenv('CTCASR_ALLOW_PROBE_BUILD', '1')
+        probe = hip.load(path)
+        assert probe.ctcasr_build_flags() == (hip.BUILD_PROBE_WRONG_RESULTS |
+                                              hip.BUILD_NONDEFAULT_TUNING)
+    finally:
+        hip._lib = product
+        for ext in ('.so', '.o', '.remarks'):
+            try:
+                os.remove(path[:-3] + ext)
+            except OSError:
+                pass
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from ctc_asr_amd import hip
     with pytest.raises(hip.CtcAsrError):

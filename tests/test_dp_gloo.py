@@ -46,9 +46,24 @@ def _reducer_worker(rank, world, port, out):
     reducer.hook('b', 100, 400)
     assert not reducer.works and torch.all(arena == float(rank + 1))
     reducer.hook('a', 0, 100)
-    assert len(reducer.works) == 1          # one merged bucket over the whole arena
+    assert len(reducer.works) == 1          # below max_bucket_bytes: one merged bucket
     reducer.finish()
     assert torch.all(arena == 3.0)
+    # ... and a released range larger than max_bucket_bytes goes out in equal pieces no larger
+    # than that (1000 floats, at most 300 per collective -> 4 x 250), every element exactly once
+    arena.fill_(float(rank + 1))
+    reducer = GradientReducer(arena, world, bucket_bytes=4, hold_until='a',
+                              max_bucket_bytes=1200)
+    for name, start, stop in reversed(slices):
+        reducer.hook(name, start, stop)
+    assert len(reducer.works) == 4 and reducer.launched == 4
+    reducer.finish()
+    assert torch.all(arena == 3.0)
+    # force=True runs the collectives whatever the world size; inactive = no-op
+    idle = GradientReducer(arena, 1, bucket_bytes=4)
+    idle.hook('c', 400, 1000)
+    idle.finish()
+    assert idle.launched == 0
     if rank == 0:
         out.put('ok')
     dist.destroy_process_group()

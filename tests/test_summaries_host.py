@@ -27,3 +27,22 @@ def test_throughput_line_has_the_reference_fields():
     assert examples_per_sec > 0 and audio_per_sec > 0
     _, _, audio_after = logger.line(1240, 1.0)
     assert audio_after == 0.0            # the window restarts
+
+
+def test_throughput_counts_the_steps_actually_in_the_window(monkeypatch):
+    """The first line of an epoch is logged after ONE step: examples/sec must be one batch over
+    the window, not log_frequency batches (the reference's hook assumes the latter)."""
+    now = [100.0]
+    monkeypatch.setattr(summaries.time, 'time', lambda: now[0])
+    logger = summaries.ThroughputLogger(log_frequency=200, batch_size=16)
+    logger.add_audio(160.0)
+    now[0] += 2.0
+    _, examples_per_sec, audio_per_sec = logger.line(1, 5.0)
+    assert examples_per_sec == 8.0 and audio_per_sec == 80.0
+    now[0] += 30.0                       # decode + summaries of the log step: not training time
+    logger.restart()
+    for _ in range(200):
+        logger.add_audio(160.0)
+    now[0] += 50.0
+    line, examples_per_sec, _ = logger.line(201, 4.0)
+    assert examples_per_sec == 64.0 and '(0.250 sec/batch)' in line

@@ -56,8 +56,19 @@ WORKLOADS = {
     # the reference's best published model (testruns.md: 3c4r2d / 3c5r2d, LSTM cells, 2048 units)
     'ref_best': ((32, 32, 96), 4, 2048, 2048, 16, 10.0, 'lstm'),
     'tiny': ((8, 8), 1, 128, 128, 4, 2.0, 'lstm'),                # plumbing check
+    # configs[4]: mixed-length bucketed batches (0.7-17 s, LibriSpeech-shaped), beam width 64;
+    # `seconds` is a placeholder - every batch of the seeded bucket sequence has its own length
+    'c5': ((32, 32), 2, 1024, 2048, 16, None, 'lstm'),
 }
-BASELINE_NAMES = {'c2': 'BASELINE.json configs[1]', 'c3': 'BASELINE.json configs[2]'}
+BASELINE_NAMES = {'c2': 'BASELINE.json configs[1]', 'c3': 'BASELINE.json configs[2]',
+                  'c5': 'BASELINE.json configs[4]'}
+C5_BEAM_WIDTH = 64
+
+RELEASE_TEXT = {
+    'held': 'after the last persistent recurrence launch of the step (hold_until=rnn0), in '
+            'buckets of at most max_bucket_bytes',
+    'early': 'per layer, behind its weight-gradient GEMMs on the side stream, beside the '
+             'recurrences of the layers below (CTCASR_ALLREDUCE_EARLY=1)'}
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
@@ -217,9 +228,11 @@ def pmc_traffic(workload, which, launch_steps):
                             'profiles/pmc_traffic.json'.format(workload, which, launch_steps)}
 
 
-def measure(name, args, rank, local_rank, world):
+def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=True):
     """Build the workload ``name`` on this rank's GPU, run warm-up + timed steps under the
-    contract's protocol and return the result dict (rank 0) or None."""
+    contract's protocol and return the result dict (rank 0) or None.  ``allreduce_early``
+    selects the release mode of the gradient buckets (None: the environment / default),
+    ``reduce=False`` runs the same step without any collective (to price the all-reduce)."""
     from ctc_asr_amd import hip
     from ctc_asr_amd.engine import Trainer
     from ctc_asr_amd.model import CTCModel, GATES, ModelConfig
@@ -232,7 +245,8 @@ def measure(name, args, rank, local_rank, world):
                       num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell, cudnn=True,
                       dense_dropout_rate=args.dropout)
     # fixed input shape: let MIOpen benchmark its convolution kernels once (warm-up steps)
-    trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True)
+    trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True,
+                      allreduce_early=allreduce_early, reduce=reduce)
     model = trainer.model
     if args.rnn_bwd_whole_chip:
         model.rnn_bwd_flags = hip.RNN_WHOLE_CHIP
@@ -253,7 +267,9 @@ def measure(name, args, rank, local_rank, world):
         # hot path from raw audio: log-mel features + per-utterance normalisation on the GPU,
         # then forward / CTC / backward / all-reduce / Adam
         hip.features(pcm_d, nsamp_d, 'mel', 'local', False, 16000, out=feat_buf, out_len=len_d)
-        return trainer.train_step(feat_buf, len_d, packed, check=False)
+        # (check=True: the production path of train.py - its error checks are deferred and do
+        # not stall the host, engine.Trainer.train_step)
+        return trainer.train_step(feat_buf, len_d, packed, check=not args.no_step_checks)
 
     for _ in range(args.warmup):
         loss = step()
@@ -283,10 +299,14 @@ def measure(name, args, rank, local_rank, world):
     hip.EVENTS = None
     kernel_events = hip.rnn_kernel_events()
     hip.set_option('rnn_kernel_events', 0)
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)          # MAX over ranks (the contract)
+    trainer.drain_checks()
     CTCModel.check_status(model.last_status)
     # a persistent recurrence launch that gave up at a grid barrier would have produced garbage
     # (sticky word: covers every layer, pass and step since the check before the timed region)
@@ -390,12 +410,302 @@ def measure(name, args, rank, local_rank, world):
                 'bytes_per_step': int(model.arena.size * 4),
                 'launches_per_step': trainer.reducer.launched / float(args.steps),
                 'bucket_bytes': int(trainer.reducer.bucket_elems * 4),
-                'release': 'per layer, behind its weight-gradient GEMMs (CTCASR_ALLREDUCE_EARLY)'
-                           if trainer.reducer.hold_until is None
-                           else 'after the last persistent recurrence launch of the step'}
+                'max_bucket_bytes': int(trainer.reducer.max_bucket_elems * 4),
+                'mode': trainer.release if reduce else 'stubbed',
+                'release': RELEASE_TEXT[trainer.release] if reduce else
+                           'no collective at all (timing reference; replicas drift apart)',
+                'rank_ms_per_step': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3),
+                                     'all': [round(v, 3) for v in rank_ms]}}
     del trainer, model
     torch.cuda.empty_cache()
     return result, (cfg, frames, batch, seconds)
+
+
+# ------------------------------------------------------------------------------ C5
+def c5_bucket_sequence(batch, count, seed=1234, pool=4096, num_buckets=96):
+    """A fixed, seeded sequence of ``count`` bucketed batches: ``pool`` utterance durations from
+    the LibriSpeech-shaped log-normal of SURVEY.md 8d within [0.7, 17] s (utterances outside
+    are dropped like the reference's corpus filter does), bucket boundaries
+    picked like ``get_bucket_boundaries`` does from a length-sorted CSV (``num_buckets`` = 96,
+    the reference default), a seeded shuffle, and the package's own grouping code
+    (``input_functions._group_batches``: a bucket emits a batch when it holds ``batch``
+    utterances).  Returns a list of int arrays of sample counts, one per batch."""
+    import bisect
+    import random
+    from ctc_asr_amd import input_functions as inp
+    from ctc_asr_amd.synth import librispeech_like_durations
+    rng = np.random.default_rng(seed)
+    seconds = np.sort(librispeech_like_durations(rng, pool, drop=True))
+    samples = np.round(seconds * 16000).astype(np.int64)
+    frames = [1 + int(np.ceil((n - 400) / 160.0)) for n in samples]
+    lengths = [int(float('{:.4f}'.format(n / 16000.0)) / 0.01) for n in samples]
+    step = len(lengths) // num_buckets
+    boundaries = sorted({lengths[i] for i in range(step, len(lengths), step)})
+    order = list(range(pool))
+    random.Random(seed).shuffle(order)
+    stream = ((None, None, None, frames[i], int(samples[i])) for i in order)
+    out = []
+    for group in inp._group_batches(stream, True, boundaries, batch):
+        if len(group) == batch:
+            out.append(np.array([item[4] for item in group], dtype=np.int32))
+        if len(out) == count:
+            break
+    del bisect
+    return out
+
+
+def measure_c5(args, rank, local_rank, world):
+    """BASELINE.json configs[4] on this rank's GPU: training over a fixed seeded sequence of
+    ``args.steps`` bucketed mixed-length batches (one untimed pass to warm the allocator over the
+    sequence's shapes, one timed pass), then evaluation-style decoding of the same batches with
+    the beam search at width 64 (logits of all batches decoded in grouped launches)."""
+    from ctc_asr_amd import hip
+    from ctc_asr_amd.engine import Trainer
+    from ctc_asr_amd.labels import encode
+    from ctc_asr_amd.model import CTCModel, GATES, ModelConfig
+    from ctc_asr_amd.synth import random_label, random_pcm
+    import torch.distributed as dist
+
+    device = 'cuda:{}'.format(local_rank)
+    filters, layers, hidden, dense, batch, _, rnn_cell = WORKLOADS['c5']
+    cfg = ModelConfig(used_model='ds2', conv_filters=filters, num_units_dense=dense,
+                      num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell, cudnn=True,
+                      dense_dropout_rate=args.dropout, beam_width=C5_BEAM_WIDTH)
+    trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank)
+    model = trainer.model
+    sequence = c5_bucket_sequence(batch, args.steps)
+    rng = np.random.default_rng(4321 + rank)
+    noise = torch.from_numpy(random_pcm(rng, 272000 + 4096 * batch)).to(device)
+    batches = []
+    for nsamp in sequence:
+        width = int(nsamp.max())
+        pcm = torch.zeros((batch, width), dtype=torch.int16, device=device)
+        rows = []
+        for b, n in enumerate(nsamp):
+            start = int(rng.integers(0, 4096 * batch))
+            pcm[b, :n] = noise[start:start + int(n)]
+            text = random_label(rng, max(1, int(n / 16000.0 * 15.0)))
+            rows.append(list(encode(text)))
+        batches.append({'pcm': pcm, 'nsamp': torch.from_numpy(nsamp).to(device),
+                        'labels': CTCModel.pack_labels(rows, model.device),
+                        'seconds': float(nsamp.sum()) / 16000.0,
+                        'padded_seconds': batch * width / 16000.0,
+                        't_out': cfg.output_time(hip.features_num_frames(width))})
+
+    def train_pass():
+        loss = None
+        for item in batches:
+            feats, lengths = hip.features(item['pcm'], item['nsamp'], 'mel', 'local', False, 16000)
+            loss = trainer.train_step(feats, lengths, item['labels'],
+                                      check=not args.no_step_checks)
+        return loss
+
+    train_pass()
+    torch.cuda.synchronize()
+    trainer.drain_checks()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    hip.set_option('rnn_kernel_events', 1)
+    hip.rnn_kernel_events()
+    trainer.host_wait_s = 0.0
+    t0 = time.perf_counter()
+    loss = train_pass()
+    issued = time.perf_counter() - t0 - trainer.host_wait_s
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_events = hip.rnn_kernel_events()
+    hip.set_option('rnn_kernel_events', 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    trainer.drain_checks()
+
+    # evaluation-style decode: forward in eval mode, logits kept, grouped beam-search launches
+    def decode_pass():
+        pending, t_fwd, t_dec, decoded_utts = [], 0.0, 0.0, 0
+        torch.cuda.synchronize()
+        for item in batches:
+            t1 = time.perf_counter()
+            feats, lengths = hip.features(item['pcm'], item['nsamp'], 'mel', 'local', False, 16000)
+            logits, seq_len = model.inference_fn(feats, lengths, training=False)
+            pending.append((logits.clone(), seq_len.clone(), None))
+            torch.cuda.synchronize()
+            t_fwd += time.perf_counter() - t1
+            group = model.decode_group_size(max(int(p[0].shape[0]) for p in pending), batch,
+                                            beam_width=C5_BEAM_WIDTH)
+            if len(pending) >= group or item is batches[-1]:
+                t1 = time.perf_counter()
+                results = model.decode_many(pending, beam_width=C5_BEAM_WIDTH)
+                t_dec += time.perf_counter() - t1
+                decoded_utts += sum(len(r[0]) for r in results)
+                pending = []
+        return t_fwd, t_dec, decoded_utts
+
+    decode_pass()                       # warm-up (tree pools, shapes)
+    t_fwd, t_dec, decoded_utts = decode_pass()
+    model.check_rnn_error()
+
+    result = None
+    if rank == 0:
+        audio_s = world * sum(item['seconds'] for item in batches)
+        padded_s = world * sum(item['padded_seconds'] for item in batches)
+        steps = len(batches)
+        gates = GATES[cfg.cell]
+        bwd_calls, bwd_ms = kernel_events['bwd']
+        fwd_calls, fwd_ms = kernel_events['fwd']
+        rnn_flops = sum(2.0 * 2 * batch * hidden * gates * hidden * item['t_out'] * layers
+                        for item in batches)
+        t_outs = [item['t_out'] for item in batches]
+        result = {
+            'metric': 'audio-seconds/s training throughput (DS2, mixed-length bucketed batches '
+                      '0.7-17 s)',
+            'value': round(audio_s / elapsed, 2), 'unit': 'audio-s/s', 'n_gpus': world,
+            'steps': steps, 'warmup': steps, 'ms_per_step': round(elapsed / steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (16 kHz int16 Gaussian-noise PCM resident in HBM, durations from a '
+                    'log-normal (median 10.5 s) filtered to [0.7, 17] s, 96 buckets, seeded order; random labels '
+                    'at 15 chars/s)',
+            'config': {'workload': '{}: DS2 {}-conv + {}xBiLSTM-{}, bucketed batches of {}/GPU, '
+                                   'utterances 0.7-17 s, beam width {}'.format(
+                                       BASELINE_NAMES['c5'], len(filters), layers, hidden, batch,
+                                       C5_BEAM_WIDTH),
+                       'name': 'c5', 'global_batch': world * batch,
+                       'parallelism': 'dp{}'.format(world), 'dense_dropout_rate': args.dropout,
+                       'bucket_sequence': {'batches': steps, 'seed': 1234, 'pool': 4096,
+                                           'num_buckets': 96,
+                                           'ctc_steps_min_mean_max': [min(t_outs), round(
+                                               float(np.mean(t_outs)), 1), max(t_outs)],
+                                           'audio_seconds': round(audio_s, 1),
+                                           'padded_audio_seconds': round(padded_s, 1)},
+                       'parameters': model.arena.num_parameters()},
+            'loss': round(float(loss), 4),
+            'padded_audio_s_per_s': round(padded_s / elapsed, 2),
+            'host_enqueue_ms_per_step': round(issued / steps * 1e3, 3),
+            'decode': {
+                'beam_width': C5_BEAM_WIDTH, 'utterances': decoded_utts * world,
+                'value': round(audio_s / t_dec, 2), 'unit': 'audio-s/s',
+                'seconds_beam_search': round(t_dec, 4),
+                'seconds_forward_incl_features': round(t_fwd, 4),
+                'value_incl_forward': round(audio_s / (t_dec + t_fwd), 2),
+                'note': 'evaluation path: eval-mode forward per batch, logits kept, beam search '
+                        'in grouped launches (CTCModel.decode_many), host conversion included'},
+            'roofline': {
+                'kernel': 'prnn_bwd_kernel<LSTM> over the whole bucket sequence (launches of '
+                          'T\'/2 steps x 2 directions, batch {})'.format(batch),
+                'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP32_MFMA_PEAK_TFLOPS,
+                'achieved': round(rnn_flops / (bwd_ms * 1e-3) / 1e12, 2) if bwd_ms else None,
+                'frac': round(rnn_flops / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                if bwd_ms else None,
+                'traffic': None, 'launches': bwd_calls,
+                'avg_launch_us': round(bwd_ms * 1e3 / max(bwd_calls, 1), 1),
+                'cus_occupied': 128,
+                'other_pass': {'kernel': 'prnn_fwd_kernel', 'launches': fwd_calls,
+                               'achieved': round(rnn_flops / (fwd_ms * 1e-3) / 1e12, 2)
+                               if fwd_ms else None}},
+        }
+    del trainer, model
+    torch.cuda.empty_cache()
+    return result
+
+
+# ------------------------------------------------------------------------------ parity probe
+PROBE_BATCH, PROBE_FRAMES, PROBE_LABEL_LEN = 2, 199, 30        # T' = 100
+
+
+def _probe_setup(cfg_kwargs):
+    """Model, parameters and inputs of the parity probe - deterministic, so that the GPU process
+    and the CPU child build the same thing independently."""
+    from ctc_asr_amd.model import ModelConfig, init_params
+    cfg = ModelConfig(**cfg_kwargs)
+    flat = init_params(cfg, 0)
+    rng = np.random.default_rng(2024)
+    for name in flat:       # the initialiser's biases are zero: give every term something to do
+        flat[name] = (flat[name] + rng.normal(size=flat[name].shape) * 0.01).astype(np.float32)
+    feats = rng.normal(size=(PROBE_BATCH, PROBE_FRAMES, 80)).astype(np.float32)
+    lengths = np.full(PROBE_BATCH, PROBE_FRAMES, dtype=np.int32)
+    labels = [[int(v) for v in rng.integers(1, 28, size=PROBE_LABEL_LEN)]
+              for _ in range(PROBE_BATCH)]
+    return cfg, flat, feats, lengths, labels
+
+
+def _parity_probe_worker(spec):
+    """Child process: the oracle's side of the probe (float64 torch restatement on the CPU)."""
+    from ctc_asr_amd.model import to_oracle_layout
+    from oracle import torch_ref
+    cfg, flat, feats, lengths, labels = _probe_setup(spec['cfg'])
+    torch.set_num_threads(spec['threads'])
+    ref = torch_ref.TorchRefModel(to_oracle_layout(flat, cfg), cfg.used_model, cfg.rnn_cell,
+                                  cfg.cudnn, dtype=torch.float64)
+    with torch.no_grad():
+        logits, seq_len = ref(torch.tensor(feats, dtype=torch.float64), lengths)
+        loss, _ = ref.loss(logits, seq_len, labels)
+    np.save(spec['logits_path'], logits.numpy())
+    print(json.dumps({'loss': float(loss)}))
+
+
+def parity_probe(cfg_kwargs, device, hard_limit_s=300.0):
+    """The second half of BASELINE.json's metric ("CTC loss delta vs ref"): one forward + CTC
+    loss of the workload's architecture on a small fixed batch (B = 2, T' = 100, seeded weights
+    and inputs, dropout off) on the GPU - through the same kernels as the timed steps - against
+    the oracle (``oracle/torch_ref.py`` in float64, in a child process on the host).  The oracle
+    is the checker here, outside the timed region."""
+    import tempfile
+    from ctc_asr_amd.model import CTCModel
+    cfg, flat, feats, lengths, labels = _probe_setup(cfg_kwargs)
+    model = CTCModel(cfg, device, params=flat)
+    logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(lengths), training=True)
+    loss = float(model.loss_fn(logits, seq_len, labels))
+    model.check_rnn_error()
+    got = logits.cpu().numpy()
+    del model
+    torch.cuda.empty_cache()
+    _, physical = host_cores()
+    with tempfile.TemporaryDirectory() as tmp:
+        spec = {'cfg': cfg_kwargs, 'threads': min(32, physical),
+                'logits_path': os.path.join(tmp, 'logits.npy')}
+        code = ('import json,sys; sys.path.insert(0, {!r}); import bench; '
+                'bench._parity_probe_worker(json.loads(sys.argv[1]))').format(ROOT)
+        try:
+            out = subprocess.run([sys.executable, '-c', code, json.dumps(spec)],
+                                 capture_output=True, text=True, timeout=hard_limit_s)
+            ref_loss = json.loads(out.stdout.strip().splitlines()[-1])['loss']
+            ref_logits = np.load(spec['logits_path'])
+        except Exception as err:
+            return {'ctc_loss_delta': None, 'logits_max_abs_delta': None,
+                    'note': 'oracle child failed: {}'.format(type(err).__name__)}
+    return {'ctc_loss_delta': abs(loss - ref_loss),
+            'logits_max_abs_delta': float(np.abs(got - ref_logits).max()),
+            'loss_gpu': loss, 'loss_oracle': ref_loss, 'tolerance': 1e-3,
+            'batch': PROBE_BATCH, 'ctc_steps': int(got.shape[0]),
+            'note': 'forward + CTC loss of this workload\'s architecture, seeded weights / inputs, '
+                    'dropout off, GPU fp32 vs oracle/torch_ref.py float64 on the host (checker, '
+                    'outside the timed region)'}
+
+
+def merge_release_modes(legs, stub):
+    """N > 1: fold the measurements of the release modes ({'held': line, 'early': line}) and of
+    the stubbed step into ONE result line - the better mode's line, with every mode's step time,
+    per-rank spread and exposed all-reduce time (= its step minus the stubbed step) under
+    ``allreduce.modes``."""
+    best = min(legs, key=lambda m: legs[m]['ms_per_step'])
+    result = legs[best]
+    result['allreduce']['modes'] = {
+        m: {'ms_per_step': leg['ms_per_step'], 'value': leg['value'],
+            'mode': leg['allreduce']['mode'],     # early falls back to held at H = 2048
+            'launches_per_step': leg['allreduce']['launches_per_step'],
+            'rank_ms_per_step': leg['allreduce']['rank_ms_per_step'],
+            'exposed_allreduce_ms': round(leg['ms_per_step'] - stub['ms_per_step'], 3)}
+        for m, leg in legs.items()}
+    result['allreduce']['chosen'] = best
+    result['allreduce']['stubbed_ms_per_step'] = stub['ms_per_step']
+    result['allreduce']['exposed_allreduce_ms'] = round(
+        result['ms_per_step'] - stub['ms_per_step'], 3)
+    return result
 
 
 def free_port():
@@ -432,6 +742,12 @@ def main():
                     help='dense_dropout_rate (reference default 0.1)')
     ap.add_argument('--rnn-bwd-whole-chip', action='store_true',
                     help='persistent backward recurrence on all 256 CUs (default: 128)')
+    ap.add_argument('--no-parity-probe', action='store_true',
+                    help='skip the CTC-loss / logits delta against the oracle (N = 1)')
+    ap.add_argument('--no-step-checks', action='store_true',
+                    help='train_step(check=False): without the deferred per-step error checks')
+    ap.add_argument('--c5-batches', type=int, default=24,
+                    help='bucketed batches in the C5 sequence of the default N = 1 run')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -473,13 +789,44 @@ def main():
             raise SystemExit('bench.py: ranks do not map to {} distinct GPUs: {}'.format(
                 world, devices))
 
-    result, (cfg, frames, batch, seconds) = measure(args.workload, args, rank, local_rank, world)
-    other = {}
+    def workload_cfg_kwargs(name):
+        filters, layers, hidden, dense, _, _, rnn_cell = WORKLOADS[name]
+        return dict(used_model='ds2', conv_filters=list(filters), num_units_dense=dense,
+                    num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell,
+                    cudnn=True, dense_dropout_rate=0.0)
+
+    other, exit_code = {}, 0
+    if args.workload == 'c5':
+        result = measure_c5(args, rank, local_rank, world)
+        cfg = frames = batch = seconds = None
+    elif world == 1:
+        result, (cfg, frames, batch, seconds) = measure(args.workload, args, rank, local_rank,
+                                                        world)
+    else:
+        # N > 1: the driver runs this once per N, so the run itself is the experiment - both
+        # release modes of the gradient buckets back to back (each: warm-up + K timed steps under
+        # the contract's protocol), then the same step with the collectives stubbed out.  `value`
+        # is the better mode's; everything measured is in `allreduce.modes`.
+        forced = os.environ.get('CTCASR_ALLREDUCE_EARLY')
+        legs = {}
+        for mode in (('early',) if forced == '1' else ('held',) if forced == '0'
+                     else ('held', 'early')):
+            legs[mode], shape = measure(args.workload, args, rank, local_rank, world,
+                                        allreduce_early=(mode == 'early'))
+        stub, _ = measure(args.workload, args, rank, local_rank, world, reduce=False)
+        cfg, frames, batch, seconds = shape
+        result = merge_release_modes(legs, stub) if rank == 0 else None
     if world == 1 and args.workload == 'c3' and not args.no_other_workloads:
         second, _ = measure('c2', args, rank, local_rank, world)
         other['c2'] = {k: second[k] for k in ('value', 'unit', 'ms_per_step', 'config',
                                               'step_tflops_fp32', 'frac_of_fp32_mfma_peak',
                                               'kernel_ms_per_step', 'roofline')}
+        c5_args = argparse.Namespace(**vars(args))
+        c5_args.steps = args.c5_batches
+        third = measure_c5(c5_args, rank, local_rank, world)
+        other['c5'] = {k: third[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'config',
+                                             'padded_audio_s_per_s', 'decode', 'roofline',
+                                             'host_enqueue_ms_per_step')}
     if rank == 0:
         if world > 1:
             result['allreduce']['ranks_seen_by_allreduce'] = ranks_seen
@@ -488,12 +835,18 @@ def main():
                 result['devices_shared'] = True      # not a measurement: plumbing check only
         if other:
             result['other_workloads'] = other
-        if world == 1 and not args.no_cpu_baseline:
-            filters, layers, hidden, dense, _, _, rnn_cell = WORKLOADS[args.workload]
-            cfg_kwargs = dict(used_model='ds2', conv_filters=list(filters), num_units_dense=dense,
-                              num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell,
-                              cudnn=True, dense_dropout_rate=0.0)
-            result['cpu_baseline'] = cpu_baseline(cfg_kwargs, batch, seconds, frames)
+        if world == 1 and not args.no_parity_probe:
+            # BASELINE.json's metric, second half: CTC loss (and logits) delta vs the oracle
+            probe = parity_probe(workload_cfg_kwargs(args.workload), 'cuda:{}'.format(local_rank))
+            result['ctc_loss_delta'] = probe['ctc_loss_delta']
+            result['logits_max_abs_delta'] = probe['logits_max_abs_delta']
+            result['parity_probe'] = probe
+            if probe['ctc_loss_delta'] is None or probe['ctc_loss_delta'] > 1e-3 or \
+                    probe['logits_max_abs_delta'] > 1e-3:
+                exit_code = 3                    # the line is printed, the run fails
+        if world == 1 and not args.no_cpu_baseline and args.workload != 'c5':
+            result['cpu_baseline'] = cpu_baseline(workload_cfg_kwargs(args.workload), batch,
+                                                  seconds, frames)
             if result['cpu_baseline']['value']:
                 result['gpu_over_cpu'] = round(result['value'] / result['cpu_baseline']['value'],
                                                1)
@@ -501,6 +854,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.stderr.write('bench.py: parity probe above the 1e-3 bar (see parity_probe).\n')
+        sys.exit(exit_code)
 
 
 if __name__ == '__main__':

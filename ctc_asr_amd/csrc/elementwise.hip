@@ -155,13 +155,6 @@ adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restric
     }
 }
 
-// One lane sleeps for `ticks` of the 100 MHz wall clock: a spacer for a side stream whose work
-// should not grab the chip in front of a persistent kernel that is about to start.
-__global__ void delay_kernel(unsigned long long ticks) {
-    const unsigned long long start = wall_clock64();
-    while (wall_clock64() - start < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
 int grid_for(int64_t work_items) {
     int64_t blocks = (work_items + 255) / 256;
     if (blocks > 2048) blocks = 2048;   // 256 CUs x 8, grid-stride the rest
@@ -233,13 +226,6 @@ extern "C" int ctcasr_dropout(const float *in, float *out, int64_t n, float drop
     if (n == 0) return CTCASR_OK;
     dropout_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(
         in, out, n, dropout_rate, 1.f / (1.f - dropout_rate), seed);
-    return ctcasr_launch_status();
-}
-
-extern "C" int ctcasr_stream_delay(int microseconds, ctcasr_stream_t stream) {
-    if (microseconds < 0 || microseconds > 100000) return CTCASR_ERR_BAD_ARGUMENT;
-    if (microseconds == 0) return CTCASR_OK;
-    delay_kernel<<<1, 64, 0, (hipStream_t)stream>>>((unsigned long long)microseconds * 100ull);
     return ctcasr_launch_status();
 }
 

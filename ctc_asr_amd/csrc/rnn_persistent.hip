@@ -67,6 +67,10 @@ struct SyncWords {
     unsigned pad[63];
     unsigned long long prof[16];   // CTCASR_RNN_PROF=1: per-phase 100 MHz ticks of workgroup 0
     unsigned long long prof_all[256][4];   // ... and of every workgroup (forward pass)
+    // residency hand-shake (ctcasr_rnn_resident_gate): workgroups of a launch that carries a
+    // ticket count themselves in at entry; the one that completes the grid posts the ticket
+    unsigned resident[PRNN_CNT_STRIDE];
+    unsigned resident_ticket[PRNN_CNT_STRIDE];
 };
 
 struct PArgs {
@@ -88,7 +92,9 @@ struct PArgs {
     int chain0;            // first batch tile of this launch
     int s_lo, s_hi;        // backward: this launch runs steps s_hi-1 ... s_lo (a whole pass: 0, T)
     float *carry;          // backward, LSTM: dc [2, B, H] handed from one launch to the next
+    float *rs;             // backward, reduce-scatter form: the exchange ring (prnn_rs_ring_bytes)
     int prof;              // record phase timings of workgroup 0
+    unsigned ticket;       // != 0: post it once every workgroup of this launch is running
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) {
@@ -263,6 +269,37 @@ __device__ __forceinline__ void counters_done(SyncWords *sy, int dir, int chain,
     }
 }
 
+// Residency hand-shake.  Work on another stream that should fill the CUs a persistent launch
+// leaves free (weight-gradient GEMMs beside the half-chip backward recurrence) must not get to
+// the chip first: the persistent kernel's workgroups would then wait for CUs until the first
+// GEMM has drained (measured: it starts 1.9 ms late).  Round 1/2 idled the side stream with a
+// timed spacer kernel (70-100 us, a guess that a kernel trace showed losing its race up to
+// 3.6 ms).  Now every workgroup of a launch that carries a ticket counts itself in when it
+// STARTS - by then it holds its CU - and the one that completes the grid posts the ticket; a
+// one-lane gate kernel on the other stream (ctcasr_rnn_resident_gate) waits for that ticket,
+// with a bound.  Tickets are 24-bit launch numbers chosen by the caller, compared modulo 2^24.
+__device__ __forceinline__ void resident_signal(SyncWords *sy, unsigned ticket) {
+    if (ticket == 0 || threadIdx.x != 0) return;
+    const unsigned before = __hip_atomic_fetch_add(&sy->resident[0], 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1 == gridDim.x) {
+        __hip_atomic_store(&sy->resident[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->resident_ticket[0], ticket, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void resident_gate_kernel(SyncWords *sy, unsigned ticket, unsigned long long ticks) {
+    const unsigned long long start = wall_clock64();
+    for (;;) {
+        const unsigned seen = __hip_atomic_load(&sy->resident_ticket[0], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        if (((seen - ticket) & 0xFFFFFFu) < 0x800000u) break;      // seen >= ticket (mod 2^24)
+        if (wall_clock64() - start >= ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward.  NT N-tiles of 16 gate columns per workgroup (cols = 16*NT = G * UPB), QW = 16-float
 // K chunks per wave (H = 64 * QW), MT = batch tiles of 16 rows.
@@ -286,6 +323,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     constexpr int QL = QS - REGW;        // ... of which in LDS
     constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
     float4 *frag = reinterpret_cast<float4 *>(smem);
     constexpr int RED_FLOATS = 4 * NT * MT * 16 * 17;
     // chain = batch tile with its own barrier (CHAINS = 2: waves 0-3 / 4-7); `tid` and `wave`
@@ -664,6 +702,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     // LDS + 256 registers per lane, which a one-wave-per-SIMD kernel can afford)
     static_assert(!TWO_TILES || (G == 1 && REGW > 0), "two tiles: plain RNN, static slot map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
     float4 *frag = reinterpret_cast<float4 *>(smem);
     constexpr int RED_FLOATS = 4 * NT * MT * 16 * 17;
     // chain = batch tile with its own barrier (see ChainSync); `tid` / `wave` count within it
@@ -1001,6 +1040,267 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
         for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// backward, REDUCE-SCATTER form (LSTM, H = 1024, 64 workgroups per direction = half the chip).
+//
+// prnn_bwd_kernel is an all-gather: a workgroup owns 16 output units j of dh = dgates x R and so
+// needs the dgates of ALL 4H gate columns of every row - 256 KB per 16-row tile and step, pulled
+// through a per-CU load path that delivers ~50 GB/s on freshly written data (10 of the 12.7 us
+// per step at B = 32).  Here the product is cut along K instead: a workgroup
+// keeps the 64 ROWS of R that belong to the gate columns of its OWN 16 units (the same 256 KB of
+// weights, as w_hh_t[j][g*H + u0 .. u0+16) fragments), so its A operand - the dgates it has just
+// computed, [16 rows x 64] - never leaves the CU (4 KB through LDS).  It multiplies them into a
+// partial dh [16 x 1024] = 64 MFMA tiles and writes tile jt (1 KB, accumulator layout, lane
+// linear) to the slot [consumer jt][producer = this workgroup] of an exchange ring.  After ONE
+// direction barrier the workgroup that owns units 16 jt .. 16 jt + 15 reads its 64 contiguous KB
+// (one tile from each producer; wave w sums producers 16 w .. 16 w + 15 in registers, the four
+// wave sums meet in LDS) and has dh for its units.  Per step and 16-row tile a CU reads 64 KB
+// and writes 64 KB instead of reading 256 KB; nothing is read twice, so there is nothing for an
+// L2 to share and the loads bypass it (sc1), which in turn allows the buffer to be a RING of two
+// steps (33.5 MB for both directions and tiles - it lives in the Infinity Cache) instead of one
+// block per time step: a workgroup that has passed the barrier of step s knows that every
+// workgroup has finished reading the partials of step s + 1, whose slot step s - 1 overwrites.
+// Same MFMA work as prnn_bwd_kernel (K = 64 per tile: 16 MFMAs, two tiles interleaved on two
+// accumulators), same barrier, one round trip per step.
+//
+// LDS: B fragments [4 waves][32 slots][64 lanes] float4 (128 KB; the other 32 slots of a wave
+// live in 128 registers), then per chain: partial sums [4][16][17], the A operand [16][68] and
+// the chain's sync words.
+// ---------------------------------------------------------------------------------------------
+#define PRNN_RS_H 1024
+#define PRNN_RS_NWG 64                  // workgroups per direction = consumers = producers
+#define PRNN_RS_QL 32                   // B-fragment slots per wave in LDS (of 64)
+#define PRNN_RS_APITCH 68               // floats per row of the A operand in LDS
+#define PRNN_RS_TILE_BYTES 1024u        // one 16 x 16 fp32 accumulator tile
+#define PRNN_RS_SLOT_BYTES ((size_t)2 * PRNN_MAX_CHAINS * PRNN_RS_NWG * PRNN_RS_NWG * 1024)
+#ifndef PRNN_RS_LOCK
+#define PRNN_RS_LOCK 1
+#endif
+// Two chains: the MFMA phases of the two batch tiles take turns.  Left alone the chains fall into
+// lockstep - both in their MFMA phase at once, each at half rate, then both in their exchange
+// phase with the matrix pipe idle (measured 11.9 us per step: 2 x 3.9 of MFMA + 4 of exchange).
+// With the pipe handed over explicitly one chain's exchange round trip (partial loads, gate
+// math, drain, barrier) runs under the other chain's MFMAs.
+struct MfmaTurn {           // in LDS, one per workgroup
+    unsigned lock;          // 1 while a chain is in its MFMA phase
+    unsigned done[2];       // waves of chain c that have finished MFMA phases (cumulative)
+    unsigned pad;
+};
+size_t prnn_rs_ring_bytes() { return 2 * PRNN_RS_SLOT_BYTES; }
+
+template <int CHAINS>
+__global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArgs p) {
+    constexpr int H = PRNN_RS_H, GH = 4 * H, NWG = PRNN_RS_NWG, QL = PRNN_RS_QL;
+    constexpr int JW = H / 16 / 4;          // j tiles (consumers) per wave: 16
+    constexpr int QS = JW * 4;              // B-fragment slots per wave: (tile, gate) pairs
+    constexpr int REGW = QS - QL;
+    constexpr int RED_FLOATS = 4 * 16 * 17, A_FLOATS = 16 * PRNN_RS_APITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    float4 *frag = reinterpret_cast<float4 *>(smem);
+    const int chain =
+        CHAINS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PRNN_THREADS)
+                   : p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
+    const int lchain = CHAINS > 1 ? chain : 0;
+    const int row0 = chain * 16;
+    char *chain_mem = smem + (size_t)4 * QL * 64 * sizeof(float4) +
+                      (size_t)lchain * ((RED_FLOATS + A_FLOATS) * sizeof(float) + 16);
+    float *red = reinterpret_cast<float *>(chain_mem);
+    float *dgs = red + RED_FLOATS;
+    ChainSync *cs = reinterpret_cast<ChainSync *>(dgs + A_FLOATS);
+    MfmaTurn *turn = reinterpret_cast<MfmaTurn *>(
+        smem + (size_t)4 * QL * 64 * sizeof(float4) +
+        (size_t)CHAINS * ((RED_FLOATS + A_FLOATS) * sizeof(float) + 16));
+    unsigned bar_epoch = 0, arrivals = 0;
+    if constexpr (CHAINS > 1 && !PRNN_RS_LOCK) {
+        if (chain == 0) __builtin_amdgcn_s_setprio(PRNN_CHAIN0_PRIO);
+    }
+    const int tid = threadIdx.x % PRNN_THREADS, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int B = p.B, T = p.T;
+    const int u0 = slice * 16;
+    if (CHAINS > 1 && threadIdx.x == 0) *turn = MfmaTurn{0u, {0u, 0u}, 0u};
+
+    // ---- this workgroup's 64 rows of R, as B fragments: slot (tile jl, gate q) of wave w holds
+    // R[n = q H + u0 + 4 (lane >> 4) + r][j = 16 (16 w + jl) + (lane & 15)], r = 0..3 - four
+    // consecutive floats of a row of w_hh_t
+    float4 wreg[REGW];
+    {
+        const float *wrow = p.w + ((size_t)dir * H + (size_t)wave * JW * 16 + (lane & 15)) * GH +
+                            u0 + 4 * (lane >> 4);
+        auto slot = [&](int sl) -> float4 {
+            return ldg4(wrow + (size_t)(sl >> 2) * 16 * GH + (size_t)(sl & 3) * H);
+        };
+        for (int sl = lchain; sl < QL; sl += CHAINS) frag[(wave * QL + sl) * 64 + lane] = slot(sl);
+#pragma unroll
+        for (int sl = 0; sl < REGW; ++sl) wreg[sl] = slot(QL + sl);
+    }
+    if (CHAINS > 1 && tid == 0) *cs = ChainSync{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // exchange ring [slot = step & 1][dir][tile chain][consumer][producer][1 KB]
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.rs, 0, (int)(2 * PRNN_RS_SLOT_BYTES), 0x00020000);
+    const unsigned x_dc = (unsigned)((dir * PRNN_MAX_CHAINS + chain) * NWG * NWG) *
+                          PRNN_RS_TILE_BYTES;
+    // read: my 64 tiles are contiguous, wave w takes producers 16 w .. 16 w + 15
+    const unsigned x_rd = x_dc + (unsigned)(slice * NWG + wave * 16) * PRNN_RS_TILE_BYTES +
+                          (unsigned)lane * 16u;
+    // write: tile of consumer 16 w + jl lands in that consumer's block at producer = slice
+    const unsigned x_wr = x_dc + (unsigned)((wave * JW) * NWG + slice) * PRNN_RS_TILE_BYTES +
+                          (unsigned)lane * 16u;
+
+    // ---- the item of this thread: row tid >> 4 of the tile, unit tid & 15 ----------------------
+    const int ib = tid >> 4, iu = tid & 15;
+    const int brow = row0 + ib, unit = u0 + iu;
+    const int steps = brow < B ? row_steps(p.seq_len, brow, T) : 0;
+    float dc_state = 0.f;
+    if (p.s_hi < T && brow < B) dc_state = p.carry[((size_t)dir * B + brow) * H + unit];
+
+    unsigned long long pt[5] = {0, 0, 0, 0, 0};
+    const bool prof = p.prof && tid == 0;       // thread 0 of every chain of every workgroup
+    for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
+        // everything the cell derivative needs except dh_rec: requested before the barrier
+        const bool running = s < steps;
+        const int t = running ? row_time(dir, s, steps) : 0;
+        float dyv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cv = 0.f, cpv = 0.f;
+        if (running) {
+            dyv = p.dy[((size_t)t * B + brow) * 2 * H + dir * H + unit];
+            const float *gr = p.gates + (((size_t)t * B + brow) * 2 + dir) * 4 * H + unit;
+            gi = gr[0]; gf = gr[H]; gg = gr[2 * H]; go = gr[3 * H];
+            cv = p.cells[(((size_t)t * B + brow) * 2 + dir) * H + unit];
+            if (s > 0)
+                cpv = p.cells[(((size_t)row_time(dir, s - 1, steps) * B + brow) * 2 + dir) * H +
+                              unit];
+        }
+
+        float dh = dyv;
+        if (s < T - 1) {
+            // partial dh of step s + 1 from every workgroup of this direction (the first step
+            // of a continued pass reads what the previous launch left: nothing to wait for)
+            if (s < p.s_hi - 1) {
+                dir_wait<CHAINS>(p.sync, cs, dir, chain, group_size, (unsigned)(p.s_hi - 2 - s),
+                                 tid);
+                if (s == p.s_lo && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
+            const unsigned rd = x_rd + (unsigned)((s + 1) & 1) * (unsigned)PRNN_RS_SLOT_BYTES;
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = load16_sc1<16>(x_rsrc, rd + (unsigned)i * PRNN_RS_TILE_BYTES);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i].x += v[i + 8].x; v[i].y += v[i + 8].y;
+                v[i].z += v[i + 8].z; v[i].w += v[i + 8].w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i].x += v[i + 4].x; v[i].y += v[i + 4].y;
+                v[i].z += v[i + 4].z; v[i].w += v[i + 4].w;
+            }
+            const float4 sum = make_float4((v[0].x + v[2].x) + (v[1].x + v[3].x),
+                                           (v[0].y + v[2].y) + (v[1].y + v[3].y),
+                                           (v[0].z + v[2].z) + (v[1].z + v[3].z),
+                                           (v[0].w + v[2].w) + (v[1].w + v[3].w));
+            // accumulator layout: lane holds rows 4 (lane >> 4) + r of column lane & 15
+            float *rw = red + (wave * 16 + 4 * (lane >> 4)) * 17 + (lane & 15);
+            rw[0] = sum.x; rw[17] = sum.y; rw[34] = sum.z; rw[51] = sum.w;
+            if constexpr (CHAINS == 1) __syncthreads();
+            else chain_barrier(cs, bar_epoch, lane);
+            dh += (red[(0 * 16 + ib) * 17 + iu] + red[(1 * 16 + ib) * 17 + iu]) +
+                  (red[(2 * 16 + ib) * 17 + iu] + red[(3 * 16 + ib) * 17 + iu]);
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c; }
+
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (running) {
+            const float tc = tanhf_(cv);
+            const float dc = dc_state + dh * go * (1.f - tc * tc);
+            dg[0] = dc * gg * gi * (1.f - gi);
+            dg[1] = dc * cpv * gf * (1.f - gf);
+            dg[2] = dc * gi * (1.f - gg * gg);
+            dg[3] = dh * tc * go * (1.f - go);
+            dc_state = dc * gf;
+        }
+        // dh of step s - 1 needs these dgates x R; step 0 has nobody to hand them to
+        if (s > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgs[ib * PRNN_RS_APITCH + g * 16 + iu] = dg[g];
+            if constexpr (CHAINS == 1) {
+                __syncthreads();
+            } else {
+                if (PRNN_RS_LOCK && tid == 0) {         // take the matrix pipe for this chain
+                    unsigned expected = 0u;
+                    while (!__hip_atomic_compare_exchange_strong(
+                        &turn->lock, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        expected = 0u;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                chain_barrier(cs, bar_epoch, lane);
+                if (PRNN_RS_LOCK) __builtin_amdgcn_s_setprio(2);
+            }
+            float4 a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                a[q] = *reinterpret_cast<const float4 *>(
+                    dgs + (lane & 15) * PRNN_RS_APITCH + 16 * q + 4 * (lane >> 4));
+            if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
+            auto bfrag = [&](int sl) -> float4 {        // compile-time slot after unrolling
+                return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+            };
+            const unsigned wr = x_wr + (unsigned)(s & 1) * (unsigned)PRNN_RS_SLOT_BYTES;
+#pragma unroll
+            for (int jp = 0; jp < JW; jp += 2) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mma4x2(acc0, acc1, a[q], bfrag(jp * 4 + q), a[q], bfrag((jp + 1) * 4 + q));
+                store16_sc1(x_rsrc, wr + (unsigned)(jp * NWG) * PRNN_RS_TILE_BYTES,
+                            acc0[0], acc0[1], acc0[2], acc0[3]);
+                store16_sc1(x_rsrc, wr + (unsigned)((jp + 1) * NWG) * PRNN_RS_TILE_BYTES,
+                            acc1[0], acc1[1], acc1[2], acc1[3]);
+            }
+            if constexpr (CHAINS > 1 && PRNN_RS_LOCK) {
+                // the last of the chain's four waves through its MFMAs hands the pipe over
+                __builtin_amdgcn_s_setprio(0);
+                if (lane == 0) {
+                    const unsigned before = __hip_atomic_fetch_add(
+                        &turn->done[lchain], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((before & 3u) == 3u)
+                        __hip_atomic_store(&turn->lock, 0u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+            if (s > p.s_lo) dir_arrive<CHAINS>(p.sync, cs, dir, chain, grp, tid, arrivals);
+        }
+        // dxw in its GEMM layout: read after the launch only
+        if (running) {
+            float *dx = p.dxw + (((size_t)t * B + brow) * 2 + dir) * GH + unit;
+            dx[0] = dg[0]; dx[H] = dg[1]; dx[2 * H] = dg[2]; dx[3 * H] = dg[3];
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[4] += c - c0; c0 = c; }
+    }
+    if (p.s_lo > 0 && brow < B) p.carry[((size_t)dir * B + brow) * H + unit] = dc_state;
+    if (prof) {
+        if (blockIdx.x == 0 && lchain == 0)
+            for (int i = 0; i < 5; ++i) p.sync->prof[4 + i] = pt[i];
+        // every (workgroup, chain): wait | partial loads + sum | gates + MFMA + publish | drain
+        const int slot = (int)(blockIdx.x * CHAINS + lchain) & 255;
+        p.sync->prof_all[slot][0] = pt[0];
+        p.sync->prof_all[slot][1] = pt[1];
+        p.sync->prof_all[slot][2] = pt[2] + pt[3];
+        p.sync->prof_all[slot][3] = pt[4];
+    }
+}
+
 int device_cu_count() {
     static int cus = -1;
     if (cus < 0) {
@@ -1103,8 +1403,13 @@ extern "C" int ctcasr_set_option(const char *name, int value) {
     return CTCASR_ERR_BAD_ARGUMENT;
 }
 
-size_t prnn_exchange_bytes(int T, int B, int H, int G) {
+static size_t prnn_step_exchange_bytes(int T, int B, int H, int G) {
     return ctcasr_align_up((size_t)(T + 1) * 2 * B * G * H * sizeof(float), 256);
+}
+// the per-step blocks, then (LSTM, H = 1024) the ring of the reduce-scatter backward kernel
+size_t prnn_exchange_bytes(int T, int B, int H, int G) {
+    return prnn_step_exchange_bytes(T, B, H, G) +
+           (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() : 0);
 }
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
@@ -1123,6 +1428,7 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
     p.T = T; p.B = B; p.H = H;
     p.s_lo = step_begin; p.s_hi = step_end;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
+    p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
     if (seq_len && step_begin == 0 && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
@@ -1207,6 +1513,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
+    p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
     const int gates_k = cell == CTCASR_CELL_LSTM ? 4 : (cell == CTCASR_CELL_GRU ? 3 : 1);
     if (seq_len && step_end == T &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * gates_k * H * sizeof(float), s) != hipSuccess)
@@ -1270,6 +1577,16 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
             }
         return CTCASR_OK;
     }
+    if (cell == CTCASR_CELL_LSTM && H == PRNN_RS_H && (flags & CTCASR_RNN_REDUCE_SCATTER)) {
+        // reduce-scatter form: 64 workgroups per direction, two chains per workgroup for B > 16
+        p.nwg = PRNN_RS_NWG;
+        p.rs = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xchg) +
+                                         prnn_step_exchange_bytes(T, B, H, 4));
+        const size_t per_chain = (size_t)(4 * 16 * 17 + 16 * PRNN_RS_APITCH) * 4 + 16;
+        const size_t lds = (size_t)4 * PRNN_RS_QL * 64 * 16 + 16;     // + MfmaTurn
+        if (mt == 2) return launch_persistent(prnn_bwd_rs_kernel<2>, p, lds + 2 * per_chain, s, 2);
+        return launch_persistent(prnn_bwd_rs_kernel<1>, p, lds + per_chain, s, 1);
+    }
     if (cell == CTCASR_CELL_LSTM) {
         if (chains && !half_chip) {
             p.nwg = H / 16;
@@ -1315,12 +1632,18 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
 
 size_t prnn_error_offset() { return offsetof(SyncWords, error); }
 
+int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t s) {
+    resident_gate_kernel<<<1, 1, 0, s>>>(reinterpret_cast<SyncWords *>(sync), ticket & 0xFFFFFFu,
+                                         (unsigned long long)max_wait_us * 100ull);
+    return ctcasr_launch_status();
+}
+
 // Which non-default tuning / probe macros this library was compiled with (include/ctcasr.h).
 extern "C" unsigned ctcasr_build_flags(void) {
     unsigned flags = 0;
     if (PRNN_PROBE_HALF_LOADS) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
-        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1)
+        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

@@ -282,6 +282,7 @@ int cell_gates(int cell) {
 extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
 size_t prnn_sync_bytes();
 size_t prnn_error_offset();
+int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t s);
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
              const float *b_hh_n, const int32_t *seq_len, int T, int B, int H, float *y,
@@ -333,7 +334,8 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_b
                                     int flags, ctcasr_stream_t stream) {
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
-    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER))
+    if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
+                         CTCASR_RNN_REDUCE_SCATTER))
         return CTCASR_ERR_BAD_ARGUMENT;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
@@ -394,7 +396,8 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     (void)b_hh_n; (void)db_hh_n;   // the GRU bias gradient is the column sum of drec (caller)
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
-    if (flags & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER))
+    if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
+                         CTCASR_RNN_REDUCE_SCATTER))
         return CTCASR_ERR_BAD_ARGUMENT;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
@@ -464,6 +467,21 @@ extern "C" int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, in
                          prnn_sync_bytes()) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     return err ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
+}
+
+// Enqueue a one-lane gate on `stream` that returns once the persistent launch carrying `ticket`
+// (CTCASR_RNN_TICKET(ticket) in its `flags`) on this workspace has ALL its workgroups running,
+// or after `max_wait_us`.  Shapes that take the streaming kernels: no-op.
+extern "C" int ctcasr_rnn_resident_gate(void *workspace, size_t workspace_bytes, int cell, int T,
+                                        int B, int H, unsigned ticket, int max_wait_us,
+                                        ctcasr_stream_t stream) {
+    if (max_wait_us < 0 || max_wait_us > 100000 || ticket == 0 || ticket > 0xFFFFFFu)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
+        return CTCASR_ERR_WORKSPACE;
+    if (!ctcasr_rnn_persistent_supported(cell, T, B, H) || max_wait_us == 0) return CTCASR_OK;
+    return prnn_resident_gate(reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), ticket,
+                              max_wait_us, (hipStream_t)stream);
 }
 
 // GRU only: byte offset inside `reserve` of drec [T, B, 2, 3H] - the gradient w.r.t. the

@@ -14,9 +14,10 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libctcasr.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 BUILD_PROBE_WRONG_RESULTS, BUILD_NONDEFAULT_TUNING = 1, 2      # ctcasr_build_flags() bits
 RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP, RNN_ONE_BARRIER = 0, 1, 2, 4   # rnn_fwd/bwd `flags`
+RNN_REDUCE_SCATTER = 8
 CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
 CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}
 
@@ -42,6 +43,8 @@ SIGNATURES = {
     'ctcasr_rnn_workspace_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_rnn_persistent_supported': (_c_int, [_c_int] * 4),
     'ctcasr_rnn_poll_error': (_c_int, [_c_p, _c_sz] + [_c_int] * 4 + [_c_p]),
+    'ctcasr_rnn_resident_gate': (_c_int, [_c_p, _c_sz] + [_c_int] * 4 + [ctypes.c_uint, _c_int,
+                                                                          _c_p]),
     'ctcasr_rnn_gru_drec_offset': (_c_sz, [_c_int] * 3),
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
@@ -62,7 +65,6 @@ SIGNATURES = {
     'ctcasr_conv0_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     'ctcasr_conv0_wrw_workspace_bytes': (_c_sz, [_c_int, _c_int]),
     'ctcasr_conv0_wrw': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_sz, _c_p]),
-    'ctcasr_stream_delay': (_c_int, [_c_int, _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
@@ -306,6 +308,17 @@ def rnn_poll_error(cell, workspace, num_steps, batch, hidden):
                                         hidden, _stream()), 'rnn persistent kernel')
 
 
+@_on_tensor_device
+def rnn_resident_gate(cell, workspace, num_steps, batch, hidden, ticket, max_wait_us=200):
+    """Make the CURRENT stream wait (bounded) until the persistent launch carrying ``ticket``
+    (``rnn_fwd`` / ``rnn_bwd(..., ticket=...)``) on ``workspace`` has all its workgroups running:
+    work enqueued behind the gate cannot take the CUs that launch needs."""
+    _check(load().ctcasr_rnn_resident_gate(_dev(workspace, torch.uint8, 'workspace'),
+                                           workspace.numel(), CELL_IDS[cell], num_steps, batch,
+                                           hidden, int(ticket), int(max_wait_us), _stream()),
+           'rnn_resident_gate')
+
+
 def rnn_gru_drec(reserve, num_steps, batch, hidden):
     """View of drec f32[T, B, 2, 3H] inside a GRU reserve (valid after `rnn_bwd`)."""
     start = load().ctcasr_rnn_gru_drec_offset(num_steps, batch, hidden)
@@ -324,14 +337,15 @@ def rnn_workspace(cell, num_steps, batch, hidden, device):
 
 @_on_tensor_device
 def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None,
-            steps=None, flags=RNN_DEFAULT, xw_bias=None):
+            steps=None, flags=RNN_DEFAULT, xw_bias=None, ticket=0):
     """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace).
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_fwd_steps`): cut
     a pass into calls covering 0..T in ascending order, passing the same ``y``, ``reserve`` and
     ``workspace`` to each.  ``flags``: RNN_DEFAULT / RNN_HALF_CHIP / RNN_WHOLE_CHIP (which
     variant of the persistent kernel runs - a per-call choice, no process-wide state).
-    ``xw_bias`` f32[2*G*H] (optional) is added to xw inside the kernel."""
+    ``xw_bias`` f32[2*G*H] (optional) is added to xw inside the kernel.  ``ticket`` (1..2^24-1):
+    the persistent launch posts it once all its workgroups run (`rnn_resident_gate`)."""
     num_steps, batch = xw.shape[0], xw.shape[1]
     hidden = w_hh.shape[2]
     dev = xw.device
@@ -351,13 +365,14 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
         _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
         _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
         _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
-        workspace.numel(), int(begin), int(end), int(flags), _stream()), 'rnn_fwd')
+        workspace.numel(), int(begin), int(end), int(flags) | (int(ticket) & 0xFFFFFF) << 8,
+        _stream()), 'rnn_fwd')
     return y, reserve, workspace
 
 
 @_on_tensor_device
 def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, db_hh_n=None,
-            workspace=None, steps=None, flags=RNN_DEFAULT):
+            workspace=None, steps=None, flags=RNN_DEFAULT, ticket=0):
     """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H].
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_bwd_steps`): cut
@@ -381,7 +396,8 @@ def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, d
         _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
         hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),
         _dev(db_hh_n, name='db_hh_n'), _dev(workspace, torch.uint8, 'workspace'),
-        workspace.numel(), int(begin), int(end), int(flags), _stream()), 'rnn_bwd')
+        workspace.numel(), int(begin), int(end), int(flags) | (int(ticket) & 0xFFFFFF) << 8,
+        _stream()), 'rnn_bwd')
     return dxw
 
 
@@ -545,12 +561,6 @@ def conv0_wrw(dz, x, out=None):
                                        _dev(workspace, torch.uint8, 'workspace'),
                                        workspace.numel(), _stream()), 'conv0_wrw')
     return out
-
-
-@_on_tensor_device
-def stream_delay(microseconds):
-    """Idle the current stream for ``microseconds`` (a one-lane spacer kernel)."""
-    _check(load().ctcasr_stream_delay(int(microseconds), _stream()), 'stream_delay')
 
 
 @_on_tensor_device

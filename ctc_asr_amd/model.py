@@ -317,7 +317,12 @@ class CTCModel:
         # (forward, data gradient, kernel gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
         self._conv_packed = {}          # layer -> fragment-ordered weight copies
-        self.side_head_start_us = int(os.environ.get('CTCASR_SIDE_DELAY_US', '70'))
+        # Side-stream work that should run BESIDE a half-chip persistent recurrence launch waits
+        # behind a residency gate: the launch posts a ticket once all its workgroups hold their
+        # CUs, a one-lane gate kernel on the side stream waits for it (at most this long; 0
+        # disables the gates)
+        self.side_gate_max_us = int(os.environ.get('CTCASR_SIDE_GATE_US', '300'))
+        self._ticket = 0
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
         # launch has finished run beside the next launch instead of queueing up behind the layer.
         # 0 = by batch: 2 launches up to 16 rows (C2: 22.8 ms per step against 23.1 with 3), 3
@@ -330,13 +335,29 @@ class CTCModel:
         self.early_hooks = False        # see backward(); set by engine.Trainer
         # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
         # other half of the chip runs the weight-gradient GEMMs of the layer above
-        self.rnn_bwd_flags = hip.RNN_DEFAULT
+        self.rnn_bwd_flags = int(os.environ.get('CTCASR_RNN_BWD_FLAGS', str(hip.RNN_DEFAULT)))
         self._rnn_ws = {}               # (cell, B, H) -> (zero-initialised workspace, T')
         self.dropout_seed = int(seed) * 0x9E3779B1 + 1
         self._acts = None
         self._w_hh_t = [torch.empty((2, cfg.num_units_rnn, GATES[cfg.cell] * cfg.num_units_rnn),
                                     dtype=torch.float32, device=self.device)
                         for _ in range(cfg.num_layers_rnn)]
+
+    # ------------------------------------------------------------------ residency tickets
+    def _upcoming_ticket(self):
+        """The ticket the NEXT persistent launch of this model will carry."""
+        return self._ticket % 0xFFFFFF + 1
+
+    def _take_ticket(self):
+        self._ticket = self._upcoming_ticket()
+        return self._ticket
+
+    def _gate_side_stream(self, cell, workspace, t_out, batch, hidden):
+        """With the side stream current: hold it until the next persistent launch (enqueued on
+        the main stream right after this call) has all its workgroups running."""
+        if self.side_gate_max_us > 0:
+            hip.rnn_resident_gate(cell, workspace, t_out, batch, hidden, self._upcoming_ticket(),
+                                  self.side_gate_max_us)
 
     # ------------------------------------------------------------------ forward
     def _next_seed(self):
@@ -560,13 +581,14 @@ class CTCModel:
             lo, hi = bounds[c], bounds[c + 1]
             hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
                         reserve=reserve, workspace=workspace, steps=(lo, hi),
-                        flags=hip.RNN_HALF_CHIP, xw_bias=bias_here)
+                        flags=hip.RNN_HALF_CHIP, xw_bias=bias_here, ticket=self._take_ticket())
             if c + 1 < chunks:
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    hip.stream_delay(self.side_head_start_us)
+                    # these GEMMs run beside launch c + 1: let it take its 128 CUs first
+                    self._gate_side_stream(cell, workspace, t_out, batch, hidden)
                     contribute(c)
             else:
                 main.wait_stream(side)
@@ -698,13 +720,17 @@ class CTCModel:
                           hip.rnn_persistent_supported(cfg.cell, acts['t_out'], acts['batch'],
                                                        cfg.num_units_rnn))
 
-        def on_side(tensors, fn, head_start_us=0, beside_recurrence=True):
+        persistent = hip.rnn_persistent_supported(cfg.cell, acts['t_out'], acts['batch'],
+                                                  cfg.num_units_rnn)
+
+        def on_side(tensors, fn, gate=False, beside_recurrence=True):
             """Run ``fn`` (weight-gradient work that nothing downstream in this backward pass
             reads) on the side stream once everything enqueued on the main stream so far is done.
-            ``head_start_us`` idles the side stream first so that a persistent recurrence kernel
-            enqueued next on the main stream claims its 128 CUs before these GEMMs fill the chip
-            (otherwise it starts only when the first GEMM has drained).  ``beside_recurrence``:
-            the work would run while a recurrence launch is on the main stream."""
+            ``gate``: a persistent recurrence launch is enqueued next on the main stream; the
+            side stream waits until its workgroups hold their 128 CUs before these GEMMs fill the
+            chip (otherwise the recurrence starts only when the first GEMM has drained).
+            ``beside_recurrence``: the work would run while a recurrence launch is on the main
+            stream."""
             if side is main or (whole_chip_rnn and beside_recurrence):
                 fn()
                 return
@@ -712,8 +738,9 @@ class CTCModel:
             ready.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                if head_start_us:
-                    hip.stream_delay(head_start_us)
+                if gate and persistent:
+                    self._gate_side_stream(cfg.cell, acts['rnn_ws'], acts['t_out'], acts['batch'],
+                                           cfg.num_units_rnn)
                 fn()
             for tensor in tensors:       # blocks stay reserved until the side stream is done
                 tensor.record_stream(side)
@@ -741,7 +768,7 @@ class CTCModel:
             if early:
                 done('dense4')
 
-        on_side([dz], dense4_weight_grad, head_start_us=self.side_head_start_us)
+        on_side([dz], dense4_weight_grad, gate=True)
         if not early:
             deferred.append('dense4')
 
@@ -792,10 +819,12 @@ class CTCModel:
             for c in range(chunks):
                 hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
                             dxw=dxw, workspace=acts['rnn_ws'], steps=(bounds[c + 1], bounds[c]),
-                            flags=self.rnn_bwd_flags)
+                            flags=self.rnn_bwd_flags,
+                            ticket=self._take_ticket() if persistent and not whole_chip_rnn
+                            else 0)
                 if c + 1 < chunks:
                     on_side([dxw], lambda lo=bounds[c + 1], hi=bounds[c]:
-                            partial_weight_grads(lo, hi), head_start_us=self.side_head_start_us)
+                            partial_weight_grads(lo, hi), gate=True)
             dxw2d = dxw.view(rows, 2 * gates * hidden)
             # critical path: the gradient w.r.t. this layer's input feeds the layer below
             dy_below = None
@@ -837,9 +866,7 @@ class CTCModel:
                 if early:
                     done(name)
 
-            on_side([dxw], layer_weight_grads,
-                    head_start_us=self.side_head_start_us if i > 0 else 0,
-                    beside_recurrence=i > 0)
+            on_side([dxw], layer_weight_grads, gate=i > 0, beside_recurrence=i > 0)
             if not early:
                 deferred.append(name)
             if dy_below is not None:

@@ -54,9 +54,18 @@ def write_corpus(corpus_dir, csv_path, durations, seed=1234, sampling_rate=16000
     return rows
 
 
-def librispeech_like_durations(rng, count, low=0.7, high=17.0):
-    """Log-normal utterance lengths clipped to the reference's [0.7, 17] s corpus filter."""
-    return np.clip(rng.lognormal(mean=2.35, sigma=0.45, size=count), low, high)
+def librispeech_like_durations(rng, count, low=0.7, high=17.0, drop=False):
+    """Log-normal utterance lengths (median 10.5 s) within the reference's [0.7, 17] s corpus
+    filter (``asr/params.py:142-143``): clipped to it, or - ``drop=True``, what a corpus filter
+    does - drawn again until inside it (no pile of utterances at exactly 17 s)."""
+    out = rng.lognormal(mean=2.35, sigma=0.45, size=count)
+    if not drop:
+        return np.clip(out, low, high)
+    bad = (out < low) | (out > high)
+    while bad.any():
+        out[bad] = rng.lognormal(mean=2.35, sigma=0.45, size=int(bad.sum()))
+        bad = (out < low) | (out > high)
+    return out
 
 
 def synthetic_batch(batch, seconds, seed=1234, chars_per_second=15.0, num_features=80,

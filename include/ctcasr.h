@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTCASR_ABI_VERSION 2
+#define CTCASR_ABI_VERSION 3
 
 enum {
     CTCASR_OK = 0,
@@ -166,6 +166,17 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
 /* batches of 17..32 rows: the round-1 kernels (both 16-row tiles behind ONE barrier per step)
  * instead of the default two independent chains per workgroup - for A/B measurements */
 #define CTCASR_RNN_ONE_BARRIER 4
+/* backward, LSTM with H = 1024: the reduce-scatter form of the recurrence (every workgroup
+ * multiplies the dgates of its OWN units into partial dh tiles for all units, consumers sum 64
+ * tiles) instead of the all-gather form (every workgroup reads the dgates of all units) */
+#define CTCASR_RNN_REDUCE_SCATTER 8
+/* Residency ticket (bits 8..31 of `flags`, 0 = none): a persistent launch that carries one posts
+ * it in the workspace once ALL of its workgroups are running; ctcasr_rnn_resident_gate() makes
+ * another stream wait for exactly that (bounded).  Use: work for the CUs a half-chip launch
+ * leaves free is enqueued behind such a gate, so that it cannot occupy the chip first and make
+ * the persistent kernel wait for CUs.  Tickets are caller-chosen launch numbers in 1..2^24-1,
+ * increasing per workspace, compared modulo 2^24.  (ABI v3; replaces ctcasr_stream_delay.) */
+#define CTCASR_RNN_TICKET(ticket) ((int)(((unsigned)(ticket) & 0xFFFFFFu) << 8))
 int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_bias, const float *w_hh,
                          const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                          float *y, void *reserve, void *workspace, size_t workspace_bytes,
@@ -179,6 +190,12 @@ int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
  * is cleared by this call. */
 int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, int cell, int T, int B,
                           int H, ctcasr_stream_t stream);
+/* Enqueues a one-lane gate kernel on `stream` that returns as soon as the persistent launch that
+ * carries CTCASR_RNN_TICKET(ticket) on this workspace has every workgroup running (or a later
+ * ticket has been posted), and after `max_wait_us` (<= 100 ms) at the latest.  No-op for shapes
+ * that take the streaming kernels. */
+int ctcasr_rnn_resident_gate(void *workspace, size_t workspace_bytes, int cell, int T, int B,
+                             int H, unsigned ticket, int max_wait_us, ctcasr_stream_t stream);
 int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                    const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                    const void *reserve, float *dxw, float *db_hh_n, void *workspace,
@@ -255,10 +272,6 @@ int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y
 size_t ctcasr_conv0_wrw_workspace_bytes(int B, int T);
 int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T, void *workspace,
                      size_t workspace_bytes, ctcasr_stream_t stream);
-
-/* Enqueues a one-lane kernel that idles for `microseconds` (<= 100 ms): used to let the persistent
- * recurrence of the main stream claim its half of the chip before side-stream GEMMs start. */
-int ctcasr_stream_delay(int microseconds, ctcasr_stream_t stream);
 
 /* out[n][c][r] = in[n][r][c] for n < batch (weight re-layouts, e.g. w_hh -> w_hh_t). */
 int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,

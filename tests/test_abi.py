@@ -45,7 +45,7 @@ def test_host_helper_library_exports_its_header(lib):
 
 
 def test_version_and_error_strings(lib):
-    assert lib.ctcasr_abi_version() == 2
+    assert lib.ctcasr_abi_version() == 3
     assert lib.ctcasr_error_string(0) == b'ok'
     assert b'workspace' in lib.ctcasr_error_string(-3)
     assert lib.ctcasr_error_string(-5) == b'in-kernel wait timed out'
@@ -60,6 +60,11 @@ def test_argument_errors_are_reported_not_thrown(lib):
     # unknown flag bits of the step-range entry points are an argument error
     assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
                                     0, 0, 8, 64, None) == -1
+    # ... the upper 24 bits are the residency ticket, not variant flags
+    assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
+                                    0, 0, 8, 5 << 8, None) == -1      # (null pointers, not flags)
+    assert lib.ctcasr_rnn_resident_gate(None, 0, 2, 8, 2, 1024, 1, 200, None) == -3
+    assert lib.ctcasr_rnn_resident_gate(None, 0, 2, 8, 2, 1024, 0, 200, None) == -1
     # the only process-wide option is the profiling switch
     assert lib.ctcasr_set_option(b'rnn_fwd_half_chip', 1) == -1
     assert lib.ctcasr_set_option(b'rnn_kernel_events', 0) == 0

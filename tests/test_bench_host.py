@@ -47,3 +47,43 @@ def test_pmc_traffic_lookup_reports_the_reason_when_absent(tmp_path, monkeypatch
     assert got['traffic_raw'] == 1500 * 1024 and got['traffic'] == 2500 * 1024
     assert got['traffic_over_algorithmic'] == 2.5
     assert bench.pmc_traffic('c3', 'rnn_bwd', 500)['traffic'] is None
+
+
+def test_release_modes_are_folded_into_one_line():
+    """N > 1: bench.py measures the held and the early release of the gradient buckets and the
+    stubbed step back to back; the printed line is the better mode's and carries all three."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def leg(mode, ms, value):
+        return {'ms_per_step': ms, 'value': value, 'allreduce': {
+            'mode': mode, 'launches_per_step': 9.0,
+            'rank_ms_per_step': {'min': ms - 0.5, 'max': ms, 'all': [ms - 0.5, ms]}}}
+
+    line = bench.merge_release_modes({'held': leg('held', 101.0, 6336.6),
+                                      'early': leg('early', 99.5, 6432.2)},
+                                     {'ms_per_step': 98.25})
+    assert line['value'] == 6432.2 and line['allreduce']['chosen'] == 'early'
+    modes = line['allreduce']['modes']
+    assert set(modes) == {'held', 'early'}
+    assert modes['held']['exposed_allreduce_ms'] == 2.75
+    assert modes['early']['exposed_allreduce_ms'] == 1.25
+    assert line['allreduce']['exposed_allreduce_ms'] == 1.25
+    assert line['allreduce']['stubbed_ms_per_step'] == 98.25
+    assert modes['early']['rank_ms_per_step']['min'] == 99.0
+
+
+def test_c5_bucket_sequence_is_fixed_and_bucketed():
+    """The C5 workload's batches: seeded (the same sequence every run), every batch from ONE
+    bucket (its utterances differ by well under a second), lengths inside the corpus filter."""
+    sys.path.insert(0, ROOT)
+    import bench
+    first = bench.c5_bucket_sequence(16, 12)
+    again = bench.c5_bucket_sequence(16, 12)
+    assert len(first) == 12 and all((a == b).all() for a, b in zip(first, again))
+    for samples in first:
+        assert samples.shape == (16,) and samples.min() >= 0.7 * 16000
+        assert samples.max() <= 17.0 * 16000
+        assert (samples.max() - samples.min()) / 16000.0 < 1.0
+    longest = [int(s.max()) for s in first]
+    assert max(longest) > 2 * min(longest)           # the padded length really varies

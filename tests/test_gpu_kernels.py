@@ -533,3 +533,45 @@ def test_beam_search_random_sweep_against_the_oracle(hip):
             assert np.allclose(logp.cpu().numpy(), ref_logp, rtol=1e-5, atol=1e-3)
             cases += 1
     assert cases == 27
+
+
+@pytest.mark.parametrize('batch,lengths', [(3, False), (16, True), (19, True), (32, False),
+                                           (32, True)])
+def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengths):
+    """`RNN_REDUCE_SCATTER`: the LSTM-1024 backward recurrence with the product dgates x R cut
+    along K (every workgroup multiplies the dgates of its OWN units into a partial dh for all
+    units, consumers sum 64 partial tiles) against the default kernels (all-gather of dgates,
+    themselves checked against float64 autograd in `test_rnn_fwd_bwd`): same results to fp32
+    summation order, deterministic, bit-identical when cut into step ranges; one batch tile
+    (one chain) and two (two chains per workgroup), with and without per-row lengths."""
+    num_steps, hidden = 37, 1024
+    gen = torch.Generator(device=DEV).manual_seed(100 + batch)
+    xw = torch.randn(num_steps, batch, 2, 4 * hidden, device=DEV, generator=gen) * 0.5
+    w_hh = torch.randn(2, 4 * hidden, hidden, device=DEV, generator=gen) / 32
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=gen)
+    seq_len = None
+    if lengths:
+        seq_len = torch.randint(1, num_steps + 1, (batch,), device=DEV, generator=gen,
+                                dtype=torch.int32)
+        seq_len[0] = num_steps
+        seq_len[batch - 1] = 1
+    assert hip.rnn_persistent_supported('lstm', num_steps, batch, hidden)
+    w_hh_t = hip.transpose_batched(w_hh)
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh, seq_len)
+    ref = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws)
+    got = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws,
+                      flags=hip.RNN_REDUCE_SCATTER)
+    again = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws,
+                        flags=hip.RNN_REDUCE_SCATTER)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    assert torch.equal(got, again)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) < 2e-5 * scale
+    if seq_len is not None:       # steps past a row's length carry no gradient
+        assert float(got[1:, batch - 1].abs().max()) == 0.0
+    cut = torch.empty_like(got)
+    for hi, lo in ((37, 20), (20, 19), (19, 7), (7, 0)):
+        hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, dxw=cut, workspace=ws,
+                    steps=(lo, hi), flags=hip.RNN_REDUCE_SCATTER)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    assert torch.equal(cut, got)

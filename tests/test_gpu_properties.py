@@ -98,32 +98,53 @@ def test_beam_search_is_consistent_with_the_ctc_loss(hip):
     assert (logp <= exact + 1e-2).all() and float((exact - logp).max()) < 0.5   # 3 nats above
 
 
-@pytest.mark.parametrize('cell,hidden,batch', [('lstm', 1024, 16), ('lstm', 1024, 32),
-                                               ('rnn_relu', 2048, 16)])
-def test_recurrence_full_size_symmetries(hip, cell, hidden, batch):
-    """T'=500 through the persistent kernels: determinism, explicit full lengths == no lengths,
-    a backward pass cut into step ranges == one launch, and the mirror symmetry of the two
-    directions (time-reversed input with the directions' weights swapped gives the time-reversed
-    output with the halves swapped) - all bit for bit."""
-    num_steps, gates = 500, hip.CELL_GATES[cell]
+@pytest.mark.parametrize('cell,hidden,batch,num_steps', [
+    ('lstm', 1024, 16, 500), ('lstm', 1024, 32, 500), ('rnn_relu', 2048, 16, 500),
+    # C5: 17 s utterances (T' = 850) through the BiLSTM-1024 kernels, one and two batch tiles
+    ('lstm', 1024, 16, 850), ('lstm', 1024, 32, 850),
+    # the round-2 kernels at full length: LSTM-2048 (one direction per launch), GRU-1024 / -2048
+    ('lstm', 2048, 16, 500), ('gru', 1024, 16, 500), ('gru', 2048, 16, 500),
+    ('gru', 1024, 32, 500)])
+def test_recurrence_full_size_symmetries(hip, cell, hidden, batch, num_steps):
+    """T'=500 / 850 through the persistent kernels: determinism, explicit full lengths == no
+    lengths, a backward pass cut into step ranges == one launch, and the mirror symmetry of the
+    two directions (time-reversed input with the directions' weights swapped gives the
+    time-reversed output with the halves swapped) - all bit for bit.  Exercises the exchange
+    buffer indexing, the carry between launches and the counter reset (`counters_done`) over
+    the full length for every persistent kernel family."""
+    gates = hip.CELL_GATES[cell]
     assert hip.rnn_persistent_supported(cell, num_steps, batch, hidden)
     gen = torch.Generator(device=DEV).manual_seed(7)
     scale = 0.5 if cell == 'lstm' else 0.05
     xw = torch.randn(num_steps, batch, 2, gates * hidden, device=DEV, generator=gen) * scale
     w_hh = torch.randn(2, gates * hidden, hidden, device=DEV, generator=gen) / np.sqrt(hidden)
-    if cell != 'lstm':
+    if cell not in ('lstm', 'gru'):
         w_hh *= 0.5
     dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=gen)
-    y, reserve, ws = hip.rnn_fwd(cell, xw, w_hh)
+    # (GRU: the candidate gate's recurrent bias is an argument of the forward pass)
+    kw = {}
+    if cell == 'gru':
+        kw['b_hh_n'] = torch.randn(2, 3 * hidden, device=DEV, generator=gen) * 0.1
+    kw_mirror = {k: v.flip(0).contiguous() for k, v in kw.items()}
+    y, reserve, ws = hip.rnn_fwd(cell, xw, w_hh, **kw)
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert torch.isfinite(y).all() and float(y.abs().max()) > 1e-3
-    y_again, _, _ = hip.rnn_fwd(cell, xw, w_hh)
+    y_again, _, _ = hip.rnn_fwd(cell, xw, w_hh, **kw)
     assert torch.equal(y_again, y)
     full = torch.full((batch,), num_steps, dtype=torch.int32, device=DEV)
-    y_len, _, _ = hip.rnn_fwd(cell, xw, w_hh, full)
+    y_len, _, _ = hip.rnn_fwd(cell, xw, w_hh, full, **kw)
     assert torch.equal(y_len, y)
+    # a forward pass cut into step ranges == one launch (state carried through the workspace)
+    y_cut, reserve_cut = torch.empty_like(y), torch.empty_like(reserve)
+    cuts = [0, num_steps // 4, num_steps // 2 + 1, num_steps - 3, num_steps]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        hip.rnn_fwd(cell, xw, w_hh, y=y_cut, reserve=reserve_cut, workspace=ws, steps=(lo, hi),
+                    **kw)
+    hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
+    assert torch.equal(y_cut, y)
     # mirror symmetry
-    y_mirror, _, _ = hip.rnn_fwd(cell, xw.flip(0).flip(2).contiguous(), w_hh.flip(0).contiguous())
+    y_mirror, _, _ = hip.rnn_fwd(cell, xw.flip(0).flip(2).contiguous(), w_hh.flip(0).contiguous(),
+                                 **kw_mirror)
     expect = torch.cat([y[..., hidden:], y[..., :hidden]], dim=-1).flip(0)
     assert torch.equal(y_mirror, expect)
     # backward: one launch vs four step ranges vs explicit lengths
@@ -132,7 +153,9 @@ def test_recurrence_full_size_symmetries(hip, cell, hidden, batch):
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert torch.isfinite(dxw).all()
     dxw_cut = torch.empty_like(dxw)
-    for hi, lo in ((500, 375), (375, 250), (250, 125), (125, 0)):
+    quarter = num_steps // 4
+    for hi, lo in ((num_steps, 3 * quarter), (3 * quarter, 2 * quarter), (2 * quarter, quarter),
+                   (quarter, 0)):
         hip.rnn_bwd(cell, dy, y, w_hh_t, reserve, dxw=dxw_cut, workspace=ws, steps=(lo, hi))
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert torch.equal(dxw_cut, dxw)
@@ -186,15 +209,16 @@ def test_adam_full_size_against_plain_torch(hip):
     assert abs(float(param.double().sum()) - float(p_ref.double().sum())) < 1e-3
 
 
-@pytest.mark.parametrize('layer,batch', [((40, 32), 32), ((20, 96), 16)])
-def test_convolution_kernels_are_adjoint_at_full_size(hip, layer, batch):
+@pytest.mark.parametrize('layer,batch,frames', [((40, 32), 32, 500), ((20, 96), 16, 500),
+                                                # C5: the longest utterance (17 s, T' = 850)
+                                                ((40, 32), 16, 850), ((20, 96), 16, 850)])
+def test_convolution_kernels_are_adjoint_at_full_size(hip, layer, batch, frames):
     """C3-sized convolution (batch 32, T' = 500): forward, data gradient and kernel gradient are
     three views of one bilinear form, so  <dz, conv(x; w)> = <x, bwd_data(dz; w)> =
     <w, wrw(dz, x)>  ties the three own kernels together without any reference (fp64 sums of
     fp32 results: relative 1e-4); the kernel gradient is deterministic and linear in dz, and the
     time-major variants of the last layer give the same numbers."""
     freq, cout = layer
-    frames = 500
     gen = torch.Generator(device=DEV).manual_seed(7)
     x = torch.randn(batch, frames, freq, 32, device=DEV, generator=gen)
     dz = torch.randn(batch, frames, freq // 2, cout, device=DEV, generator=gen)
@@ -239,7 +263,8 @@ def test_two_tile_recurrences_equal_the_single_barrier_kernels_at_full_size(hip,
     assert float((reserve_new.view(torch.float32) - reserve.view(torch.float32)).abs().max()) < 1e-5
     dxw_ref = hip.rnn_bwd('lstm', dy, y_ref, w_hh_t, reserve, workspace=ws,
                           flags=hip.RNN_ONE_BARRIER)
-    for flags in (hip.RNN_DEFAULT, hip.RNN_WHOLE_CHIP, hip.RNN_WHOLE_CHIP | hip.RNN_ONE_BARRIER):
+    for flags in (hip.RNN_DEFAULT, hip.RNN_WHOLE_CHIP, hip.RNN_WHOLE_CHIP | hip.RNN_ONE_BARRIER,
+                  hip.RNN_REDUCE_SCATTER):
         dxw = hip.rnn_bwd('lstm', dy, y_ref, w_hh_t, reserve, workspace=ws, flags=flags)
         again = hip.rnn_bwd('lstm', dy, y_ref, w_hh_t, reserve, workspace=ws, flags=flags)
         assert torch.equal(dxw, again), flags

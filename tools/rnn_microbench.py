@@ -26,6 +26,8 @@ def main():
     if os.environ.get('CTCASR_ONE_BARRIER'):   # B > 16: round-1 kernels (one barrier for both tiles)
         bwd_flags |= hip.RNN_ONE_BARRIER
         fwd_flags |= hip.RNN_ONE_BARRIER
+    if os.environ.get('CTCASR_RS'):            # backward: reduce-scatter form (LSTM-1024)
+        bwd_flags |= hip.RNN_REDUCE_SCATTER
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
@@ -53,6 +55,10 @@ def main():
             base = state + 9216 + 256 + (0 if name == "fwd" else 32)   # SyncWords: counters, error
             words = ws[base: base + 32].cpu().numpy().view(np.uint64)
             labels = ['wait', 'loads+mfma', 'reduce+gates+publish', 'drain+arrive']
+            if name == 'bwd' and os.environ.get('CTCASR_RS'):
+                words = ws[base: base + 40].cpu().numpy().view(np.uint64)
+                labels = ['wait', 'partial loads+sum', 'gates+A operand', 'mfma+publish',
+                          'drain+arrive+dxw']
             print('  wg0 phases (us/step): ' + ', '.join(
                 '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
             if name == 'fwd' and B > 16:
@@ -62,6 +68,24 @@ def main():
                     np.round(more[0:4], 2).tolist(), more[4]))
                 print('  chain 1: {}  (partials+barrier inside phase 2: {:.2f})'.format(
                     np.round(more[8:12], 2).tolist(), more[12]))
+            if name == 'bwd' and os.environ.get('CTCASR_RS'):
+                every = ws[state + 9216 + 256 + 128: state + 9216 + 256 + 128 + 256 * 32] \
+                    .cpu().numpy().view(np.uint64).reshape(256, 4).astype(np.float64) / 100.0 / T
+                chains = 2 if B > 16 else 1
+                every = every[:128 * chains]
+                for ch in range(chains):
+                    part = every[ch::chains]
+                    print('    chain {} over 128 workgroups (us/step)'.format(ch))
+                    for k, label in enumerate(['wait', 'partial loads+sum', 'gates+mfma+publish',
+                                               'drain+arrive+dxw']):
+                        col = part[:, k]
+                        print('      {:<20s} min {:.2f}  median {:.2f}  max {:.2f}'.format(
+                            label, col.min(), np.median(col), col.max()))
+                    busy = part[:, 1] + part[:, 2] + part[:, 3]
+                    print('      busy (all but wait)  min {:.2f}  median {:.2f}  max {:.2f}; '
+                          'per blockIdx % 8: {}'.format(
+                              busy.min(), np.median(busy), busy.max(),
+                              np.round([busy[i::8].mean() for i in range(8)], 2).tolist()))
             if name == 'fwd':
                 every = ws[base + 128: base + 128 + 256 * 32].cpu().numpy().view(np.uint64) \
                     .reshape(256, 4).astype(np.float64) / 100.0 / T

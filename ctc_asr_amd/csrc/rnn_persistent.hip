@@ -180,6 +180,40 @@ __device__ __forceinline__ void chain_barrier(ChainSync *cs, unsigned &epoch, in
     asm volatile("" ::: "memory");          // LDS reads below stay below
 }
 
+// Two chains: the MFMA phases of the two batch tiles take turns.  Left alone the chains fall into
+// lockstep - both in their MFMA phase at once, each at half rate, then both in their exchange
+// phase with the matrix pipe idle (reduce-scatter backward: 11.9 us per step = 2 x 3.9 of MFMA
+// + 4 of exchange).  With the pipe handed over explicitly one chain's exchange round trip
+// (loads, gate math, drain, barrier) runs under the other chain's MFMAs.
+struct MfmaTurn {           // in LDS, one per workgroup
+    unsigned lock;          // 1 while a chain is in its MFMA phase
+    unsigned done[2];       // waves of chain c that have finished MFMA phases (cumulative)
+    unsigned pad;
+};
+__device__ __forceinline__ void mfma_turn_take(MfmaTurn *turn) {      // one thread per chain
+    unsigned expected = 0u;
+    while (!__hip_atomic_compare_exchange_strong(&turn->lock, &expected, 1u, __ATOMIC_RELAXED,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        expected = 0u;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// every wave of the chain, after its MFMAs: the last of the four hands the pipe over
+__device__ __forceinline__ void mfma_turn_give(MfmaTurn *turn, int lchain, int lane) {
+    if (lane == 0) {
+        const unsigned before = __hip_atomic_fetch_add(&turn->done[lchain], 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((before & 3u) == 3u)
+            __hip_atomic_store(&turn->lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+#ifndef PRNN_RS_LOCK
+#define PRNN_RS_LOCK 1
+#endif
+#ifndef PRNN_TURN_PRIO
+#define PRNN_TURN_PRIO 2            // s_setprio of the waves that hold the matrix pipe
+#endif
+
 // Direction-wide barrier, split in two so that the arrival is posted as soon as a step's
 // published stores are out and the wait happens at the top of the next step.
 // `step` counts arrivals (0-based).  CHAINS = 1: `ctid` is threadIdx.x and the workgroup barrier
@@ -347,6 +381,13 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     // it 50:50 - measured 8.5 us per forward step against 7.3 with one barrier): a static
     // priority for chain 0 lets it through first, after which the chains stay out of phase and
     // each one's exchange round trip hides behind the other's MFMAs.
+    // (Round 3: both tiles as two chains in every workgroup of a WHOLE-chip launch - 128
+    // workgroups per direction, 8 units each, 1.7 us of MFMA per chain and step - with the
+    // chains' MFMA phases taking turns through an LDS lock (MfmaTurn, as in the reduce-scatter
+    // backward kernel): 7.2 us per step with the lock holder at s_setprio 2, 6.96 at equal
+    // priority, 7.14 without the lock, against 6.1 for one group of workgroups per tile - the
+    // other chain's gate math (VALU, transcendentals) crawls while a chain issues MFMAs on the
+    // same SIMD: reduce + gates + publish 0.56 -> 1.85 - 2.46 us.  Not kept.)
     if constexpr (CHAINS > 1) {
         if (chain == 0) __builtin_amdgcn_s_setprio(PRNN_CHAIN0_PRIO);
     }
@@ -1074,19 +1115,6 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
 #define PRNN_RS_APITCH 68               // floats per row of the A operand in LDS
 #define PRNN_RS_TILE_BYTES 1024u        // one 16 x 16 fp32 accumulator tile
 #define PRNN_RS_SLOT_BYTES ((size_t)2 * PRNN_MAX_CHAINS * PRNN_RS_NWG * PRNN_RS_NWG * 1024)
-#ifndef PRNN_RS_LOCK
-#define PRNN_RS_LOCK 1
-#endif
-// Two chains: the MFMA phases of the two batch tiles take turns.  Left alone the chains fall into
-// lockstep - both in their MFMA phase at once, each at half rate, then both in their exchange
-// phase with the matrix pipe idle (measured 11.9 us per step: 2 x 3.9 of MFMA + 4 of exchange).
-// With the pipe handed over explicitly one chain's exchange round trip (partial loads, gate
-// math, drain, barrier) runs under the other chain's MFMAs.
-struct MfmaTurn {           // in LDS, one per workgroup
-    unsigned lock;          // 1 while a chain is in its MFMA phase
-    unsigned done[2];       // waves of chain c that have finished MFMA phases (cumulative)
-    unsigned pad;
-};
 size_t prnn_rs_ring_bytes() { return 2 * PRNN_RS_SLOT_BYTES; }
 
 template <int CHAINS>
@@ -1234,17 +1262,9 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
             if constexpr (CHAINS == 1) {
                 __syncthreads();
             } else {
-                if (PRNN_RS_LOCK && tid == 0) {         // take the matrix pipe for this chain
-                    unsigned expected = 0u;
-                    while (!__hip_atomic_compare_exchange_strong(
-                        &turn->lock, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                        expected = 0u;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
+                if (PRNN_RS_LOCK && tid == 0) mfma_turn_take(turn);   // the matrix pipe is ours
                 chain_barrier(cs, bar_epoch, lane);
-                if (PRNN_RS_LOCK) __builtin_amdgcn_s_setprio(2);
+                if (PRNN_RS_LOCK) __builtin_amdgcn_s_setprio(PRNN_TURN_PRIO);
             }
             float4 a[4];
 #pragma unroll
@@ -1268,15 +1288,8 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
                             acc1[0], acc1[1], acc1[2], acc1[3]);
             }
             if constexpr (CHAINS > 1 && PRNN_RS_LOCK) {
-                // the last of the chain's four waves through its MFMAs hands the pipe over
                 __builtin_amdgcn_s_setprio(0);
-                if (lane == 0) {
-                    const unsigned before = __hip_atomic_fetch_add(
-                        &turn->done[lchain], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if ((before & 3u) == 3u)
-                        __hip_atomic_store(&turn->lock, 0u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                mfma_turn_give(turn, lchain, lane);
             }
             if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
             if (s > p.s_lo) dir_arrive<CHAINS>(p.sync, cs, dir, chain, grp, tid, arrivals);
@@ -1643,7 +1656,7 @@ extern "C" unsigned ctcasr_build_flags(void) {
     unsigned flags = 0;
     if (PRNN_PROBE_HALF_LOADS) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
-        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1)
+        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

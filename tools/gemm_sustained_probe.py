@@ -36,51 +36,49 @@ FLOPS = 2.0 * ROWS * K * N
 
 
 class Sampler:
-    """Power (W) and shader clock (MHz) of GPU 0, sampled every ``period`` seconds."""
+    """Power (W) and shader clock (MHz) while a phase runs: every hwmon device of the node is
+    sampled from sysfs (a box may expose the other GPUs of its node there as well; the device
+    that draws the most is the one under test) and `amd-smi metric` is asked once, mid-phase, for
+    the GPU this process sees."""
 
     def __init__(self, period=0.02):
-        self.period, self.samples, self._stop = period, [], threading.Event()
-        self.power_file = self.clock_file = None
-        for hwmon in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'):
-            for name in ('power1_average', 'power1_input'):
-                if os.path.exists(os.path.join(hwmon, name)) and self.power_file is None:
-                    self.power_file = os.path.join(hwmon, name)
-            if os.path.exists(os.path.join(hwmon, 'freq1_input')) and self.clock_file is None:
-                self.clock_file = os.path.join(hwmon, 'freq1_input')
-        self.source = 'sysfs hwmon' if self.power_file else 'amd-smi metric'
-        if not self.power_file:
-            self.period = max(period, 0.25)
+        self.period, self._stop = period, threading.Event()
+        self.devices = []
+        for hwmon in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+            power = next((os.path.join(hwmon, n) for n in ('power1_average', 'power1_input')
+                          if os.path.exists(os.path.join(hwmon, n))), None)
+            clock = os.path.join(hwmon, 'freq1_input')
+            if power:
+                self.devices.append((hwmon, power, clock if os.path.exists(clock) else None))
+        self.samples = {d[0]: [] for d in self.devices}
+        self.smi = None
 
-    def _read(self):
-        if self.power_file:
-            try:
-                power = int(open(self.power_file).read()) / 1e6
-                clock = int(open(self.clock_file).read()) / 1e6 if self.clock_file else None
-                return power, clock
-            except (OSError, ValueError):
-                return None, None
+    @staticmethod
+    def _amd_smi():
         try:
-            out = subprocess.run(['amd-smi', 'metric', '-g', '0', '--power', '--clock', '--json'],
-                                 capture_output=True, text=True, timeout=5).stdout
-            data = json.loads(out)
-            data = data[0] if isinstance(data, list) else data
-            if 'gpu_data' in data:
-                data = data['gpu_data'][0]
-            power = data.get('power', {}).get('socket_power', {})
-            power = power.get('value') if isinstance(power, dict) else power
-            clock = data.get('clock', {}).get('gfx_0', {}).get('clk', {})
-            clock = clock.get('value') if isinstance(clock, dict) else clock
-            return (float(power) if power not in (None, 'N/A') else None,
-                    float(clock) if clock not in (None, 'N/A') else None)
-        except Exception:
-            return None, None
+            out = subprocess.run(['amd-smi', 'metric', '--power', '--clock', '--json'],
+                                 capture_output=True, text=True, timeout=10).stdout
+            return json.loads(out)
+        except Exception as err:
+            return {'error': type(err).__name__}
 
     def __enter__(self):
-        self.samples, self._stop = [], threading.Event()
+        self.samples = {d[0]: [] for d in self.devices}
+        self.smi, self._stop = None, threading.Event()
 
         def loop():
+            ticks = 0
             while not self._stop.is_set():
-                self.samples.append(self._read())
+                for name, power, clock in self.devices:
+                    try:
+                        self.samples[name].append((
+                            int(open(power).read()) / 1e6,
+                            int(open(clock).read()) / 1e6 if clock else None))
+                    except (OSError, ValueError):
+                        pass
+                ticks += 1
+                if ticks == 10 and self.smi is None:
+                    self.smi = self._amd_smi()
                 time.sleep(self.period)
         self.thread = threading.Thread(target=loop, daemon=True)
         self.thread.start()
@@ -92,11 +90,19 @@ class Sampler:
         return False
 
     def summary(self):
-        power = [p for p, _ in self.samples if p is not None]
-        clock = [c for _, c in self.samples if c is not None]
-        fmt = lambda xs: None if not xs else {'mean': round(sum(xs) / len(xs), 1),
-                                              'max': round(max(xs), 1), 'n': len(xs)}
-        return {'power_w': fmt(power), 'sclk_mhz': fmt(clock), 'source': self.source}
+        best, best_mean = None, -1.0
+        for name, rows in self.samples.items():
+            power = [p for p, _ in rows]
+            if power and sum(power) / len(power) > best_mean:
+                best, best_mean = name, sum(power) / len(power)
+        out = {'hwmon_devices': len(self.devices), 'amd_smi': self.smi}
+        if best is not None:
+            rows = self.samples[best]
+            clock = [c for _, c in rows if c is not None]
+            out.update({'busiest_hwmon': best, 'power_w_mean': round(best_mean, 1),
+                        'power_w_max': round(max(p for p, _ in rows), 1), 'samples': len(rows),
+                        'sclk_mhz_mean': round(sum(clock) / len(clock), 1) if clock else None})
+        return out
 
 
 def analyze(path):

@@ -331,6 +331,10 @@ class CTCModel:
         # launches per persistent FORWARD recurrence when the next layer's input projection is
         # pipelined with it on the other half of the chip (1 = off: whole-chip single launch)
         self.fwd_chunks = max(1, int(os.environ.get('CTCASR_FWD_CHUNKS', '4')))
+        # ... for batches up to this size: above 16 rows the forward kernel runs one group of
+        # workgroups per 16-row tile and fills the chip whatever the flag says, so the projection
+        # GEMMs would only compete with it (measured at B = 32: profiles/r03_gemm_...md)
+        self.fwd_pipeline_max_batch = int(os.environ.get('CTCASR_FWD_PIPELINE_MAX_BATCH', '16'))
         self._side_stream = None
         self.early_hooks = False        # see backward(); set by engine.Trainer
         # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
@@ -539,7 +543,8 @@ class CTCModel:
         with the NEXT layer's input projection on the other half: pays when that projection is a
         big GEMM (another LSTM layer follows), the steps map to the same time index for every row
         and nothing (dropout) sits between the layers."""
-        return (self.fwd_chunks > 1 and cell == 'lstm' and hidden == 1024 and batch <= 16 and
+        return (self.fwd_chunks > 1 and cell == 'lstm' and hidden == 1024 and
+                batch <= self.fwd_pipeline_max_batch and
                 rnn_len is None and
                 rnn_rate == 0.0 and layer + 1 < self.cfg.num_layers_rnn and
                 t_out >= 8 * self.fwd_chunks and

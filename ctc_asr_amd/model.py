@@ -791,19 +791,23 @@ class CTCModel:
             # utterance (no per-row lengths: the cuDNN-semantics path) - dxw of a finished range
             # of steps is final, so its share of dW_ih / dW_hh starts on the side stream while the
             # next launch carries the recurrence on.
-            # (Not for the LSTM at H = 2048: its backward kernel occupies the whole chip one
-            # direction at a time, nothing could run beside it.)
+            # (Not for the LSTM / GRU at H = 2048: their backward kernels occupy the whole chip one
+            # direction at a time, nothing could run beside them.)
+            # GRU: dW_hh and db_hh are products / sums of drec (the candidate gate's gradient
+            # scaled by r), which the backward kernel leaves in the reserve next to the gates.
             chunks = 1
-            if (side is not main and acts['rnn_len'] is None and cell != 'gru' and
-                    not (cell == 'lstm' and hidden == 2048) and
-                    hip.rnn_persistent_supported(cell, t_out, batch, hidden)):
+            if (side is not main and acts['rnn_len'] is None and not whole_chip_rnn and
+                    persistent):
                 chunks = self.bwd_chunks or (2 if batch <= 16 else 3)
                 if t_out < 8 * chunks:
                     chunks = 1
             dy = dy.contiguous()
             dxw = torch.empty((t_out, batch, 2, gh), dtype=torch.float32, device=dy.device)
 
-            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw):
+            drec = hip.rnn_gru_drec(acts['reserves'][i], t_out, batch, hidden) if cell == 'gru' \
+                else dxw
+
+            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec):
                 # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
                 x3 = x.view(t_out, batch, -1)
                 for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
@@ -817,7 +821,7 @@ class CTCModel:
                         b, shift, cols = min(b, t_out - 1), 1, slice(hidden, 2 * hidden)
                     if b > a:
                         g[name + '/w_hh'][d].addmm_(
-                            dxw[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
+                            drec[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
                             y[a + shift:b + shift, :, cols].reshape((b - a) * batch, hidden))
 
             bounds = [t_out * (chunks - c) // chunks for c in range(chunks + 1)]   # T ... 0
@@ -840,18 +844,21 @@ class CTCModel:
                     dy_below = hip.dropout(dy_below, rnn_rate, seeds[0])
 
             def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i, chunks=chunks,
-                             last=bounds[-2], partial_weight_grads=partial_weight_grads):
+                             last=bounds[-2], partial_weight_grads=partial_weight_grads,
+                             drec=drec):
                 hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
                 if chunks > 1:          # the earlier launches' shares are already in
                     partial_weight_grads(0, last)
-                    g[name + '/b_hh'].copy_(g[name + '/b_ih'])
+                    if cell == 'gru':
+                        hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
+                                              g[name + '/b_hh'].view(-1))
+                    else:
+                        g[name + '/b_hh'].copy_(g[name + '/b_ih'])
                     return
                 torch.mm(dxw2d.t(), x.view(rows, -1),
                          out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
                 # gradient w.r.t. the recurrent pre-activations: dxw itself, except for the GRU
-                drec = dxw
                 if cell == 'gru':
-                    drec = hip.rnn_gru_drec(acts['reserves'][i], t_out, batch, hidden)
                     hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
                                           g[name + '/b_hh'].view(-1))
                 else:

@@ -269,13 +269,31 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
         hip.features(pcm_d, nsamp_d, 'mel', 'local', False, 16000, out=feat_buf, out_len=len_d)
         # (check=True: the production path of train.py - its error checks are deferred and do
         # not stall the host, engine.Trainer.train_step)
-        return trainer.train_step(feat_buf, len_d, packed, check=not args.no_step_checks)
+        # (at N > 1 nothing may raise on one rank only in the middle of the loop: the checks run
+        # at the two synchronisation points below and their outcome is agreed on by all ranks)
+        return trainer.train_step(feat_buf, len_d, packed,
+                                  check=not args.no_step_checks and world == 1)
+
+    failure = []
+
+    def checks():
+        """Errors of the steps so far; at N > 1 a failed leg (e.g. a recurrence time-out under
+        the early release mode) is reported in the line instead of killing the other legs."""
+        try:
+            trainer.drain_checks()
+            CTCModel.check_status(model.last_status)
+            # a persistent recurrence launch that gave up at a grid barrier produced garbage
+            # (sticky word: covers every layer, pass and step since the previous check)
+            model.check_rnn_error()
+        except (hip.CtcAsrError, ValueError) as err:
+            if world == 1:
+                raise
+            failure.append('rank {}: {}'.format(rank, err))
 
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    CTCModel.check_status(model.last_status)
-    model.check_rnn_error()
+    checks()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -306,11 +324,12 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
         dist.all_gather(every, mine)
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         elapsed = max(float(t.item()) for t in every)          # MAX over ranks (the contract)
-    trainer.drain_checks()
-    CTCModel.check_status(model.last_status)
-    # a persistent recurrence launch that gave up at a grid barrier would have produced garbage
-    # (sticky word: covers every layer, pass and step since the check before the timed region)
-    model.check_rnn_error()
+    checks()
+    failed_ranks = 0
+    if world > 1:
+        flag = torch.tensor([1.0 if failure else 0.0], device=device)
+        dist.all_reduce(flag)
+        failed_ranks = int(flag.item())
 
     result = None
     if rank == 0:
@@ -416,6 +435,9 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                            'no collective at all (timing reference; replicas drift apart)',
                 'rank_ms_per_step': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3),
                                      'all': [round(v, 3) for v in rank_ms]}}
+            if failed_ranks:
+                result['allreduce']['failed'] = '{} rank(s) reported an error; {}'.format(
+                    failed_ranks, '; '.join(failure) or 'see the other ranks\' stderr')
     del trainer, model
     torch.cuda.empty_cache()
     return result, (cfg, frames, batch, seconds)
@@ -692,10 +714,12 @@ def merge_release_modes(legs, stub):
     the stubbed step into ONE result line - the better mode's line, with every mode's step time,
     per-rank spread and exposed all-reduce time (= its step minus the stubbed step) under
     ``allreduce.modes``."""
-    best = min(legs, key=lambda m: legs[m]['ms_per_step'])
+    valid = [m for m in legs if 'failed' not in legs[m]['allreduce']] or list(legs)
+    best = min(valid, key=lambda m: legs[m]['ms_per_step'])
     result = legs[best]
     result['allreduce']['modes'] = {
         m: {'ms_per_step': leg['ms_per_step'], 'value': leg['value'],
+            'failed': leg['allreduce'].get('failed'),
             'mode': leg['allreduce']['mode'],     # early falls back to held at H = 2048
             'launches_per_step': leg['allreduce']['launches_per_step'],
             'rank_ms_per_step': leg['allreduce']['rank_ms_per_step'],
@@ -816,6 +840,8 @@ def main():
         stub, _ = measure(args.workload, args, rank, local_rank, world, reduce=False)
         cfg, frames, batch, seconds = shape
         result = merge_release_modes(legs, stub) if rank == 0 else None
+        if rank == 0 and 'failed' in result['allreduce']:
+            exit_code = 4                # every measured mode failed: the line says why
     if world == 1 and args.workload == 'c3' and not args.no_other_workloads:
         second, _ = measure('c2', args, rank, local_rank, world)
         other['c2'] = {k: second[k] for k in ('value', 'unit', 'ms_per_step', 'config',
@@ -855,7 +881,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if exit_code:
-        sys.stderr.write('bench.py: parity probe above the 1e-3 bar (see parity_probe).\n')
+        sys.stderr.write('bench.py: {}.\n'.format(
+            'parity probe above the 1e-3 bar (see parity_probe)' if exit_code == 3 else
+            'every release mode reported an error (see allreduce.modes)'))
         sys.exit(exit_code)
 
 

@@ -28,6 +28,7 @@
 #include <vector>
 
 #define PRNN_THREADS 256
+#define PRNN_BLOCK_ROWS 32          // rows one persistent launch covers (two 16-row tiles)
 #ifndef PRNN_GROUPS
 #define PRNN_GROUPS 8
 #endif
@@ -87,7 +88,9 @@ struct PArgs {
     const float *bias;     // forward: [2, G*H] added to xw (NULL: none)
     const float *b_hh;     // GRU forward: recurrent bias [2, 3H] (its candidate-gate third is read)
     float *drec;           // GRU backward: d(recurrent pre-activations) [T, B, 2, 3H]
-    int T, B, H, nwg;      // nwg = workgroups per direction (and chain)
+    int T, B, H, nwg;      // nwg = workgroups per direction (and chain); B = rows of this launch
+    int BS;                // batch stride of the [T, batch, ...] tensors (>= B: a launch may cover a
+                           // block of at most 32 rows of a bigger batch, pointers offset by the host)
     int ndir, dir0;        // directions in this launch (2, or 1 when they run one after the other)
     int chain0;            // first batch tile of this launch
     int s_lo, s_hi;        // backward: this launch runs steps s_hi-1 ... s_lo (a whole pass: 0, T)
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
 #endif
-    const int H = p.H, B = p.B, T = p.T;
+    const int H = p.H, B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * UPB;
     const int kq = 4 * (lane >> 4);
 
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
                     if (s < steps) {
                         const int t = row_time(dir, s, steps);
                         it_t[it] = t;
-                        const float *x = p.xw + (((size_t)t * B + b) * 2 + dir) * GR * H + u0 + u;
+                        const float *x = p.xw + (((size_t)t * BS + b) * 2 + dir) * GR * H + u0 + u;
 #pragma unroll
                         for (int g = 0; g < GR; ++g) xw[it][g] = x[(size_t)g * H] + xb[it][g];
                     }
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
             if (it_t[it] < 0) continue;
             const int item = tid + it * PRNN_THREADS;
             const int b = row0 + item / UPB, unit = u0 + item % UPB;
-            p.y[((size_t)it_t[it] * B + b) * 2 * H + dir * H + unit] = hv[it];
+            p.y[((size_t)it_t[it] * BS + b) * 2 * H + dir * H + unit] = hv[it];
         }
         if constexpr (CELL == CTCASR_CELL_LSTM || GRU) {
 #pragma unroll
@@ -675,11 +678,11 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
                 if (it_t[it] < 0) continue;
                 const int item = tid + it * PRNN_THREADS;
                 const int b = row0 + item / UPB, unit = u0 + item % UPB;
-                float *gr = p.gates + (((size_t)it_t[it] * B + b) * 2 + dir) * 4 * H + unit;
+                float *gr = p.gates + (((size_t)it_t[it] * BS + b) * 2 + dir) * 4 * H + unit;
                 gr[0] = rsv[it][0]; gr[H] = rsv[it][1]; gr[2 * H] = rsv[it][2];
                 gr[3 * H] = rsv[it][3];
                 if constexpr (!GRU)
-                    p.cells[(((size_t)it_t[it] * B + b) * 2 + dir) * H + unit] = rsv[it][4];
+                    p.cells[(((size_t)it_t[it] * BS + b) * 2 + dir) * H + unit] = rsv[it][4];
             }
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
@@ -786,7 +789,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
 #endif
-    const int H = p.H, B = p.B, T = p.T, GH = G * p.H;
+    const int H = p.H, B = p.B, T = p.T, GH = G * p.H, BS = p.BS;
     const int u0 = slice * UPB;
     const int kq = 4 * (lane >> 4);
     // fragment slot: lanes l and l+8 share one in the half-tile layout
@@ -856,29 +859,29 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                         const int t = row_time(dir, s, steps);
                         const int unit = u0 + u;
                         it_t[it] = t;
-                        dyv[it] = p.dy[((size_t)t * B + b) * 2 * H + dir * H + unit];
+                        dyv[it] = p.dy[((size_t)t * BS + b) * 2 * H + dir * H + unit];
                         if constexpr (CELL == CTCASR_CELL_LSTM) {
-                            const float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+                            const float *gr = p.gates + (((size_t)t * BS + b) * 2 + dir) * 4 * H + unit;
                             gv[it][0] = gr[0]; gv[it][1] = gr[H];
                             gv[it][2] = gr[2 * H]; gv[it][3] = gr[3 * H];
-                            cv[it] = p.cells[(((size_t)t * B + b) * 2 + dir) * H + unit];
+                            cv[it] = p.cells[(((size_t)t * BS + b) * 2 + dir) * H + unit];
                             cpv[it] = 0.f;
                             if (s > 0) {
                                 const int tp = row_time(dir, s - 1, steps);
-                                cpv[it] = p.cells[(((size_t)tp * B + b) * 2 + dir) * H + unit];
+                                cpv[it] = p.cells[(((size_t)tp * BS + b) * 2 + dir) * H + unit];
                             }
                         } else if constexpr (GRU) {
                             // r, z, n, q = R_n h + b_Rn of this step; h of the step before
-                            const float *gr = p.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+                            const float *gr = p.gates + (((size_t)t * BS + b) * 2 + dir) * 4 * H + unit;
                             gv[it][0] = gr[0]; gv[it][1] = gr[H];
                             gv[it][2] = gr[2 * H]; gv[it][3] = gr[3 * H];
                             hv[it] = 0.f;
                             if (s > 0) {
                                 const int tp = row_time(dir, s - 1, steps);
-                                hv[it] = p.y[((size_t)tp * B + b) * 2 * H + dir * H + unit];
+                                hv[it] = p.y[((size_t)tp * BS + b) * 2 * H + dir * H + unit];
                             }
                         } else {
-                            hv[it] = p.y[((size_t)t * B + b) * 2 * H + dir * H + unit];
+                            hv[it] = p.y[((size_t)t * BS + b) * 2 * H + dir * H + unit];
                         }
                     }
                 }
@@ -1052,11 +1055,11 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                 }
             }
             if (it_t[it] >= 0) {      // dxw in its GEMM layout: read after the launch only
-                float *dx = p.dxw + (((size_t)it_t[it] * B + row0 + b) * 2 + dir) * GH + u0 + u;
+                float *dx = p.dxw + (((size_t)it_t[it] * BS + row0 + b) * 2 + dir) * GH + u0 + u;
 #pragma unroll
                 for (int g = 0; g < G; ++g) dx[(size_t)g * H] = GRU && g == 2 ? dxn : dg[g];
                 if constexpr (GRU) {  // drec: dW_hh and db_hh are GEMMs / column sums of it
-                    float *dr = p.drec + (((size_t)it_t[it] * B + row0 + b) * 2 + dir) * GH + u0 + u;
+                    float *dr = p.drec + (((size_t)it_t[it] * BS + row0 + b) * 2 + dir) * GH + u0 + u;
 #pragma unroll
                     for (int g = 0; g < G; ++g) dr[(size_t)g * H] = dg[g];
                 }
@@ -1148,7 +1151,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
     const int wg = blockIdx.x % (p.ndir * p.nwg);
     const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
-    const int B = p.B, T = p.T;
+    const int B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * 16;
     if (CHAINS > 1 && threadIdx.x == 0) *turn = MfmaTurn{0u, {0u, 0u}, 0u};
 
@@ -1197,12 +1200,12 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
         const int t = running ? row_time(dir, s, steps) : 0;
         float dyv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cv = 0.f, cpv = 0.f;
         if (running) {
-            dyv = p.dy[((size_t)t * B + brow) * 2 * H + dir * H + unit];
-            const float *gr = p.gates + (((size_t)t * B + brow) * 2 + dir) * 4 * H + unit;
+            dyv = p.dy[((size_t)t * BS + brow) * 2 * H + dir * H + unit];
+            const float *gr = p.gates + (((size_t)t * BS + brow) * 2 + dir) * 4 * H + unit;
             gi = gr[0]; gf = gr[H]; gg = gr[2 * H]; go = gr[3 * H];
-            cv = p.cells[(((size_t)t * B + brow) * 2 + dir) * H + unit];
+            cv = p.cells[(((size_t)t * BS + brow) * 2 + dir) * H + unit];
             if (s > 0)
-                cpv = p.cells[(((size_t)row_time(dir, s - 1, steps) * B + brow) * 2 + dir) * H +
+                cpv = p.cells[(((size_t)row_time(dir, s - 1, steps) * BS + brow) * 2 + dir) * H +
                               unit];
         }
 
@@ -1296,7 +1299,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
         }
         // dxw in its GEMM layout: read after the launch only
         if (running) {
-            float *dx = p.dxw + (((size_t)t * B + brow) * 2 + dir) * GH + unit;
+            float *dx = p.dxw + (((size_t)t * BS + brow) * 2 + dir) * GH + unit;
             dx[0] = dg[0]; dx[H] = dg[1]; dx[2 * H] = dg[2]; dx[3 * H] = dg[3];
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[4] += c - c0; c0 = c; }
@@ -1397,9 +1400,11 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
     // the GRU rides on the LSTM kernels' four-gate column layout (fourth slot empty)
     const bool gru = cell == CTCASR_CELL_GRU && (H == 1024 || H == 2048);
     const bool rnn = (cell == CTCASR_CELL_RNN_RELU || cell == CTCASR_CELL_RNN_TANH) && H == 2048;
-    if (!(lstm || gru || rnn) || B < 1 || B > 32 || T < 1) return 0;
-    // the exchange buffer is addressed through a 32-bit buffer descriptor
-    if ((size_t)(T + 1) * 2 * B * (lstm ? 4 : (gru ? 3 : 1)) * H * sizeof(float) >= (1ull << 31))
+    // batches of 33..64 rows run as two launches over blocks of at most 32 rows
+    if (!(lstm || gru || rnn) || B < 1 || B > 2 * PRNN_BLOCK_ROWS || T < 1) return 0;
+    // the exchange buffer (of one block of rows) is addressed through a 32-bit buffer descriptor
+    const int rows = B < PRNN_BLOCK_ROWS ? B : PRNN_BLOCK_ROWS;
+    if ((size_t)(T + 1) * 2 * rows * (lstm ? 4 : (gru ? 3 : 1)) * H * sizeof(float) >= (1ull << 31))
         return 0;
     const char *mode = getenv("CTCASR_RNN_MODE");   // "stream" forces the per-step kernels
     if (mode && mode[0] == 's') return 0;
@@ -1426,7 +1431,7 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
 }
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
-             const float *b_hh_n, const int32_t *seq_len, int T, int B, int H, float *y,
+             const float *b_hh_n, const int32_t *seq_len, int T, int B, int BS, int H, float *y,
              float *gates, float *cells, void *sync, float *carry, int step_begin, int step_end,
              int flags, hipStream_t s) {
     // forward default: the whole chip (nothing of the same layer can overlap it)
@@ -1438,12 +1443,10 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
     p.bias = xw_bias; p.b_hh = b_hh_n;
     p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.sync = reinterpret_cast<SyncWords *>(sync);
-    p.T = T; p.B = B; p.H = H;
+    p.T = T; p.B = B; p.BS = BS; p.H = H;
     p.s_lo = step_begin; p.s_hi = step_end;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
-    if (seq_len && step_begin == 0 && hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
     const bool one_barrier = (flags & CTCASR_RNN_ONE_BARRIER) != 0;
     // 128 workgroups per direction, 16 * NT gate columns each, QW = H / 64 K chunks per wave
@@ -1509,7 +1512,8 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
 }
 
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
-             const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
+             const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
+             const float *cells,
              float *dxw, float *drec, void *sync, float *carry, int step_begin, int step_end,
              int flags, hipStream_t s) {
     PArgs p = {};
@@ -1522,18 +1526,11 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     // backward default: half of the chip (measured faster than the whole-chip variant even
     // without GEMMs beside it)
     const bool half_chip = (flags & CTCASR_RNN_WHOLE_CHIP) == 0;
-    p.T = T; p.B = B; p.H = H;
+    p.T = T; p.B = B; p.BS = BS; p.H = H;
     p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
-    const int gates_k = cell == CTCASR_CELL_LSTM ? 4 : (cell == CTCASR_CELL_GRU ? 3 : 1);
-    if (seq_len && step_end == T &&
-        hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * gates_k * H * sizeof(float), s) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
-    if (seq_len && step_end == T && cell == CTCASR_CELL_GRU &&
-        hipMemsetAsync(drec, 0, (size_t)T * B * 2 * 3 * H * sizeof(float), s) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
     const int mt = (B + 15) / 16;
     // batches of 17..32 rows = two independent 16-row tiles (see ChainSync):
     //   half of the chip: two chains inside every workgroup (8 waves): LSTM 11.0 us per step

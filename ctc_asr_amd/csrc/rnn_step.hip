@@ -285,13 +285,29 @@ size_t prnn_error_offset();
 int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t s);
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
-             const float *b_hh_n, const int32_t *seq_len, int T, int B, int H, float *y,
+             const float *b_hh_n, const int32_t *seq_len, int T, int B, int BS, int H, float *y,
              float *gates, float *cells, void *sync, float *carry, int step_begin, int step_end,
              int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
-             const int32_t *seq_len, int T, int B, int H, const float *gates, const float *cells,
-             float *dxw, float *drec, void *sync, float *carry, int step_begin, int step_end,
-             int flags, hipStream_t s);
+             const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
+             const float *cells, float *dxw, float *drec, void *sync, float *carry,
+             int step_begin, int step_end, int flags, hipStream_t s);
+
+// The persistent kernels cover at most 32 rows (two 16-row tiles) per launch: a bigger batch
+// (33..64) runs as consecutive launches over blocks of rows, each block with its own barrier
+// words, exchange buffer and carry in the workspace, the tensors addressed with the full batch
+// as stride.
+#define PRNN_BLOCK_ROWS 32
+static int prnn_blocks(int B) { return (B + PRNN_BLOCK_ROWS - 1) / PRNN_BLOCK_ROWS; }
+static int prnn_block_rows(int B, int block) {
+    const int left = B - block * PRNN_BLOCK_ROWS;
+    return left < PRNN_BLOCK_ROWS ? left : PRNN_BLOCK_ROWS;
+}
+// bytes of one block's region: barrier words, then its exchange buffer
+static size_t prnn_block_bytes(int T, int B, int H, int G) {
+    const int rows = B < PRNN_BLOCK_ROWS ? B : PRNN_BLOCK_ROWS;
+    return ctcasr_align_up(prnn_sync_bytes(), 256) + prnn_exchange_bytes(T, rows, H, G);
+}
 
 static size_t rnn_state_bytes(int B, int H) {
     return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256);
@@ -309,9 +325,10 @@ extern "C" size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0 || cell_gates(cell) == 0) return 0;
     // state ping-pong [2,2,B,H] + cell / dc carry [2,B,H]
     // persistent variant: + the per-step exchange buffer (h forward, dgates backward)
-    return rnn_state_bytes(B, H) + ctcasr_align_up(prnn_sync_bytes(), 256) +
+    return rnn_state_bytes(B, H) +
            (ctcasr_rnn_persistent_supported(cell, T, B, H)
-                ? prnn_exchange_bytes(T, B, H, cell_gates(cell)) : 0);
+                ? prnn_blocks(B) * prnn_block_bytes(T, B, H, cell_gates(cell))
+                : ctcasr_align_up(prnn_sync_bytes(), 256));
 }
 
 static int rnn_check(int cell, int T, int B, int H) {
@@ -350,13 +367,25 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_b
     p.hbuf = reinterpret_cast<float *>(workspace);
     p.cbuf = p.hbuf + (size_t)4 * B * H;
     p.T = T; p.B = B; p.H = H; p.b_hh = b_hh_n; p.xw_bias = xw_bias;
-    if (ctcasr_rnn_persistent_supported(cell, T, B, H))
-        return prnn_fwd(cell, xw, xw_bias, w_hh, b_hh_n, seq_len, T, B, H, y, p.gates, p.cells,
-                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
-                        step_begin, step_end, flags, s);
+    // (rows past their length keep zeros in y)
     if (seq_len && step_begin == 0 &&
         hipMemsetAsync(y, 0, (size_t)T * B * 2 * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
+    if (ctcasr_rnn_persistent_supported(cell, T, B, H)) {
+        const int G = cell_gates(cell);
+        for (int blk = 0; blk < prnn_blocks(B); ++blk) {
+            const size_t b0 = (size_t)blk * PRNN_BLOCK_ROWS;
+            rc = prnn_fwd(cell, xw + b0 * 2 * G * H, xw_bias, w_hh, b_hh_n,
+                          seq_len ? seq_len + b0 : nullptr, T, prnn_block_rows(B, blk), B, H,
+                          y + b0 * 2 * H, p.gates + b0 * 2 * 4 * H,
+                          p.cells + b0 * 2 * H,
+                          reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
+                              blk * prnn_block_bytes(T, B, H, G),
+                          p.cbuf + b0 * 2 * H, step_begin, step_end, flags, s);
+            if (rc != CTCASR_OK) return rc;
+        }
+        return CTCASR_OK;
+    }
     const int upb = cell == CTCASR_CELL_LSTM ? 8 : (cell == CTCASR_CELL_GRU ? 16 : 32);
     dim3 grid(H / upb, 2, (B + 15) / 16);
     for (int step = step_begin; step < step_end; ++step) {
@@ -413,16 +442,27 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     p.cbuf = p.hbuf + (size_t)4 * B * H;
     p.T = T; p.B = B; p.H = H;
     p.drec = p.gates + (size_t)T * B * 2 * 4 * H;      // GRU: behind r, z, n, q in the reserve
-    if (ctcasr_rnn_persistent_supported(cell, T, B, H))
-        return prnn_bwd(cell, dy, y, w_hh_t, seq_len, T, B, H, p.gates, p.cells, dxw, p.drec,
-                        reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), p.cbuf,
-                        step_begin, step_end, flags, s);
+    // (steps past a row's length carry no gradient)
     if (seq_len && step_end == T &&
         hipMemsetAsync(dxw, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     if (cell == CTCASR_CELL_GRU && seq_len && step_end == T &&
         hipMemsetAsync(p.drec, 0, (size_t)T * B * 2 * G * H * sizeof(float), s) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
+    if (ctcasr_rnn_persistent_supported(cell, T, B, H)) {
+        for (int blk = 0; blk < prnn_blocks(B); ++blk) {
+            const size_t b0 = (size_t)blk * PRNN_BLOCK_ROWS;
+            rc = prnn_bwd(cell, dy + b0 * 2 * H, y + b0 * 2 * H, w_hh_t,
+                          seq_len ? seq_len + b0 : nullptr, T, prnn_block_rows(B, blk), B, H,
+                          p.gates + b0 * 2 * 4 * H, p.cells + b0 * 2 * H, dxw + b0 * 2 * G * H,
+                          p.drec + b0 * 2 * G * H,
+                          reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
+                              blk * prnn_block_bytes(T, B, H, G),
+                          p.cbuf + b0 * 2 * H, step_begin, step_end, flags, s);
+            if (rc != CTCASR_OK) return rc;
+        }
+        return CTCASR_OK;
+    }
     dim3 grid(H / 16, 2, (B + 15) / 16);
     for (int step = step_end - 1; step >= step_begin; --step) {
         p.step = step;
@@ -456,17 +496,20 @@ extern "C" int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, in
         return CTCASR_ERR_WORKSPACE;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CTCASR_ERR_LAUNCH;
     if (!ctcasr_rnn_persistent_supported(cell, T, B, H)) return CTCASR_OK;
-    unsigned err = 0;
-    char *word = reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
-                 prnn_error_offset();
-    if (hipMemcpy(&err, word, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
-    // after a time-out the arrival counters are in an undefined state: start over with clean
-    // barrier words (this also clears the time-out word)
-    if (err && hipMemset(reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), 0,
-                         prnn_sync_bytes()) != hipSuccess)
-        return CTCASR_ERR_LAUNCH;
-    return err ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
+    bool timed_out = false;
+    for (int blk = 0; blk < prnn_blocks(B); ++blk) {
+        unsigned err = 0;
+        char *sync = reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
+                     blk * prnn_block_bytes(T, B, H, cell_gates(cell));
+        if (hipMemcpy(&err, sync + prnn_error_offset(), sizeof(err), hipMemcpyDeviceToHost) !=
+            hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+        // after a time-out the arrival counters are in an undefined state: start over with
+        // clean barrier words (this also clears the time-out word)
+        if (err && hipMemset(sync, 0, prnn_sync_bytes()) != hipSuccess) return CTCASR_ERR_LAUNCH;
+        timed_out = timed_out || err != 0;
+    }
+    return timed_out ? CTCASR_ERR_TIMEOUT : CTCASR_OK;
 }
 
 // Enqueue a one-lane gate on `stream` that returns once the persistent launch carrying `ticket`

@@ -71,6 +71,14 @@ def test_release_modes_are_folded_into_one_line():
     assert line['allreduce']['exposed_allreduce_ms'] == 1.25
     assert line['allreduce']['stubbed_ms_per_step'] == 98.25
     assert modes['early']['rank_ms_per_step']['min'] == 99.0
+    # a mode that reported an error (a recurrence time-out on some rank) is never the chosen one
+    bad = leg('early', 90.0, 7000.0)
+    bad['allreduce']['failed'] = '1 rank(s) reported an error; rank 3: time-out'
+    line = bench.merge_release_modes({'held': leg('held', 101.0, 6336.6), 'early': bad},
+                                     {'ms_per_step': 98.25})
+    assert line['allreduce']['chosen'] == 'held' and line['value'] == 6336.6
+    assert line['allreduce']['modes']['early']['failed'].startswith('1 rank')
+    assert 'failed' not in line['allreduce']
 
 
 def test_c5_bucket_sequence_is_fixed_and_bucketed():

@@ -102,12 +102,13 @@ def test_greedy_decode(hip, shape):
 @pytest.mark.parametrize('cell', ['lstm', 'rnn_tanh', 'rnn_relu', 'gru'])
 @pytest.mark.parametrize('use_len', [False, True])
 @pytest.mark.parametrize('dims', [(9, 3, 64), (23, 18, 128), (12, 16, 1024), (7, 19, 1024),
-                                  (5, 35, 1024),   # B > 32 -> streaming at H=1024
+                                  # B = 33..64: two persistent launches over blocks of <= 32 rows
+                                  (5, 35, 1024), (6, 64, 1024), (4, 40, 2048),
+                                  (5, 70, 1024),   # B > 64 -> streaming at H=1024
                                   (6, 16, 2048), (4, 21, 2048)])
 def test_rnn_fwd_bwd(hip, cell, use_len, dims):
     # every cell at every shape: the shapes a cell has no persistent kernel for (gru / relu / tanh
-    # at H=1024, lstm / gru at H=2048, B > 32) are exactly where the streaming kernels are the
-    # only path
+    # at H=1024, B > 64) are exactly where the streaming kernels are the only path
     num_steps, batch, hidden = dims
     gates = onn.GATES[cell]
     rng = np.random.default_rng(5)
@@ -536,7 +537,7 @@ def test_beam_search_random_sweep_against_the_oracle(hip):
 
 
 @pytest.mark.parametrize('batch,lengths', [(3, False), (16, True), (19, True), (32, False),
-                                           (32, True)])
+                                           (32, True), (45, True)])
 def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengths):
     """`RNN_REDUCE_SCATTER`: the LSTM-1024 backward recurrence with the product dgates x R cut
     along K (every workgroup multiplies the dgates of its OWN units into a partial dh for all

@@ -104,7 +104,9 @@ def test_beam_search_is_consistent_with_the_ctc_loss(hip):
     ('lstm', 1024, 16, 850), ('lstm', 1024, 32, 850),
     # the round-2 kernels at full length: LSTM-2048 (one direction per launch), GRU-1024 / -2048
     ('lstm', 2048, 16, 500), ('gru', 1024, 16, 500), ('gru', 2048, 16, 500),
-    ('gru', 1024, 32, 500)])
+    ('gru', 1024, 32, 500),
+    # 33..64 rows: two launches over blocks of 32 and 16 rows (own barrier words / exchange / carry)
+    ('lstm', 1024, 48, 500)])
 def test_recurrence_full_size_symmetries(hip, cell, hidden, batch, num_steps):
     """T'=500 / 850 through the persistent kernels: determinism, explicit full lengths == no
     lengths, a backward pass cut into step ranges == one launch, and the mirror symmetry of the

@@ -88,6 +88,8 @@ struct PArgs {
     const float *bias;     // forward: [2, G*H] added to xw (NULL: none)
     const float *b_hh;     // GRU forward: recurrent bias [2, 3H] (its candidate-gate third is read)
     float *drec;           // GRU backward: d(recurrent pre-activations) [T, B, 2, 3H]
+    float *dbias;          // backward (optional): bias gradients accumulate here: [2][G * H] column
+                           // sums of dxw, then (GRU only) [2][3 * H] column sums of drec
     int T, B, H, nwg;      // nwg = workgroups per direction (and chain); B = rows of this launch
     int BS;                // batch stride of the [T, batch, ...] tensors (>= B: a launch may cover a
                            // block of at most 32 rows of a bigger batch, pointers offset by the host)
@@ -840,6 +842,15 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
         a_steps[mt] = row < B ? row_steps(p.seq_len, row, T) : 0;
     }
 
+    // bias gradients: an item's unit is the same in every step, so its share of the column sums
+    // of dxw (GRU: + of drec's candidate gate) over this launch's steps stays in registers
+    constexpr int GS = GRU ? 2 * G : G;
+    float dbs[ITEMS][GS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+        for (int g = 0; g < GS; ++g) dbs[it][g] = 0.f;
+
     unsigned long long pt[4] = {0, 0, 0, 0};
     const bool prof = p.prof && blockIdx.x == 0 && threadIdx.x == 0;
     for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
@@ -1057,7 +1068,11 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
             if (it_t[it] >= 0) {      // dxw in its GEMM layout: read after the launch only
                 float *dx = p.dxw + (((size_t)it_t[it] * BS + row0 + b) * 2 + dir) * GH + u0 + u;
 #pragma unroll
-                for (int g = 0; g < G; ++g) dx[(size_t)g * H] = GRU && g == 2 ? dxn : dg[g];
+                for (int g = 0; g < G; ++g) {
+                    dx[(size_t)g * H] = GRU && g == 2 ? dxn : dg[g];
+                    dbs[it][g] += GRU && g == 2 ? dxn : dg[g];
+                    if constexpr (GRU) dbs[it][G + g] += dg[g];
+                }
                 if constexpr (GRU) {  // drec: dW_hh and db_hh are GEMMs / column sums of it
                     float *dr = p.drec + (((size_t)it_t[it] * BS + row0 + b) * 2 + dir) * GH + u0 + u;
 #pragma unroll
@@ -1078,6 +1093,31 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                     p.carry[((size_t)dir * B + row0 + item / UPB) * H + u0 + item % UPB] =
                         dc_state[it];
             }
+        }
+    }
+    if (p.dbias) {
+        // sum the items' shares over the rows of the tile(s) through LDS (the reduction scratch
+        // is free now), then one atomic per (unit, gate slot): the other batch tile / block of
+        // rows / launch of the pass adds to the same word
+        if constexpr (CHAINS == 1) __syncthreads();
+        else chain_barrier(cs, bar_epoch, lane);
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * PRNN_THREADS;
+                if (item < 16 * MT * UPB) red[item] = dbs[it][g];
+            }
+            if constexpr (CHAINS == 1) __syncthreads();
+            else chain_barrier(cs, bar_epoch, lane);
+            if (tid < UPB) {
+                float sum = 0.f;
+                for (int r = 0; r < 16 * MT; ++r) sum += red[r * UPB + tid];
+                atomicAdd(p.dbias + (size_t)(g / G) * 2 * GH + ((size_t)dir * G + g % G) * H + u0 +
+                              tid, sum);
+            }
+            if constexpr (CHAINS == 1) __syncthreads();
+            else chain_barrier(cs, bar_epoch, lane);
         }
     }
     if (prof)
@@ -1188,7 +1228,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
     const int ib = tid >> 4, iu = tid & 15;
     const int brow = row0 + ib, unit = u0 + iu;
     const int steps = brow < B ? row_steps(p.seq_len, brow, T) : 0;
-    float dc_state = 0.f;
+    float dc_state = 0.f, dbs[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.s_hi < T && brow < B) dc_state = p.carry[((size_t)dir * B + brow) * H + unit];
 
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
@@ -1257,6 +1297,8 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
             dg[2] = dc * gi * (1.f - gg * gg);
             dg[3] = dh * tc * go * (1.f - go);
             dc_state = dc * gf;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dbs[g] += dg[g];
         }
         // dh of step s - 1 needs these dgates x R; step 0 has nobody to hand them to
         if (s > 0) {
@@ -1305,6 +1347,19 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
         if (prof) { unsigned long long c = wall_clock64(); pt[4] += c - c0; c0 = c; }
     }
     if (p.s_lo > 0 && brow < B) p.carry[((size_t)dir * B + brow) * H + unit] = dc_state;
+    if (p.dbias) {              // bias gradients: sum over the tile's 16 rows, then one atomic
+        if constexpr (CHAINS == 1) __syncthreads();
+        else chain_barrier(cs, bar_epoch, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dgs[ib * PRNN_RS_APITCH + g * 16 + iu] = dbs[g];
+        if constexpr (CHAINS == 1) __syncthreads();
+        else chain_barrier(cs, bar_epoch, lane);
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int r = 0; r < 16; ++r) sum += dgs[r * PRNN_RS_APITCH + tid];
+            atomicAdd(p.dbias + ((size_t)dir * 4 + (tid >> 4)) * H + u0 + (tid & 15), sum);
+        }
+    }
     if (prof) {
         if (blockIdx.x == 0 && lchain == 0)
             for (int i = 0; i < 5; ++i) p.sync->prof[4 + i] = pt[i];
@@ -1513,10 +1568,10 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
 
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
-             const float *cells,
-             float *dxw, float *drec, void *sync, float *carry, int step_begin, int step_end,
-             int flags, hipStream_t s) {
+             const float *cells, float *dxw, float *drec, float *dbias, void *sync,
+             float *carry, int step_begin, int step_end, int flags, hipStream_t s) {
     PArgs p = {};
+    p.dbias = dbias;
     p.s_lo = step_begin; p.s_hi = step_end; p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.w = w_hh_t; p.seq_len = seq_len; p.y = const_cast<float *>(y); p.dy = dy; p.dxw = dxw;

@@ -290,8 +290,8 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
              int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
-             const float *cells, float *dxw, float *drec, void *sync, float *carry,
-             int step_begin, int step_end, int flags, hipStream_t s);
+             const float *cells, float *dxw, float *drec, float *dbias, void *sync,
+             float *carry, int step_begin, int step_end, int flags, hipStream_t s);
 
 // The persistent kernels cover at most 32 rows (two 16-row tiles) per launch: a bigger batch
 // (33..64) runs as consecutive launches over blocks of rows, each block with its own barrier
@@ -419,10 +419,10 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, c
 extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
                                     const float *w_hh_t, const float *b_hh_n,
                                     const int32_t *seq_len, int T, int B, int H,
-                                    const void *reserve, float *dxw, float *db_hh_n,
+                                    const void *reserve, float *dxw, float *dbias,
                                     void *workspace, size_t workspace_bytes, int step_begin,
                                     int step_end, int flags, ctcasr_stream_t stream) {
-    (void)b_hh_n; (void)db_hh_n;   // the GRU bias gradient is the column sum of drec (caller)
+    (void)b_hh_n;
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
@@ -455,7 +455,7 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
             rc = prnn_bwd(cell, dy + b0 * 2 * H, y + b0 * 2 * H, w_hh_t,
                           seq_len ? seq_len + b0 : nullptr, T, prnn_block_rows(B, blk), B, H,
                           p.gates + b0 * 2 * 4 * H, p.cells + b0 * 2 * H, dxw + b0 * 2 * G * H,
-                          p.drec + b0 * 2 * G * H,
+                          p.drec + b0 * 2 * G * H, dbias,
                           reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
                               blk * prnn_block_bytes(T, B, H, G),
                           p.cbuf + b0 * 2 * H, step_begin, step_end, flags, s);
@@ -475,15 +475,25 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
         else
             rnn_bwd_step_kernel<CTCASR_CELL_RNN_TANH><<<grid, RNN_THREADS, 0, s>>>(p);
     }
-    return ctcasr_launch_status();
+    if (ctcasr_launch_status() != CTCASR_OK) return CTCASR_ERR_LAUNCH;
+    // bias gradients (streaming path): column sums over the whole pass once its last range -
+    // the one that ends at step 0 - is through
+    if (dbias && step_begin == 0) {
+        rc = ctcasr_colsum_accumulate(dxw, dbias, (int64_t)T * B, 2 * G * H, stream);
+        if (rc == CTCASR_OK && cell == CTCASR_CELL_GRU)
+            rc = ctcasr_colsum_accumulate(p.drec, dbias + (size_t)2 * G * H, (int64_t)T * B,
+                                          2 * G * H, stream);
+        return rc;
+    }
+    return CTCASR_OK;
 }
 
 extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                               const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
-                              const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                              const void *reserve, float *dxw, float *dbias, void *workspace,
                               size_t workspace_bytes, ctcasr_stream_t stream) {
     return ctcasr_rnn_bwd_steps(cell, dy, y, w_hh_t, b_hh_n, seq_len, T, B, H, reserve, dxw,
-                                db_hh_n, workspace, workspace_bytes, 0, T, CTCASR_RNN_DEFAULT,
+                                dbias, workspace, workspace_bytes, 0, T, CTCASR_RNN_DEFAULT,
                                 stream);
 }
 

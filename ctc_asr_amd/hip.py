@@ -371,13 +371,15 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
 
 
 @_on_tensor_device
-def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, db_hh_n=None,
+def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, dbias=None,
             workspace=None, steps=None, flags=RNN_DEFAULT, ticket=0):
     """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H].
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_bwd_steps`): cut
     a pass into calls covering T..0 in descending order, passing the same ``dxw`` and
-    ``workspace`` to each."""
+    ``workspace`` to each.  ``dbias`` (optional, zeroed by the caller before the pass): the bias
+    gradients are accumulated into it - f32[2*G*H] column sums of dxw, then for the GRU f32[2*3H]
+    column sums of drec - complete after the call that covers step 0."""
     num_steps, batch = dy.shape[0], dy.shape[1]
     hidden = w_hh_t.shape[1]
     gates = CELL_GATES[cell]
@@ -395,7 +397,7 @@ def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, d
         CELL_IDS[cell], _dev(dy, name='dy'), _dev(y, name='y'), _dev(w_hh_t, name='w_hh_t'),
         _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
         hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),
-        _dev(db_hh_n, name='db_hh_n'), _dev(workspace, torch.uint8, 'workspace'),
+        _dev(dbias, name='dbias'), _dev(workspace, torch.uint8, 'workspace'),
         workspace.numel(), int(begin), int(end), int(flags) | (int(ticket) & 0xFFFFFF) << 8,
         _stream()), 'rnn_bwd')
     return dxw

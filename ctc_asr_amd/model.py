@@ -824,11 +824,18 @@ class CTCModel:
                             drec[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
                             y[a + shift:b + shift, :, cols].reshape((b - a) * batch, hidden))
 
+            # the bias gradients - column sums of dxw (GRU: and of drec) - come out of the
+            # recurrence kernels themselves (accumulated into the zeroed arena slices: b_ih, and
+            # for the GRU b_hh right behind it), not out of extra passes over dxw
+            b_start = self.arena.offsets[name + '/b_ih']
+            b_count = 2 * gh * (2 if cell == 'gru' else 1)
+            assert self.arena.offsets[name + '/b_hh'] == b_start + 2 * gh
+            dbias = self.arena.grad[b_start:b_start + b_count]
             bounds = [t_out * (chunks - c) // chunks for c in range(chunks + 1)]   # T ... 0
             for c in range(chunks):
                 hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
-                            dxw=dxw, workspace=acts['rnn_ws'], steps=(bounds[c + 1], bounds[c]),
-                            flags=self.rnn_bwd_flags,
+                            dxw=dxw, dbias=dbias, workspace=acts['rnn_ws'],
+                            steps=(bounds[c + 1], bounds[c]), flags=self.rnn_bwd_flags,
                             ticket=self._take_ticket() if persistent and not whole_chip_rnn
                             else 0)
                 if c + 1 < chunks:
@@ -846,23 +853,15 @@ class CTCModel:
             def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i, chunks=chunks,
                              last=bounds[-2], partial_weight_grads=partial_weight_grads,
                              drec=drec):
-                hip.colsum_accumulate(dxw2d, g[name + '/b_ih'].view(-1))
+                if cell != 'gru':       # (the GRU's db_hh came out of the kernel with db_ih)
+                    g[name + '/b_hh'].copy_(g[name + '/b_ih'])
                 if chunks > 1:          # the earlier launches' shares are already in
                     partial_weight_grads(0, last)
-                    if cell == 'gru':
-                        hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
-                                              g[name + '/b_hh'].view(-1))
-                    else:
-                        g[name + '/b_hh'].copy_(g[name + '/b_ih'])
                     return
                 torch.mm(dxw2d.t(), x.view(rows, -1),
                          out=g[name + '/w_ih'].view(2 * gates * hidden, -1))
-                # gradient w.r.t. the recurrent pre-activations: dxw itself, except for the GRU
-                if cell == 'gru':
-                    hip.colsum_accumulate(drec.view(rows, 2 * gates * hidden),
-                                          g[name + '/b_hh'].view(-1))
-                else:
-                    g[name + '/b_hh'].copy_(g[name + '/b_ih'])
+                # (drec: the gradient w.r.t. the recurrent pre-activations - dxw itself, except for
+                # the GRU)
                 # dW_hh[d] = sum_t drec_t^T h_{t-1}: one GEMM per direction over shifted views
                 if t_out > 1:
                     gh = gates * hidden

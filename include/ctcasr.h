@@ -137,7 +137,13 @@ int ctcasr_ctc_beam_decode(const float *logits, const int32_t *seq_len, int T, i
  * gradients are GEMMs of), w_hh_t = w_hh transposed to [2, H, G*H] (caller keeps it current;
  * ctcasr_transpose_batched does it).  GRU: the recurrent path differs from dxw in the candidate
  * gate (scaled by r); that tensor, drec [T,B,2,3H], is left in `reserve` at
- * ctcasr_rnn_gru_drec_offset(): dW_hh and db_hh are GEMM / column sums of it (db_hh_n: unused). */
+ * ctcasr_rnn_gru_drec_offset(): dW_hh is a GEMM of it.
+ *   dbias    (optional) bias gradients, ACCUMULATED into (caller zeroes them before a pass):
+ *            [2, G*H] column sums of dxw over (t, b) = db_ih, then - GRU only - [2, 3H] column sums
+ *            of drec = db_hh (for the other cells db_hh = db_ih).  Complete once the launch that
+ *            covers step 0 has run (the persistent kernels add each launch's share, the
+ *            streaming path sums the whole pass at its end).  Summation order is not fixed
+ *            (atomics), like ctcasr_colsum_accumulate's. */
 size_t ctcasr_rnn_gru_drec_offset(int T, int B, int H);
 size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H);
 size_t ctcasr_rnn_workspace_bytes(int cell, int T, int B, int H);
@@ -198,7 +204,7 @@ int ctcasr_rnn_resident_gate(void *workspace, size_t workspace_bytes, int cell, 
                              int H, unsigned ticket, int max_wait_us, ctcasr_stream_t stream);
 int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                    const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
-                   const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                   const void *reserve, float *dxw, float *dbias, void *workspace,
                    size_t workspace_bytes, ctcasr_stream_t stream);
 /* Steps [step_begin, step_end) of the backward recurrence only (it walks the steps downwards;
  * step s is time s of the forward direction and time seq_len-1-s of the backward direction).
@@ -208,7 +214,7 @@ int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_
  * the next launch continues the recurrence. */
 int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y, const float *w_hh_t,
                          const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
-                         const void *reserve, float *dxw, float *db_hh_n, void *workspace,
+                         const void *reserve, float *dxw, float *dbias, void *workspace,
                          size_t workspace_bytes, int step_begin, int step_end, int flags,
                          ctcasr_stream_t stream);
 

@@ -185,18 +185,34 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
         assert np.abs((y_half - y).cpu().numpy()).max() < 1e-6
     w_hh_t = hip.transpose_batched(_t(w_hh))
     assert torch.equal(w_hh_t.cpu(), torch.tensor(w_hh).transpose(1, 2).contiguous())
-    dxw = hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, workspace=ws)
+    # ``dbias``: the bias gradients (column sums of dxw over time and batch; GRU: then those of
+    # drec) accumulate inside the recurrence kernels / at the end of the streaming pass
+    gh = gates * hidden
+    dbias = torch.zeros(2 * gh * (2 if cell == 'gru' else 1), device=DEV)
+    dxw = hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, dbias=dbias, workspace=ws)
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     assert np.abs(dxw.cpu().numpy() - xw_t.grad.numpy()).max() < 1e-4
+
+    def bias_sums():
+        want = [dxw.double().sum(dim=(0, 1)).reshape(-1)]
+        if cell == 'gru':
+            want.append(hip.rnn_gru_drec(reserve, num_steps, batch, hidden).double()
+                        .sum(dim=(0, 1)).reshape(-1))
+        return torch.cat(want)
+    want_db = bias_sums()
+    assert float((dbias.double() - want_db).abs().max()) < 1e-4 * max(1.0, float(want_db.abs().max()))
     # the same pass cut into three launches (ctcasr_rnn_bwd_steps) is bit-identical
     if num_steps >= 5:
         cuts = [num_steps, num_steps - 2, num_steps // 2, 0]
         dxw_cut = torch.full_like(dxw, float('nan'))
+        dbias_cut = torch.zeros_like(dbias)
         for hi, lo in zip(cuts[:-1], cuts[1:]):
-            hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, dxw=dxw_cut, workspace=ws,
-                        steps=(lo, hi))
+            hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, dxw=dxw_cut, dbias=dbias_cut,
+                        workspace=ws, steps=(lo, hi))
         hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
         assert torch.equal(dxw_cut, dxw)
+        assert float((dbias_cut.double() - want_db).abs().max()) < \
+            1e-4 * max(1.0, float(want_db.abs().max()))
         with pytest.raises(ValueError):
             hip.rnn_bwd(cell, _t(dy), y, w_hh_t, reserve, sl, steps=(0, 2))
         with pytest.raises(RuntimeError):
@@ -560,8 +576,11 @@ def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengt
     w_hh_t = hip.transpose_batched(w_hh)
     y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh, seq_len)
     ref = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws)
-    got = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws,
+    dbias = torch.zeros(2 * 4 * hidden, device=DEV)
+    got = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws, dbias=dbias,
                       flags=hip.RNN_REDUCE_SCATTER)
+    want_db = got.double().sum(dim=(0, 1)).reshape(-1)
+    assert float((dbias.double() - want_db).abs().max()) < 1e-4 * max(1.0, float(want_db.abs().max()))
     again = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, workspace=ws,
                         flags=hip.RNN_REDUCE_SCATTER)
     hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)

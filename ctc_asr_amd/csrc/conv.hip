@@ -30,6 +30,21 @@
 
 namespace {
 
+// Backward of the fused epilogue min(max(z, 0), cutoff): the gradient passes where the stored
+// OUTPUT lies strictly inside (0, cutoff).  Applied to dz while it is staged, so the backward
+// kernels take the upstream gradient as it is (no elementwise pass in front of them); `act` NULL
+// = dz is the pre-activation gradient already.
+__device__ __forceinline__ float4 mask_dz(float4 g, const float *act, size_t index4, float upper) {
+    if (act) {
+        const float4 v = reinterpret_cast<const float4 *>(act)[index4];
+        g.x = (v.x > 0.f && v.x < upper) ? g.x : 0.f;
+        g.y = (v.y > 0.f && v.y < upper) ? g.y : 0.f;
+        g.z = (v.z > 0.f && v.z < upper) ? g.z : 0.f;
+        g.w = (v.w > 0.f && v.w < upper) ? g.w : 0.f;
+    }
+    return g;
+}
+
 constexpr int CV_CIN = 32;
 constexpr int CV_KT = 11, CV_KF = 21;
 constexpr int CV_PITCH = 36;       // floats per (frame, position) cell of the patch
@@ -188,7 +203,8 @@ conv_fwd_kernel(const float *__restrict__ x, const float4 *__restrict__ wp,
 template <int COUT, int FI>
 __global__ void __launch_bounds__(256)
 conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp,
-                     float *__restrict__ dx, int T, int dz_time_major) {
+                     float *__restrict__ dx, int T, int dz_time_major,
+                     const float *__restrict__ act, float upper) {
     using G = Geometry<COUT, FI>;
     constexpr int PASSES = COUT / 32;           // 32 dz channels staged at a time
     extern __shared__ __attribute__((aligned(16))) float patch[];   // [PT][PF][CV_PITCH]
@@ -222,8 +238,8 @@ conv_bwd_data_kernel(const float *__restrict__ dz, const float4 *__restrict__ wp
             if (ts >= 0 && ts < T && fo >= 0 && fo < G::FO) {
                 const size_t cell = dz_time_major ? (size_t)ts * gridDim.y + b
                                                   : (size_t)b * T + ts;
-                v = reinterpret_cast<const float4 *>(dz)[(cell * G::FO + fo) * (COUT / 4) +
-                                                         pass * 8 + c4];
+                const size_t at = (cell * G::FO + fo) * (COUT / 4) + pass * 8 + c4;
+                v = mask_dz(reinterpret_cast<const float4 *>(dz)[at], act, at, upper);
             }
             patch4[((pr * G::PF + pos) * CV_PITCH) / 4 + c4] = v;
         }
@@ -293,14 +309,14 @@ int launch_fwd(const float *x, const float *packed, const float *bias, float *y,
 
 template <int COUT, int FI>
 int launch_bwd(const float *dz, const float *packed, float *dx, int B, int T, int dz_time_major,
-               hipStream_t s) {
+               const float *act, float upper, hipStream_t s) {
     using G = Geometry<COUT, FI>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bwd_data_kernel<COUT, FI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
         return CTCASR_ERR_LAUNCH;
     dim3 grid((T + G::TT - 1) / G::TT, B);
     conv_bwd_data_kernel<COUT, FI><<<grid, 256, G::LDS, s>>>(
-        dz, reinterpret_cast<const float4 *>(packed), dx, T, dz_time_major);
+        dz, reinterpret_cast<const float4 *>(packed), dx, T, dz_time_major, act, upper);
     return ctcasr_launch_status();
 }
 
@@ -346,7 +362,8 @@ struct WrwGeometry {
 template <int FI>
 __global__ void __launch_bounds__(256, 2)
 conv_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
-                float *__restrict__ partial, int B, int T, int cout, int dz_time_major) {
+                float *__restrict__ partial, int B, int T, int cout, int dz_time_major,
+                const float *__restrict__ act, float upper, float *__restrict__ dbias) {
     using G = WrwGeometry<FI>;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *dzs = wsm;                                   // [WR_ROWS][WR_DZP]
@@ -362,6 +379,10 @@ conv_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
     for (int kf = 0; kf < CV_KF; ++kf) acc[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 rdz[G::DZ_PER], rx[G::X_PER];
+    // bias gradient = column sums of the (masked) dz: every dz element is staged by the 11
+    // workgroups of its kt rows, the kt = 0 ones add it up (thread: channels 4 c4 .. 4 c4 + 3)
+    const bool sum_bias = dbias != nullptr && kt == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int tile) {                 // global -> registers (zeros outside the tensor)
         const int b = tile / tiles_per_b, t0 = (tile % tiles_per_b) * G::TT;
 #pragma unroll
@@ -371,8 +392,11 @@ conv_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
             rdz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < G::DZ4 && t < T) {
                 const size_t cell = dz_time_major ? (size_t)t * B + b : (size_t)b * T + t;
-                rdz[j] = *reinterpret_cast<const float4 *>(
-                    dz + (cell * G::FO + fo) * cout + cg * 32 + 4 * c4);
+                const size_t at = ((cell * G::FO + fo) * cout + cg * 32 + 4 * c4) / 4;
+                rdz[j] = mask_dz(reinterpret_cast<const float4 *>(dz)[at], act, at, upper);
+                if (sum_bias) {
+                    bsum.x += rdz[j].x; bsum.y += rdz[j].y; bsum.z += rdz[j].z; bsum.w += rdz[j].w;
+                }
             }
         }
 #pragma unroll
@@ -417,6 +441,16 @@ conv_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
 #pragma unroll
             for (int kf = 0; kf < CV_KF; ++kf)
                 acc[kf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[kf * WR_XP], acc[kf], 0, 0, 0);
+        }
+    }
+    if (sum_bias) {      // 32 threads per c4: fold them through LDS, one atomic per channel
+        __syncthreads();
+        reinterpret_cast<float4 *>(wsm)[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float sum = 0.f;
+            for (int r = 0; r < 32; ++r) sum += wsm[(r * 8 + (tid >> 2)) * 4 + (tid & 3)];
+            atomicAdd(dbias + cg * 32 + tid, sum);
         }
     }
     // D[m = 4 g + r][n]: co = co_tile * 16 + 4 g + r, ci = ci_tile * 16 + n
@@ -465,9 +499,11 @@ extern "C" size_t ctcasr_conv_s12_wrw_workspace_bytes(int B, int T, int freq_in,
 // dz [B, T, freq_in / 2, cout], x [B, T, freq_in, 32] (both NHWC) -> dw [cout, 32, 11, 21]
 // (overwritten); deterministic (fixed summation order).
 extern "C" int ctcasr_conv_s12_wrw(const float *dz, const float *x, float *dw, int B, int T,
-                                   int freq_in, int cout, int dz_time_major, void *workspace,
+                                   int freq_in, int cout, int dz_time_major, const float *act,
+                                   float relu_cutoff, float *dbias, void *workspace,
                                    size_t workspace_bytes, ctcasr_stream_t stream) {
-    if (!dz || !x || !dw || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!dz || !x || !dw || B <= 0 || T <= 0 || (act && relu_cutoff <= 0.f))
+        return CTCASR_ERR_BAD_ARGUMENT;
     if (!covered(freq_in, cout)) return CTCASR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ctcasr_conv_s12_wrw_workspace_bytes(B, T, freq_in, cout))
         return CTCASR_ERR_WORKSPACE;
@@ -480,15 +516,15 @@ extern "C" int ctcasr_conv_s12_wrw(const float *dz, const float *x, float *dw, i
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WrwGeometry<40>::LDS) != hipSuccess)
             return CTCASR_ERR_LAUNCH;
-        conv_wrw_kernel<40><<<grid, 256, WrwGeometry<40>::LDS, s>>>(dz, x, partial, B, T, cout,
-                                                                    dz_time_major);
+        conv_wrw_kernel<40><<<grid, 256, WrwGeometry<40>::LDS, s>>>(
+            dz, x, partial, B, T, cout, dz_time_major, act, relu_cutoff, dbias);
     } else {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wrw_kernel<20>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WrwGeometry<20>::LDS) != hipSuccess)
             return CTCASR_ERR_LAUNCH;
-        conv_wrw_kernel<20><<<grid, 256, WrwGeometry<20>::LDS, s>>>(dz, x, partial, B, T, cout,
-                                                                    dz_time_major);
+        conv_wrw_kernel<20><<<grid, 256, WrwGeometry<20>::LDS, s>>>(
+            dz, x, partial, B, T, cout, dz_time_major, act, relu_cutoff, dbias);
     }
     const int total = cout * CV_CIN * CV_KT * CV_KF;
     conv_wrw_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, dw, nsplit, cout);
@@ -524,12 +560,15 @@ extern "C" int ctcasr_conv_s12_fwd(const float *x, const float *packed, const fl
 // -> dx [B, T, freq_in, 32].
 extern "C" int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B,
                                         int T, int freq_in, int cout, int dz_time_major,
+                                        const float *act, float relu_cutoff,
                                         ctcasr_stream_t stream) {
-    if (!dz || !packed || !dx || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!dz || !packed || !dx || B <= 0 || T <= 0 || (act && relu_cutoff <= 0.f))
+        return CTCASR_ERR_BAD_ARGUMENT;
     if (!covered(freq_in, cout) || B > 65535) return CTCASR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (cout == 32) return launch_bwd<32, 40>(dz, packed, dx, B, T, dz_time_major, s);
-    return launch_bwd<96, 20>(dz, packed, dx, B, T, dz_time_major, s);
+    if (cout == 32)
+        return launch_bwd<32, 40>(dz, packed, dx, B, T, dz_time_major, act, relu_cutoff, s);
+    return launch_bwd<96, 20>(dz, packed, dx, B, T, dz_time_major, act, relu_cutoff, s);
 }
 
 // =============================================================================================
@@ -659,7 +698,8 @@ constexpr int C0_DW = C0_CO * C0_KT * C0_KF;     // 14432 floats
 
 __global__ void __launch_bounds__(256)
 conv0_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
-                 float *__restrict__ partial, int T, int t_out, int pt0) {
+                 float *__restrict__ partial, int T, int t_out, int pt0,
+                 const float *__restrict__ act, float upper, float *__restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) float smem0[];
     float *patch = smem0;                               // [C0_PT][C0_PW2]
     float *dzl = smem0 + C0_PT * C0_PW2;                // [640 positions][C0_DZP]
@@ -667,19 +707,32 @@ conv0_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
     const int t0 = blockIdx.x * C0_TT, b = blockIdx.y;
     const int kg = lane >> 4, n = lane & 15;
 
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);       // (thread: channels 4 c4 .. 4 c4 + 3)
+    for (int i = tid; i < C0_TT * C0_FO * 8; i += 256) {
+        const int c4 = i & 7, pos = i >> 3, t = t0 + pos / C0_FO;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < t_out) {
+            const size_t at = ((size_t)(b * t_out + t) * C0_FO + pos % C0_FO) * 8 + c4;
+            v = mask_dz(reinterpret_cast<const float4 *>(dz)[at], act, at, upper);
+        }
+        bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+        *reinterpret_cast<float4 *>(dzl + pos * C0_DZP + 4 * c4) = v;
+    }
+    if (dbias) {         // bias gradient: every dz element is staged exactly once, by this kernel
+        reinterpret_cast<float4 *>(patch)[tid] = bsum;     // (scratch: the x patch comes next)
+        __syncthreads();
+        if (tid < 32) {
+            float sum = 0.f;
+            for (int r = 0; r < 32; ++r) sum += patch[(r * 8 + (tid >> 2)) * 4 + (tid & 3)];
+            atomicAdd(dbias + tid, sum);
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < C0_PT * C0_PW2; i += 256) {
         const int col = i % C0_PW2, pr = i / C0_PW2;
         const int ts = 2 * t0 - pt0 + pr, fi = col - 19;
         patch[i] = (ts >= 0 && ts < T && fi >= 0 && fi < C0_FI)
                        ? x[((size_t)b * T + ts) * C0_FI + fi] : 0.f;
-    }
-    for (int i = tid; i < C0_TT * C0_FO * 8; i += 256) {
-        const int c4 = i & 7, pos = i >> 3, t = t0 + pos / C0_FO;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < t_out)
-            v = reinterpret_cast<const float4 *>(dz)[((size_t)(b * t_out + t) * C0_FO +
-                                                      pos % C0_FO) * 8 + c4];
-        *reinterpret_cast<float4 *>(dzl + pos * C0_DZP + 4 * c4) = v;
     }
     __syncthreads();
 
@@ -756,8 +809,10 @@ extern "C" size_t ctcasr_conv0_wrw_workspace_bytes(int B, int T) {
 
 // dz [B, ceil(T/2), 40, 32] (NHWC), x [B, T, 80] -> dw [32, 1, 11, 41] (overwritten).
 extern "C" int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T,
+                                const float *act, float relu_cutoff, float *dbias,
                                 void *workspace, size_t workspace_bytes, ctcasr_stream_t stream) {
-    if (!dz || !x || !dw || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (!dz || !x || !dw || B <= 0 || T <= 0 || (act && relu_cutoff <= 0.f))
+        return CTCASR_ERR_BAD_ARGUMENT;
     if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ctcasr_conv0_wrw_workspace_bytes(B, T))
         return CTCASR_ERR_WORKSPACE;
@@ -771,7 +826,8 @@ extern "C" int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((t_out + C0_TT - 1) / C0_TT, B);
     float *partial = reinterpret_cast<float *>(workspace);
-    conv0_wrw_kernel<<<grid, 256, C0_WRW_LDS, s>>>(dz, x, partial, T, t_out, pt0);
+    conv0_wrw_kernel<<<grid, 256, C0_WRW_LDS, s>>>(dz, x, partial, T, t_out, pt0, act,
+                                                   relu_cutoff, dbias);
     const int parts = (int)(grid.x * grid.y);
     float *bands = partial + (size_t)parts * C0_DW;
     conv0_wrw_reduce_kernel<<<dim3((C0_DW + 255) / 256, C0_BANDS), 256, 0, s>>>(partial, bands, parts);

@@ -59,12 +59,14 @@ SIGNATURES = {
     'ctcasr_conv_s12_supported': (_c_int, [_c_int, _c_int]),
     'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
     'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_f, _c_int, _c_p]),
-    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p]),
+    'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
     'ctcasr_conv_s12_wrw_workspace_bytes': (_c_sz, [_c_int] * 4),
-    'ctcasr_conv_s12_wrw': (_c_int, [_c_p] * 3 + [_c_int] * 5 + [_c_p, _c_sz, _c_p]),
+    'ctcasr_conv_s12_wrw': (_c_int, [_c_p] * 3 + [_c_int] * 5 + [_c_p, _c_f, _c_p] +
+                            [_c_p, _c_sz, _c_p]),
     'ctcasr_conv0_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p]),
     'ctcasr_conv0_wrw_workspace_bytes': (_c_sz, [_c_int, _c_int]),
-    'ctcasr_conv0_wrw': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_sz, _c_p]),
+    'ctcasr_conv0_wrw': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_f, _c_p, _c_p, _c_sz,
+                                  _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
@@ -486,8 +488,10 @@ def conv_s12_fwd(x, packed, cout, bias=None, out=None, relu_cutoff=0.0, time_maj
 
 
 @_on_tensor_device
-def conv_s12_bwd_data(dz, packed, out=None, time_major=False):
-    """dz f32[B,T,F/2,cout] (NHWC; ``time_major``: [T,B,F/2,cout]) -> dx f32[B,T,F,32]."""
+def conv_s12_bwd_data(dz, packed, out=None, time_major=False, act=None, relu_cutoff=0.0):
+    """dz f32[B,T,F/2,cout] (NHWC; ``time_major``: [T,B,F/2,cout]) -> dx f32[B,T,F,32].
+    ``act`` (the layer's stored output, same layout): dz is the gradient w.r.t. that output and
+    the mask of min(max(., 0), relu_cutoff) is applied while dz is staged."""
     if time_major:
         frames, batch, freq_out, cout = dz.shape
     else:
@@ -500,14 +504,17 @@ def conv_s12_bwd_data(dz, packed, out=None, time_major=False):
         _check(load().ctcasr_conv_s12_bwd_data(_dev(dz, name='dz'), _dev(packed, name='packed'),
                                                _dev(out, name='dx'), batch, frames,
                                                2 * freq_out, cout, 1 if time_major else 0,
+                                               _dev(act, name='act'), float(relu_cutoff),
                                                _stream()), 'conv_s12_bwd_data')
     return out
 
 
 @_on_tensor_device
-def conv_s12_wrw(dz, x, out=None, time_major=False):
+def conv_s12_wrw(dz, x, out=None, time_major=False, act=None, relu_cutoff=0.0, dbias=None):
     """Kernel gradient of the same layer: dz f32[B,T,F/2,cout] (``time_major``: [T,B,F/2,cout]),
-    x f32[B,T,F,32] (NHWC) -> dw f32[cout,32,11,21]."""
+    x f32[B,T,F,32] (NHWC) -> dw f32[cout,32,11,21].  ``act`` / ``relu_cutoff``: see
+    `conv_s12_bwd_data`; ``dbias`` f32[cout] (zeroed by the caller) then receives the bias
+    gradient, the column sums of the masked dz."""
     if time_major:
         frames, batch, freq_out, cout = dz.shape
     else:
@@ -524,7 +531,8 @@ def conv_s12_wrw(dz, x, out=None, time_major=False):
     with _Timed('conv_s12_wrw'):
         _check(load().ctcasr_conv_s12_wrw(_dev(dz, name='dz'), _dev(x, name='x'),
                                           _dev(out, name='dw'), batch, frames, 2 * freq_out, cout,
-                                          1 if time_major else 0,
+                                          1 if time_major else 0, _dev(act, name='act'),
+                                          float(relu_cutoff), _dev(dbias, name='dbias'),
                                           _dev(workspace, torch.uint8, 'workspace'),
                                           workspace.numel(), _stream()), 'conv_s12_wrw')
     return out
@@ -548,9 +556,10 @@ def conv0_fwd(x, weight, bias=None, out=None, relu_cutoff=0.0):
 
 
 @_on_tensor_device
-def conv0_wrw(dz, x, out=None):
+def conv0_wrw(dz, x, out=None, act=None, relu_cutoff=0.0, dbias=None):
     """Kernel gradient of the first DS2 convolution: dz f32[B,ceil(T/2),40,32] (NHWC),
-    x f32[B,T,80] -> dw f32[32,1,11,41]."""
+    x f32[B,T,80] -> dw f32[32,1,11,41]; ``act`` / ``relu_cutoff`` / ``dbias`` as in
+    `conv_s12_wrw`."""
     batch, frames = x.shape[0], x.shape[1]
     if x.shape[2] != 80 or tuple(dz.shape) != (batch, (frames + 1) // 2, 40, 32):
         raise CtcAsrError('conv0_wrw covers x [B,T,80], dz [B,ceil(T/2),40,32] only.')
@@ -559,7 +568,8 @@ def conv0_wrw(dz, x, out=None):
     workspace = _workspace(load().ctcasr_conv0_wrw_workspace_bytes(batch, frames), x.device)
     with _Timed('conv0_wrw'):
         _check(load().ctcasr_conv0_wrw(_dev(dz, name='dz'), _dev(x, name='x'),
-                                       _dev(out, name='dw'), batch, frames,
+                                       _dev(out, name='dw'), batch, frames, _dev(act, name='act'),
+                                       float(relu_cutoff), _dev(dbias, name='dbias'),
                                        _dev(workspace, torch.uint8, 'workspace'),
                                        workspace.numel(), _stream()), 'conv0_wrw')
     return out

@@ -317,6 +317,8 @@ class CTCModel:
         # (forward, data gradient, kernel gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
         self._conv_packed = {}          # layer -> fragment-ordered weight copies
+        # backward of the conv epilogue (mask + bias gradient) inside the gradient kernels
+        self.conv_fused_bwd = os.environ.get('CTCASR_CONV_FUSED_BWD', '1') == '1'
         # Side-stream work that should run BESIDE a half-chip persistent recurrence launch waits
         # behind a residency gate: the launch posts a ticket once all its workgroups hold their
         # CUs, a one-lane gate kernel on the side stream waits for it (at most this long; 0
@@ -906,33 +908,44 @@ class CTCModel:
             for i in range(len(cfg.conv_filters) - 1, -1, -1):
                 name = 'conv{}'.format(i)
                 tm = acts['last_time_major'] and i == len(cfg.conv_filters) - 1
-                # the bias gradient (sum of dz over batch, time and frequency) falls out of the
-                # epilogue's backward pass: channels are the columns of the [.., F, C] view
                 out_phys = conv_out[i] if tm else conv_out[i].permute(0, 2, 3, 1)
-                dz = hip.bias_act_bwd(out_phys, dact, cfg.relu_cutoff,
-                                      cfg.conv_dropout_rate, g[name + '/bias'])
-                if not tm:
-                    dz = dz.permute(0, 3, 1, 2)    # logical NCHW view of the NHWC storage
+                own = acts['conv_own'][i]
+                # Own kernels, no conv dropout: the epilogue's backward pass - the mask of
+                # min(max(., 0), cutoff) and the bias gradient - happens inside the gradient
+                # kernels while they stage dz (round 3; before: an elementwise pass per layer)
+                fused_bwd = (self.conv_fused_bwd and own is not None and
+                             cfg.conv_dropout_rate == 0.0)
+                if fused_bwd:
+                    dz = dact if tm else dact.permute(0, 3, 1, 2)
+                    mask = dict(act=out_phys, relu_cutoff=cfg.relu_cutoff)
+                else:
+                    # the bias gradient (sum of dz over batch, time and frequency) falls out of
+                    # the epilogue's backward pass: channels are the columns of the [.., F, C] view
+                    dz = hip.bias_act_bwd(out_phys, dact, cfg.relu_cutoff,
+                                          cfg.conv_dropout_rate, g[name + '/bias'])
+                    if not tm:
+                        dz = dz.permute(0, 3, 1, 2)    # logical NCHW view of the NHWC storage
+                    mask = {}
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
-                # the 11x21 / stride (1,2) / 32->32 layer has its own data-gradient kernel
-                # (implicit GEMM, any T, no padded intermediates: 0.62 ms vs 1.6 ms at C2)
-                if acts['conv_own'][i] == 'conv0':
+                if own == 'conv0':
                     # first layer: kernel gradient straight from the features, no padded copy
                     hip.conv0_wrw(dz.permute(0, 2, 3, 1), acts['features'],
-                                  out=g[name + '/kernel'])
+                                  out=g[name + '/kernel'],
+                                  dbias=g[name + '/bias'] if fused_bwd else None, **mask)
                     done(name)
                     continue
                 conv_in = acts['conv_in'][i]
-                if acts['conv_own'][i] == 's12':
+                if own == 's12':
                     # own kernels: kernel gradient straight from the unpadded NHWC input
                     # (deterministic two-stage reduction), then the data gradient (weights were
                     # packed by the forward pass of this step)
                     dz_phys = dz if tm else dz.permute(0, 2, 3, 1)
                     hip.conv_s12_wrw(dz_phys, conv_in.permute(0, 2, 3, 1), out=g[name + '/kernel'],
-                                     time_major=tm)
+                                     time_major=tm,
+                                     dbias=g[name + '/bias'] if fused_bwd else None, **mask)
                     if i > 0:
                         dact = hip.conv_s12_bwd_data(dz_phys, self._conv_packed[i],
-                                                     time_major=tm)
+                                                     time_major=tm, **mask)
                     done(name)
                     continue
                 need_dx = i > 0

@@ -259,14 +259,22 @@ int ctcasr_conv_s12_pack_weights(const float *w, float *packed, int cout, ctcasr
 int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
                         int T, int freq_in, int cout, float relu_cutoff, int y_time_major,
                         ctcasr_stream_t stream);
+/* Backward of the fused epilogue (round 3): `act` != NULL is the layer's stored OUTPUT (same
+ * layout as dz) and `dz` the gradient w.r.t. that output - the kernels apply the mask
+ * [0 < act < relu_cutoff] while they stage dz, so no elementwise pass runs in front of them; the
+ * wrw kernels then also ADD the bias gradient (column sums of the masked dz over b, t, f) to
+ * dbias[cout] when it is non-NULL (caller zeroes it; atomics: summation order not fixed).
+ * `act` NULL: dz is the pre-activation gradient already (relu_cutoff ignored). */
 int ctcasr_conv_s12_bwd_data(const float *dz, const float *packed, float *dx, int B, int T,
-                             int freq_in, int cout, int dz_time_major, ctcasr_stream_t stream);
+                             int freq_in, int cout, int dz_time_major, const float *act,
+                             float relu_cutoff, ctcasr_stream_t stream);
 /*   wrw: dz [B, T, freq_in/2, cout], x [B, T, freq_in, 32] -> dw [cout, 32, 11, 21] (overwritten):
  *        the kernel gradient, split over (b, t) tiles with a deterministic two-stage reduction;
  *        workspace: per-split partial sums, ctcasr_conv_s12_wrw_workspace_bytes(B, T, freq_in, cout) */
 size_t ctcasr_conv_s12_wrw_workspace_bytes(int B, int T, int freq_in, int cout);
 int ctcasr_conv_s12_wrw(const float *dz, const float *x, float *dw, int B, int T, int freq_in,
-                        int cout, int dz_time_major, void *workspace, size_t workspace_bytes,
+                        int cout, int dz_time_major, const float *act, float relu_cutoff,
+                        float *dbias, void *workspace, size_t workspace_bytes,
                         ctcasr_stream_t stream);
 
 /* ---- the first DS2 convolution: 1 -> 32 channels, 11 x 41 taps, stride (2, 2), SAME padding ----
@@ -276,8 +284,9 @@ int ctcasr_conv0_fwd(const float *x, const float *w, const float *bias, float *y
 /*   wrw: dz [B, ceil(T/2), 40, 32] (NHWC), x [B, T, 80] -> dw [32, 1, 11, 41] (overwritten);
  *        workspace: per-workgroup partial sums, ctcasr_conv0_wrw_workspace_bytes(B, T) */
 size_t ctcasr_conv0_wrw_workspace_bytes(int B, int T);
-int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T, void *workspace,
-                     size_t workspace_bytes, ctcasr_stream_t stream);
+int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T, const float *act,
+                     float relu_cutoff, float *dbias, void *workspace, size_t workspace_bytes,
+                     ctcasr_stream_t stream);
 
 /* out[n][c][r] = in[n][r][c] for n < batch (weight re-layouts, e.g. w_hh -> w_hh_t). */
 int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,

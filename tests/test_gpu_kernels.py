@@ -488,6 +488,28 @@ def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
     ref_w = w64.grad.numpy()
     assert tuple(dw.shape) == ref_w.shape
     assert np.abs(dw.cpu().numpy() - ref_w).max() < 2e-4 * max(1.0, np.abs(ref_w).max())
+    # backward of the fused epilogue inside the gradient kernels (`act` = the stored output of
+    # min(max(., 0), cutoff), dz = the gradient w.r.t. that output): identical to masking dz
+    # first (`bias_act_bwd`), and the bias gradient comes out of the kernel-gradient kernel
+    act = _t(y_act)
+    dbias_ref = torch.zeros(cout, device=DEV)
+    masked = hip.bias_act_bwd(act, _t(dz), 1.5, 0.0, dbias_ref)
+    assert 0.05 < float((masked != 0).float().mean()) < 0.95
+    dbias = torch.zeros(cout, device=DEV)
+    assert torch.equal(hip.conv_s12_wrw(_t(dz), _t(x_np), act=act, relu_cutoff=1.5, dbias=dbias),
+                       hip.conv_s12_wrw(masked, _t(x_np)))
+    assert float((dbias - dbias_ref).abs().max()) < 1e-4 * max(1.0, float(dbias_ref.abs().max()))
+    assert torch.equal(hip.conv_s12_bwd_data(_t(dz), packed, act=act, relu_cutoff=1.5),
+                       hip.conv_s12_bwd_data(masked, packed))
+    act_tm = act.permute(1, 0, 2, 3).contiguous()
+    dbias_tm = torch.zeros(cout, device=DEV)
+    assert torch.equal(hip.conv_s12_wrw(dz_tm, _t(x_np), time_major=True, act=act_tm,
+                                        relu_cutoff=1.5, dbias=dbias_tm),
+                       hip.conv_s12_wrw(masked, _t(x_np)))
+    assert float((dbias_tm - dbias_ref).abs().max()) < 1e-4 * max(1.0, float(dbias_ref.abs().max()))
+    assert torch.equal(hip.conv_s12_bwd_data(dz_tm, packed, time_major=True, act=act_tm,
+                                             relu_cutoff=1.5),
+                       hip.conv_s12_bwd_data(masked, packed))
 
 
 @pytest.mark.parametrize('shape', [(1, 1), (2, 9), (2, 10), (3, 64), (2, 131), (1, 999), (1, 1000)])
@@ -522,6 +544,14 @@ def test_conv0_fwd_matches_the_library_convolution(hip, shape):
     ref_dw = w64.grad.numpy()
     assert dw.shape == ref_dw.shape
     assert np.abs(dw - ref_dw).max() < 2e-4 * max(1.0, np.abs(ref_dw).max())
+    # backward of the fused epilogue inside the kernel (mask from the stored output + bias sums)
+    act = _t(y_act)
+    dbias_ref = torch.zeros(32, device=DEV)
+    masked = hip.bias_act_bwd(act, _t(dz), 0.7, 0.0, dbias_ref)
+    dbias = torch.zeros(32, device=DEV)
+    assert torch.equal(hip.conv0_wrw(_t(dz), _t(x_np), act=act, relu_cutoff=0.7, dbias=dbias),
+                       hip.conv0_wrw(masked, _t(x_np)))
+    assert float((dbias - dbias_ref).abs().max()) < 1e-4 * max(1.0, float(dbias_ref.abs().max()))
 
 
 def test_beam_search_random_sweep_against_the_oracle(hip):

@@ -105,7 +105,12 @@ def main(src, workload, out_md):
            '(`rnn_kernel_events`): **{} us** per launch unprofiled, {} us in the profiled run '
            '(kernel trace row below).\n'.format(line['roofline']['avg_launch_us'],
                                                 kt_line['roofline']['avg_launch_us']),
-           '## Kernel trace, steady state\n\n' + read('kt.md'),
+           '## Kernel trace, steady state\n\n' + read('kt.md') +
+           '\n(`resident_gate_kernel`: a one-lane gate on the side stream, spin bounded at 300 us.  '
+           'Its interval in the trace starts when the queue reaches its packet, so a gate that '
+           'sits behind a `hipStreamWaitEvent` on the main stream shows the wait for that event - '
+           'the 3.4 ms entries coincide with the 3.9 ms data-gradient GEMM of the main stream in '
+           'the timeline below - the others take 5 - 9 us.)\n',
            '\n## PMC FETCH_SIZE (KB per dispatch, as reported)\n\n' + read('fetch.md'),
            '\n## PMC WRITE_SIZE (KB per dispatch, as reported)\n\n' + read('write.md'),
            '\n## Traffic and MFMA-busy of the recurrence kernels\n\n' + '\n\n'.join(traffic_text) +

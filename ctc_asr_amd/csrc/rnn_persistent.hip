@@ -767,10 +767,12 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
                         smem + (size_t)4 * QL * SLOTS * sizeof(float4) +
                         (size_t)CHAINS * RED_FLOATS * sizeof(float)) + lchain;
     unsigned bar_epoch = 0, arrivals = 0;
-    // Two chains left alone run in lockstep (both wait, then both want the matrix pipe, sharing
-    // it 50:50 - measured 8.5 us per forward step against 7.3 with one barrier): a static
-    // priority for chain 0 lets it through first, after which the chains stay out of phase and
-    // each one's exchange round trip hides behind the other's MFMAs.
+    // Two chains: a static priority for chain 0 (left alone they start in lockstep).  Round 3
+    // tried explicit MFMA turns here as well (the LDS lock of the reduce-scatter kernel around
+    // the loads + MFMA loop): 11.8 us per step against 11.0 without at B = 32 (GRU 10.3 / 9.7,
+    // RNN-2048 11.45 / 11.40) - with the matrix pipe to itself a chain's loads + MFMA phase still
+    // takes 5.8 us: this kernel is bound by the A-operand loads in flight (two batches of 16 KB
+    // per wave at ~2 us of latency), not by the two chains sharing the pipe.
     if constexpr (CHAINS > 1) {
         if (chain == 0) __builtin_amdgcn_s_setprio(PRNN_CHAIN0_PRIO);
     }

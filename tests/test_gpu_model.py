@@ -64,11 +64,16 @@ def test_gradients_through_the_persistent_recurrence(chunks):
 
 @pytest.mark.parametrize('case,hidden,batch', [('ds2_gru', 1024, 2), ('ds2_gru', 2048, 3),
                                                ('ds2_lstm_2conv', 2048, 2),
-                                               ('ds2_lstm_2conv', 1024, 19)])
+                                               ('ds2_lstm_2conv', 1024, 19),
+                                               # 33..64 rows: two persistent launches per pass
+                                               # over blocks of 32 and 8 rows
+                                               ('ds2_lstm_2conv', 1024, 40)])
 def test_gradients_through_the_other_persistent_kernels(case, hidden, batch):
     """Whole-model parity (logits, loss, every gradient) for the shapes that take the round-2
     persistent kernels: GRU at H = 1024 / 2048, the LSTM at H = 2048 (one direction per launch),
-    and a batch of 19 rows (two 16-row tiles with their own barriers)."""
+    a batch of 19 rows (two 16-row tiles with their own barriers) and one of 40 rows (blocks of
+    32 + 8 rows, each with its own barrier words / exchange buffer / carry; backward in step
+    ranges with the weight gradients on the side stream)."""
     from ctc_asr_amd import hip
     cell = 'gru' if 'gru' in case else 'lstm'
     # (the fp64 CPU oracle dominates the run time: fewer frames for the H = 2048 models)

@@ -177,3 +177,33 @@ def test_the_ds2_model_memorises_a_small_batch():
     losses, greedy_hits, beam_hits, batch = module.run(steps=400, verbose=False)
     assert losses[0] > 100.0 and losses[-1] < 0.5, losses
     assert greedy_hits == batch and beam_hits == batch
+
+
+def test_deferred_checks_still_raise_where_tensorflow_raises():
+    """`Trainer.train_step(check=True)` does not stall the host on the CTC status words any more
+    (ADVICE r02): an infeasible alignment - more labels than frames, where ``tf.nn.ctc_loss``
+    raises InvalidArgumentError (asr/model.py:259) - surfaces at most `max_steps_ahead` steps
+    later or at `drain_checks()`, names the step, and never passes a drain (= never reaches a
+    checkpoint)."""
+    from ctc_asr_amd.engine import Trainer
+    from ctc_asr_amd.model import InfeasibleAlignmentError, ModelConfig
+    cfg = ModelConfig(used_model='ds2', conv_filters=(4, 4), num_units_dense=32, num_layers_rnn=1,
+                      num_units_rnn=64, rnn_cell='lstm', cudnn=True, dense_dropout_rate=0.0)
+    trainer = Trainer(cfg, device='cuda', seed=3)
+    rng = np.random.default_rng(3)
+    feats = torch.tensor(rng.normal(size=(2, 21, 80)).astype(np.float32))      # T' = 11
+    flen = torch.tensor([21, 21], dtype=torch.int32)
+    good = [[1, 2, 3], [4, 5]]
+    bad = [[1, 2, 3], list(range(1, 14))]                                      # 13 labels > 11
+    trainer.train_step(feats, flen, good)
+    trainer.drain_checks()
+    trainer.train_step(feats, flen, bad)            # does not raise here: the check is deferred
+    with pytest.raises(InfeasibleAlignmentError, match=r'batch rows \[1\].*training step 2'):
+        trainer.drain_checks()
+    trainer.drain_checks()                          # reported once
+    # without a drain the error surfaces from a later train_step, within max_steps_ahead + 1
+    trainer.train_step(feats, flen, bad)
+    with pytest.raises(InfeasibleAlignmentError):
+        for _ in range(trainer.max_steps_ahead + 1):
+            trainer.train_step(feats, flen, good)
+            torch.cuda.synchronize()

@@ -39,7 +39,12 @@ __global__ void __launch_bounds__(FEAT_THREADS)
 frame_features_kernel(const int16_t *__restrict__ pcm, const int *__restrict__ num_samples,
                       int n_max, int t_max, int mfcc, const FeatTables *__restrict__ tab,
                       float *__restrict__ raw32, double *__restrict__ cep64) {
-    __shared__ double re[FEAT_NFFT], im[FEAT_NFFT];
+    // The frame is real: its 1024-point spectrum comes out of ONE 512-point complex FFT of
+    // z[n] = x[2n] + i x[2n+1] (9 stages of 256 butterflies - one per thread - instead of 10 of
+    // 512) and an unpacking pass  X[k] = E[k] + W^k O[k]  with  E = (Z[k] + conj Z[512-k]) / 2,
+    // O = (Z[k] - conj Z[512-k]) / 2i.
+    __shared__ double re[FEAT_NFFT / 2 + 1], im[FEAT_NFFT / 2 + 1];
+    __shared__ double pw[FEAT_BINS];
     __shared__ double logmel[FEAT_NFILT];
     __shared__ double wsum[FEAT_THREADS / 64];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -47,36 +52,45 @@ frame_features_kernel(const int16_t *__restrict__ pcm, const int *__restrict__ n
     const int frames = n <= FEAT_FRAME ? 1 : 1 + (n - FEAT_FRAME + FEAT_STEP - 1) / FEAT_STEP;
     if (t >= frames) return;
     const int16_t *x = pcm + (size_t)b * n_max;
-    for (int i = tid; i < FEAT_NFFT; i += FEAT_THREADS) {
-        double v = 0.0;
+    auto sample = [&](int i) -> double {          // pre-emphasised sample i of the frame
         const int g = t * FEAT_STEP + i;
-        if (i < FEAT_FRAME && g < n)
-            v = g == 0 ? (double)x[0] : (double)x[g] - 0.97 * (double)x[g - 1];
-        const unsigned r = bitrev10((unsigned)i);
-        re[r] = v;
-        im[r] = 0.0;
+        if (i >= FEAT_FRAME || g >= n) return 0.0;
+        return g == 0 ? (double)x[0] : (double)x[g] - 0.97 * (double)x[g - 1];
+    };
+    for (int i = tid; i < FEAT_NFFT / 2; i += FEAT_THREADS) {
+        const unsigned r = __brev((unsigned)i) >> 23;           // 9-bit reversal
+        re[r] = sample(2 * i);
+        im[r] = sample(2 * i + 1);
     }
     __syncthreads();
-    for (int s = 1; s <= 10; ++s) {
+    for (int s = 1; s <= 9; ++s) {
         const int half = 1 << (s - 1);
-        for (int idx = tid; idx < FEAT_NFFT / 2; idx += FEAT_THREADS) {
-            const int k = idx & (half - 1);
-            const int i0 = ((idx >> (s - 1)) << s) + k, i1 = i0 + half;
-            const int tw = k << (10 - s);
-            const double wr = tab->tw_re[tw], wi = tab->tw_im[tw];
-            const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
-            const double ar = re[i0], ai = im[i0];
-            re[i0] = ar + xr; im[i0] = ai + xi;
-            re[i1] = ar - xr; im[i1] = ai - xi;
-        }
+        const int idx = tid;                                     // 256 butterflies per stage
+        const int k = idx & (half - 1);
+        const int i0 = ((idx >> (s - 1)) << s) + k, i1 = i0 + half;
+        const int tw = k << (10 - s);                            // W_512^(k 2^(9-s)) = W_1024^tw
+        const double wr = tab->tw_re[tw], wi = tab->tw_im[tw];
+        const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
+        const double ar = re[i0], ai = im[i0];
+        re[i0] = ar + xr; im[i0] = ai + xi;
+        re[i1] = ar - xr; im[i1] = ai - xi;
         __syncthreads();
     }
-    // power spectrum into re[0..512]; frame energy
+    // unpack into the power spectrum pw[0..512]; frame energy
     double part = 0.0;
     for (int k = tid; k < FEAT_BINS; k += FEAT_THREADS) {
-        const double p = (re[k] * re[k] + im[k] * im[k]) / (double)FEAT_NFFT;
+        const int kz = k & (FEAT_NFFT / 2 - 1), kc = (FEAT_NFFT / 2 - k) & (FEAT_NFFT / 2 - 1);
+        const double zr = re[kz], zi = im[kz], cr = re[kc], ci = -im[kc];   // Z[k], conj Z[512-k]
+        const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
+        const double dr = 0.5 * (zr - cr), di = 0.5 * (zi - ci);
+        const double o_r = di, o_i = -dr;                                    // (d) / i
+        double wr, wi;
+        if (k < FEAT_NFFT / 2) { wr = tab->tw_re[k]; wi = tab->tw_im[k]; }
+        else { wr = -1.0; wi = 0.0; }                                        // W^512
+        const double xr = er + o_r * wr - o_i * wi, xi = ei + o_r * wi + o_i * wr;
+        const double p = (xr * xr + xi * xi) / (double)FEAT_NFFT;
         part += p;
-        re[k] = p;
+        pw[k] = p;
     }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if ((tid & 63) == 0) wsum[tid >> 6] = part;
@@ -85,7 +99,7 @@ frame_features_kernel(const int16_t *__restrict__ pcm, const int *__restrict__ n
         double acc = 0.0;
         const int start = tab->fb_start[tid], count = tab->fb_count[tid];
         const double *w = tab->fb_weight + tab->fb_offset[tid];
-        for (int i = 0; i < count; ++i) acc += re[start + i] * w[i];
+        for (int i = 0; i < count; ++i) acc += pw[start + i] * w[i];
         if (acc == 0.0) acc = 2.220446049250313e-16;      // numpy.finfo(float).eps
         const double lm = log(acc);
         logmel[tid] = lm;
@@ -129,15 +143,20 @@ mfcc_delta_kernel(const double *__restrict__ cep64, const int *__restrict__ num_
 
 // frame drop + normalisation + zero padding.  grid (B, NORM_SPLIT), 256 threads: every workgroup
 // of an utterance forms the (cheap, L2-resident) column statistics itself, in the same order, and
-// writes its own band of output rows - B workgroups alone took 160 us at C2.
+// writes its own band of output rows - B workgroups alone took 160 us at C2, this grid with one
+// column per lane 100 us, with 16-byte loads and 12 row groups per workgroup 29 us.
 // norm: 0 none, 1 local (per feature column over time), 2 local_scalar (whole matrix).
 #define NORM_SPLIT 16
 __global__ void __launch_bounds__(FEAT_THREADS)
 normalize_kernel(const float *__restrict__ raw32, const int *__restrict__ num_samples, int t_max,
                  int out_t, int drop, int norm, float *__restrict__ out, int *__restrict__ out_len) {
-    __shared__ double s1[4][FEAT_NFILT], s2[4][FEAT_NFILT];
+    // statistics: thread = (4 feature columns, one of 12 row groups): 16-byte loads, every lane
+    // busy, eight rows in flight per thread (one column per lane and one accumulator took 100 us
+    // for a 5 MB matrix: the loop only waits for its loads)
+    constexpr int RG = 12, C4 = FEAT_NFILT / 4;              // 12 x 20 = 240 threads
+    __shared__ double s1[RG][FEAT_NFILT], s2[RG][FEAT_NFILT];
     __shared__ float mean_s[FEAT_NFILT], inv_s[FEAT_NFILT];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int n = num_samples[b];
     const int frames = n <= FEAT_FRAME ? 1 : 1 + (n - FEAT_FRAME + FEAT_STEP - 1) / FEAT_STEP;
     const int step = drop ? 2 : 1;
@@ -145,18 +164,34 @@ normalize_kernel(const float *__restrict__ raw32, const int *__restrict__ num_sa
     const float *src = raw32 + (size_t)b * t_max * FEAT_NFILT;
     if (tid == 0 && blockIdx.y == 0) out_len[b] = kept;
     if (norm != 0) {
-        for (int c = lane; c < FEAT_NFILT; c += 64) {
-            double a = 0.0, q = 0.0;
-            for (int i = wave; i < kept; i += 4) {
-                const double v = (double)src[(size_t)i * step * FEAT_NFILT + c];
-                a += v; q += v * v;
+        if (tid < RG * C4) {
+            const int c4 = tid % C4, rg = tid / C4;
+            double a[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = rg; i < kept; i += 8 * RG) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = i + RG * j;
+                    v[j] = row < kept
+                               ? *reinterpret_cast<const float4 *>(
+                                     src + (size_t)row * step * FEAT_NFILT + 4 * c4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a[0] += (double)v[j].x; q[0] += (double)v[j].x * (double)v[j].x;
+                    a[1] += (double)v[j].y; q[1] += (double)v[j].y * (double)v[j].y;
+                    a[2] += (double)v[j].z; q[2] += (double)v[j].z * (double)v[j].z;
+                    a[3] += (double)v[j].w; q[3] += (double)v[j].w * (double)v[j].w;
+                }
             }
-            s1[wave][c] = a; s2[wave][c] = q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s1[rg][4 * c4 + k] = a[k]; s2[rg][4 * c4 + k] = q[k]; }
         }
         __syncthreads();
         if (tid < FEAT_NFILT) {
-            double a = s1[0][tid] + s1[1][tid] + s1[2][tid] + s1[3][tid];
-            double q = s2[0][tid] + s2[1][tid] + s2[2][tid] + s2[3][tid];
+            double a = 0.0, q = 0.0;
+            for (int rg = 0; rg < RG; ++rg) { a += s1[rg][tid]; q += s2[rg][tid]; }
             s1[0][tid] = a; s2[0][tid] = q;
         }
         __syncthreads();

@@ -582,16 +582,18 @@ def test_beam_search_random_sweep_against_the_oracle(hip):
     assert cases == 27
 
 
-@pytest.mark.parametrize('batch,lengths', [(3, False), (16, True), (19, True), (32, False),
-                                           (32, True), (45, True)])
-def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengths):
+@pytest.mark.parametrize('batch,lengths,num_steps', [
+    (3, False, 37), (16, True, 37), (19, True, 37), (32, False, 37), (32, True, 37),
+    (45, True, 37),            # two blocks of rows (32 + 13)
+    (19, False, 1), (19, True, 2), (33, False, 3)])    # degenerate passes; a block of ONE row
+def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengths, num_steps):
     """`RNN_REDUCE_SCATTER`: the LSTM-1024 backward recurrence with the product dgates x R cut
     along K (every workgroup multiplies the dgates of its OWN units into a partial dh for all
     units, consumers sum 64 partial tiles) against the default kernels (all-gather of dgates,
     themselves checked against float64 autograd in `test_rnn_fwd_bwd`): same results to fp32
     summation order, deterministic, bit-identical when cut into step ranges; one batch tile
     (one chain) and two (two chains per workgroup), with and without per-row lengths."""
-    num_steps, hidden = 37, 1024
+    hidden = 1024
     gen = torch.Generator(device=DEV).manual_seed(100 + batch)
     xw = torch.randn(num_steps, batch, 2, 4 * hidden, device=DEV, generator=gen) * 0.5
     w_hh = torch.randn(2, 4 * hidden, hidden, device=DEV, generator=gen) / 32
@@ -620,7 +622,9 @@ def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengt
     if seq_len is not None:       # steps past a row's length carry no gradient
         assert float(got[1:, batch - 1].abs().max()) == 0.0
     cut = torch.empty_like(got)
-    for hi, lo in ((37, 20), (20, 19), (19, 7), (7, 0)):
+    marks = sorted({num_steps, num_steps * 20 // 37, num_steps * 19 // 37, num_steps * 7 // 37, 0},
+                   reverse=True)
+    for hi, lo in zip(marks[:-1], marks[1:]):
         hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, seq_len, dxw=cut, workspace=ws,
                     steps=(lo, hi), flags=hip.RNN_REDUCE_SCATTER)
     hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)

@@ -68,6 +68,8 @@ SIGNATURES = {
     'ctcasr_conv0_wrw': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p, _c_f, _c_p, _c_p, _c_sz,
                                   _c_p]),
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    'ctcasr_split_bf16': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_int, _c_p, _c_i64, _c_i64,
+                                   _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
     'ctcasr_features_init_tables': (_c_int, [_c_p, _c_int, _c_p]),
@@ -443,6 +445,34 @@ def colsum_accumulate(dz, dbias):
                                            dz.numel() // cols, cols, _stream()),
            'colsum_accumulate')
     return dbias
+
+
+SPLIT_MAX_BLOCKS = 6
+
+
+@_on_tensor_device
+def split_bf16(x, order, out=None):
+    """x f32 [rows, cols] (unit column stride, any row stride) -> bf16 ``out[rows, len(order),
+    cols]``: block b holds piece ``order[b]`` of the three-piece bfloat16 split x = x1 + x2 + x3
+    (include/ctcasr.h: ctcasr_split_bf16).  ``out`` may be any bf16 view of that shape with unit
+    column stride (a row / column range of a bigger buffer, blocks stacked along the rows...)."""
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1:
+        raise CtcAsrError('split_bf16: x must be an f32 matrix in HBM with unit column stride.')
+    rows, cols = x.shape
+    order = [int(v) for v in order]
+    if out is None:
+        out = torch.empty((rows, len(order), cols), dtype=torch.bfloat16, device=x.device)
+    elif (out.dtype != torch.bfloat16 or tuple(out.shape) != (rows, len(order), cols) or
+          out.stride(2) != 1 or out.device != x.device):
+        raise CtcAsrError('split_bf16: out must be a bf16 [rows, blocks, cols] view with unit '
+                          'column stride on the device of x.')
+    arr = (ctypes.c_int * len(order))(*order)
+    _check(load().ctcasr_split_bf16(x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols,
+                                    arr, len(order), out.data_ptr(),
+                                    out.stride(0) if rows > 1 else len(order) * cols,
+                                    out.stride(1) if len(order) > 1 else cols, _stream()),
+           'split_bf16')
+    return out
 
 
 def conv_s12_supported(freq_in, cout):

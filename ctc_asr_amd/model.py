@@ -20,7 +20,7 @@ import os
 import numpy as np
 import torch
 
-from ctc_asr_amd import hip, metrics
+from ctc_asr_amd import hip, metrics, split_gemm
 from ctc_asr_amd.labels import num_classes
 
 CONV_KERNEL_SIZES = ((11, 41), (11, 21), (11, 21))   # (time, freq), asr/util/tf_contrib.py:66
@@ -337,6 +337,9 @@ class CTCModel:
         # workgroups per 16-row tile and fills the chip whatever the flag says, so the projection
         # GEMMs would only compete with it (measured at B = 32: profiles/r03_gemm_...md)
         self.fwd_pipeline_max_batch = int(os.environ.get('CTCASR_FWD_PIPELINE_MAX_BATCH', '16'))
+        # the big fp32 GEMMs (RNN input projections and their gradients) as three-piece bf16
+        # splits on the bf16 matrix pipe: fp32-grade results (split_gemm.py), 1.2x the GEMM rate
+        self.split_gemm = os.environ.get('CTCASR_SPLIT_GEMM', '1') == '1'
         self._side_stream = None
         self.early_hooks = False        # see backward(); set by engine.Trainer
         # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
@@ -468,6 +471,7 @@ class CTCModel:
         cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
         rnn_len = None if cfg.cudnn else seq_length
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
+        in_split, w_split = [], []      # bf16 pieces of layer inputs / W_ih (None: fp32 GEMMs)
         pipelined_xw = None
         x = rnn_in.contiguous()
         workspace = self._rnn_workspace(cell, t_out, batch, hidden)
@@ -485,10 +489,18 @@ class CTCModel:
             # the recurrent bias of the candidate gate) are added to xw INSIDE the recurrence
             # kernel (`xw_bias`): the GEMM then is a plain product without a bias epilogue
             # (3.93 instead of 4.16 ms per layer at C3) and no pass over xw is spent on it
+            xs = ws = None
             if pipelined_xw is not None:       # built beside the previous layer's recurrence
                 xw, pipelined_xw = pipelined_xw, None
+            elif self.split_gemm and split_gemm.worthwhile(t_out * batch, x.shape[-1],
+                                                            w_ih.shape[0]):
+                xs = split_gemm.split(x.view(t_out * batch, -1), split_gemm.A_ORDER)
+                ws = split_gemm.split(w_ih, split_gemm.B_ORDER)
+                xw = split_gemm.mm_nt(xs, ws)
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
+            in_split.append(xs)
+            w_split.append(ws)
             if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
                 y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
                     i, xw, t_out, batch, hidden, gates, workspace)
@@ -506,7 +518,8 @@ class CTCModel:
                 x = hip.dropout(x, rnn_rate, seeds[1])
             drop_seeds.append(seeds)
         acts.update(layer_in=layer_in, layer_out=layer_out, reserves=reserves, rnn_ws=workspace,
-                    rnn_len=rnn_len, t_out=t_out, drop_seeds=drop_seeds, rnn_rate=rnn_rate)
+                    rnn_len=rnn_len, t_out=t_out, drop_seeds=drop_seeds, rnn_rate=rnn_rate,
+                    in_split=in_split, w_split=w_split)
 
         rnn_flat = x.view(t_out * batch, 2 * hidden)
         dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training)
@@ -808,23 +821,62 @@ class CTCModel:
 
             drec = hip.rnn_gru_drec(acts['reserves'][i], t_out, batch, hidden) if cell == 'gru' \
                 else dxw
+            dxw2d = dxw.view(rows, 2 * gh)
+            w_ih = p[name + '/w_ih'].view(2 * gh, -1)
 
-            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec):
+            # bf16-split operands (split_gemm.py): the pieces of this layer's input and W_ih come
+            # from the forward pass where it used them; y's are the next layer's input pieces
+            use_split = self.split_gemm and split_gemm.worthwhile(rows, x.shape[-1], 2 * gh)
+            xs = ys = ws = ds = drs = None
+            if use_split:
+                xs = acts['in_split'][i] or split_gemm.split(x.view(rows, -1), split_gemm.A_ORDER)
+                acts['in_split'][i] = xs        # (the layer below reads y's pieces from here)
+                ws = acts['w_split'][i] or split_gemm.split(w_ih, split_gemm.B_ORDER)
+                above = i + 1 < cfg.num_layers_rnn and acts['in_split'][i + 1] is not None and \
+                    acts['layer_in'][i + 1] is y
+                ys = acts['in_split'][i + 1] if above else \
+                    split_gemm.split(y.view(rows, 2 * hidden), split_gemm.A_ORDER)
+                ds = split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
+                drs = ds if cell != 'gru' else \
+                    split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
+            side_tensors = [dxw] + [t.buf for t in (xs, ys, ds, drs) if t is not None]
+
+            def split_steps(lo, hi, ds=ds, drs=drs, dxw2d=dxw2d, drec=drec):
+                # pieces of dxw (GRU: and drec) for steps [lo, hi) of both directions
+                for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
+                    rng, cols = slice(a * batch, b * batch), slice(d * gh, (d + 1) * gh)
+                    hip.split_bf16(dxw2d[rng, cols], split_gemm.B_ORDER, out=ds.buf[rng, :, cols])
+                    if drs is not ds:
+                        hip.split_bf16(drec.view(rows, 2 * gh)[rng, cols], split_gemm.B_ORDER,
+                                       out=drs.buf[rng, :, cols])
+
+            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec, xs=xs,
+                                     ys=ys, ds=ds, drs=drs):
                 # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
                 x3 = x.view(t_out, batch, -1)
                 for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
-                    g[name + '/w_ih'][d].addmm_(
-                        dxw[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
-                        x3[a:b].reshape((b - a) * batch, -1))
+                    cols = slice(d * gh, (d + 1) * gh)
+                    if ds is not None:
+                        split_gemm.mm_tn_rows(g[name + '/w_ih'][d], ds, xs, a * batch, b * batch,
+                                              a_cols=cols)
+                    else:
+                        g[name + '/w_ih'][d].addmm_(
+                            dxw[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
+                            x3[a:b].reshape((b - a) * batch, -1))
                     # dW_hh[d] += drec_t^T h_(t-1) (forward) / h_(t+1) (backward direction)
                     if d == 0:
-                        a, shift, cols = max(a, 1), -1, slice(0, hidden)
+                        a, shift, hcols = max(a, 1), -1, slice(0, hidden)
                     else:
-                        b, shift, cols = min(b, t_out - 1), 1, slice(hidden, 2 * hidden)
-                    if b > a:
+                        b, shift, hcols = min(b, t_out - 1), 1, slice(hidden, 2 * hidden)
+                    if b <= a:
+                        continue
+                    if ds is not None:
+                        split_gemm.mm_tn_rows(g[name + '/w_hh'][d], drs, ys, a * batch, b * batch,
+                                              a_cols=cols, b_cols=hcols, b_shift=shift * batch)
+                    else:
                         g[name + '/w_hh'][d].addmm_(
                             drec[a:b, :, d, :].reshape((b - a) * batch, gh).t(),
-                            y[a + shift:b + shift, :, cols].reshape((b - a) * batch, hidden))
+                            y[a + shift:b + shift, :, hcols].reshape((b - a) * batch, hidden))
 
             # the bias gradients - column sums of dxw (GRU: and of drec) - come out of the
             # recurrence kernels themselves (accumulated into the zeroed arena slices: b_ih, and
@@ -834,6 +886,7 @@ class CTCModel:
             assert self.arena.offsets[name + '/b_hh'] == b_start + 2 * gh
             dbias = self.arena.grad[b_start:b_start + b_count]
             bounds = [t_out * (chunks - c) // chunks for c in range(chunks + 1)]   # T ... 0
+            split_done = []
             for c in range(chunks):
                 hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
                             dxw=dxw, dbias=dbias, workspace=acts['rnn_ws'],
@@ -841,23 +894,36 @@ class CTCModel:
                             ticket=self._take_ticket() if persistent and not whole_chip_rnn
                             else 0)
                 if c + 1 < chunks:
-                    on_side([dxw], lambda lo=bounds[c + 1], hi=bounds[c]:
-                            partial_weight_grads(lo, hi), gate=True)
-            dxw2d = dxw.view(rows, 2 * gates * hidden)
+                    def finished_steps(lo=bounds[c + 1], hi=bounds[c]):
+                        if use_split:       # these steps' pieces: beside the next launch as well
+                            split_steps(lo, hi)
+                            split_done.append(torch.cuda.Event())
+                            split_done[-1].record(torch.cuda.current_stream(self.device))
+                        partial_weight_grads(lo, hi)
+                    on_side(side_tensors, finished_steps, gate=True)
+            if use_split:
+                split_steps(0, bounds[-2])
+                for event in split_done:
+                    main.wait_event(event)
             # critical path: the gradient w.r.t. this layer's input feeds the layer below
             dy_below = None
             if i > 0 or need_dx_first:
-                w_ih = p[name + '/w_ih'].view(2 * gates * hidden, -1)
-                dy_below = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
+                if use_split:
+                    dy_below = torch.empty((rows, x.shape[-1]), dtype=torch.float32,
+                                           device=dy.device)
+                    split_gemm.mm_pieces(dy_below, ds.piece, ws.piece)
+                    dy_below = dy_below.view(t_out, batch, -1)
+                else:
+                    dy_below = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
                 if seeds[0] is not None:
                     dy_below = hip.dropout(dy_below, rnn_rate, seeds[0])
 
             def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i, chunks=chunks,
                              last=bounds[-2], partial_weight_grads=partial_weight_grads,
-                             drec=drec):
+                             drec=drec, use_split=use_split):
                 if cell != 'gru':       # (the GRU's db_hh came out of the kernel with db_ih)
                     g[name + '/b_hh'].copy_(g[name + '/b_ih'])
-                if chunks > 1:          # the earlier launches' shares are already in
+                if chunks > 1 or use_split:   # the earlier launches' shares are already in
                     partial_weight_grads(0, last)
                     return
                 torch.mm(dxw2d.t(), x.view(rows, -1),
@@ -879,7 +945,7 @@ class CTCModel:
                 if early:
                     done(name)
 
-            on_side([dxw], layer_weight_grads, gate=i > 0, beside_recurrence=i > 0)
+            on_side(side_tensors, layer_weight_grads, gate=i > 0, beside_recurrence=i > 0)
             if not early:
                 deferred.append(name)
             if dy_below is not None:

@@ -1,0 +1,117 @@
+"""The big fp32 GEMMs of the stack (RNN input projections, their data and weight gradients) on the
+bf16 matrix pipe, at fp32 accuracy.
+
+gfx950 has no xf32 and its fp32 MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md), and the
+library's fp32 GEMM sits at 88 % of that peak already: the only way to make
+these products faster is to leave the fp32 pipe.  Each fp32 operand is split into three bfloat16
+pieces a = a1 + a2 + a3 (`hip.split_bf16`, 24 mantissa bits in all, fp32's exponent range) and the
+product is the six partial products of order <= 2,
+
+    a b  ~  a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),        dropped terms <= 2^-24 |a b|,
+
+accumulated in fp32 by the library's bf16 GEMM (6/16 of the fp32-MFMA time on paper).  Measured
+against fp64 on the C3 layer shapes the result is CLOSER than the fp32 GEMM's (rms relative error
+1.5e-7 .. 6e-7 against 4e-7 .. 1.6e-6: the pieces' products are exact and the accumulation is the
+same fp32 one; `tools/gemm_split_probe.py`, `profiles/r03_gemm_bf16_split.md`).
+
+Layouts.  Every split operand is stored [rows, 6, cols] with the piece order `A_ORDER` or
+`B_ORDER`; block k of one order pairs with block k of the other.
+  - K = the column axis of both operands (forward projections): the buffers read as
+    [rows, 6 cols] ARE the K-concatenated operands - one GEMM over 6 K (`mm_nt`);
+  - K = the row axis of both operands (weight gradients): the buffers read as [6 rows, cols]
+    pair block k of a row with block k of the same row - again one GEMM (`mm_tn_rows`);
+  - K = columns of one, rows of the other (data gradient): six accumulating calls on piece views
+    (`mm_pieces`); the output is the small matrix there, the extra passes over it cost little, and
+    the library's kernels for one K = 49152 call measured slower than six K = 8192 calls.
+"""
+
+import torch
+
+from . import hip
+
+A_ORDER = (0, 1, 2, 0, 1, 0)
+B_ORDER = (2, 1, 0, 1, 0, 0)
+THREE = (0, 1, 2)
+# (piece of the first operand, piece of the second), smallest terms first
+PAIRS = ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0))
+_BLOCK_OF_PIECE = {A_ORDER: (0, 1, 2), B_ORDER: (2, 1, 0), THREE: (0, 1, 2)}
+F32 = torch.float32
+
+
+class Split:
+    """bf16 pieces of an fp32 matrix [rows, cols]: `buf` [rows, blocks, cols]."""
+
+    __slots__ = ('buf', 'order')
+
+    def __init__(self, buf, order):
+        self.buf, self.order = buf, tuple(order)
+
+    @property
+    def rows(self):
+        return self.buf.shape[0]
+
+    @property
+    def cols(self):
+        return self.buf.shape[2]
+
+    def piece(self, p):
+        """Piece p as a [rows, cols] view (row stride blocks * cols)."""
+        return self.buf[:, _BLOCK_OF_PIECE[self.order][p]]
+
+    def concat(self):
+        """[rows, blocks * cols]: the K-concatenated operand."""
+        rows, blocks, cols = self.buf.shape
+        return self.buf.view(rows, blocks * cols)
+
+
+def split(x2d, order, out=None):
+    return Split(hip.split_bf16(x2d, order, out=None if out is None else out.buf), order)
+
+
+def empty(rows, cols, order, device):
+    return Split(torch.empty((rows, len(order), cols), dtype=torch.bfloat16, device=device), order)
+
+
+def mm_nt(a, b, out=None, rows=None, accumulate=False):
+    """out[M, N] (+)= A[M, K] . B[N, K]^T from a = Split(A, A_ORDER), b = Split(B, B_ORDER) in ONE
+    call; ``rows`` = a slice of A's rows (then out is that slice's product)."""
+    assert a.order == A_ORDER and b.order == B_ORDER and a.cols == b.cols
+    lhs = a.concat() if rows is None else a.concat()[rows]
+    if out is None:
+        return torch.mm(lhs, b.concat().t(), out_dtype=F32)
+    if accumulate:
+        return torch.addmm(out, lhs, b.concat().t(), out_dtype=F32, out=out)
+    return torch.mm(lhs, b.concat().t(), out_dtype=F32, out=out)
+
+
+def mm_pieces(out, lhs, rhs, accumulate=False):
+    """out (+)= sum over `PAIRS` of lhs(i) . rhs(j): ``lhs`` / ``rhs`` map a piece index to the
+    bf16 matrix view to multiply ([M, K] and [K, N]; transposed / sliced views are fine)."""
+    for i, j in PAIRS:
+        if accumulate:
+            torch.addmm(out, lhs(i), rhs(j), out_dtype=F32, out=out)
+        else:
+            torch.mm(lhs(i), rhs(j), out_dtype=F32, out=out)
+            accumulate = True
+    return out
+
+
+def mm_tn_rows(out, a, b, lo, hi, a_cols=slice(None), b_cols=slice(None), b_shift=0,
+               accumulate=True):
+    """out[Ma, Nb] (+)= A[lo:hi, a_cols]^T . B[lo + b_shift:hi + b_shift, b_cols] - a product over
+    the ROW axis of both operands (weight gradients) - in ONE call: with a = Split(A, B_ORDER) and
+    b = Split(B, A_ORDER) the buffers read as [rows * 6, cols] matrices pair block k of a row of A
+    with block k of the matching row of B, which is exactly the six products."""
+    assert a.order == B_ORDER and b.order == A_ORDER
+    lhs = a.buf.view(a.rows * 6, a.cols)[6 * lo:6 * hi, a_cols].t()
+    rhs = b.buf.view(b.rows * 6, b.cols)[6 * (lo + b_shift):6 * (hi + b_shift), b_cols]
+    if accumulate:
+        return torch.addmm(out, lhs, rhs, out_dtype=F32, out=out)
+    return torch.mm(lhs, rhs, out_dtype=F32, out=out)
+
+
+def worthwhile(m, k, n):
+    """Shapes the split pays for: a big product (the splits are HBM passes over the operands)
+    whose dimensions suit the 8-element vectors of the split kernel."""
+    return k % 8 == 0 and n % 8 == 0 and m >= 256 and k >= 256 and n >= 256 and \
+        m * k * n >= (1 << 31)

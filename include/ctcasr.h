@@ -292,6 +292,28 @@ int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T, c
 int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,
                              ctcasr_stream_t stream);
 
+/* ---- fp32 operands of the dense / input-projection GEMMs, split for the bf16 matrix pipe ---------
+ * The GEMMs of asr/model.py:166-171 (dense), :203-214 (cuDNN RNN input projections) and their
+ * gradients are fp32 x fp32 -> fp32.  gfx950 has no xf32 and its fp32 MFMA runs at 1/16 of the bf16
+ * rate, so the host side may feed the library GEMM three-piece bfloat16 splits instead:
+ *   x = x1 + x2 + x3,  x1 = rne_bf16(x), x2 = rne_bf16(x - x1), x3 = rne_bf16(x - x1 - x2)
+ * (both differences are exact in fp32; 24 mantissa bits in all) and sum the six products of order
+ * <= 2 (x1w1; x1w2 + x2w1; x1w3 + x2w2 + x3w1) with fp32 accumulation - every term down to 2^-24
+ * relative, i.e. what an fp32 FMA chain keeps.
+ *   x     f32 [rows, cols], row stride ld_x elements (cols % 8 == 0, ld_x % 4 == 0, 16-byte aligned)
+ *   order host int[blocks], piece index (0, 1, 2) held by each block, blocks <= 6
+ *   out   bf16, element (r, b, c) at r * ld_out + b * block_stride + c (both strides in elements,
+ *         multiples of 8, 16-byte aligned base).  ld_out = blocks * cols, block_stride = cols is the
+ *         K-concatenated form [rows, blocks, cols]: order {0,1,2,0,1,0} against a second operand
+ *         split with {2,1,0,1,0,0} makes ONE bf16 GEMM over K = 6 * cols the whole product;
+ *         ld_out = cols, block_stride = rows * cols stacks the blocks along the rows instead (for an
+ *         operand whose K axis is its row axis); wider strides write a column range of a bigger
+ *         matrix. */
+#define CTCASR_SPLIT_MAX_BLOCKS 6
+int ctcasr_split_bf16(const float *x, int64_t rows, int cols, int64_t ld_x, const int *order,
+                      int blocks, void *out, int64_t ld_out, int64_t block_stride,
+                      ctcasr_stream_t stream);
+
 /* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
  * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):
  *   lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step);  m, v updated in place;

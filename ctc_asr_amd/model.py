@@ -340,6 +340,9 @@ class CTCModel:
         # the big fp32 GEMMs (RNN input projections and their gradients) as three-piece bf16
         # splits on the bf16 matrix pipe: fp32-grade results (split_gemm.py), 1.2x the GEMM rate
         self.split_gemm = os.environ.get('CTCASR_SPLIT_GEMM', '1') == '1'
+        self.split_dense4 = os.environ.get('CTCASR_SPLIT_DENSE4', '1') == '1'
+        self.split_wgrad = os.environ.get('CTCASR_SPLIT_WGRAD', '1') == '1'
+        self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
         self._side_stream = None
         self.early_hooks = False        # see backward(); set by engine.Trainer
         # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
@@ -368,16 +371,96 @@ class CTCModel:
             hip.rnn_resident_gate(cell, workspace, t_out, batch, hidden, self._upcoming_ticket(),
                                   self.side_gate_max_us)
 
+    # ------------------------------------------------------------------ bf16 pieces of the weights
+    def _prepare_weight_splits(self, rows, training):
+        """Pieces of the weights the split GEMMs of this step read (split_gemm.py): W_ih as
+        [2GH, 6, in] for the forward projection, its transpose as [in, 6, 2GH] for the data
+        gradient; the dense4 kernel stacked along its rows (forward) and as [in, 6, out] (data
+        gradient).  They are built on the side stream while the front end runs (the weights are
+        final since the last Adam step); `_weight_split` makes the main stream wait for them."""
+        cfg, p = self.cfg, self.arena.p
+        self._w_split, self._w_split_ready = {}, None
+        if not self.split_gemm:
+            return
+        gh2 = 2 * GATES[cfg.cell] * cfg.num_units_rnn
+        jobs = []
+        for i in range(cfg.num_layers_rnn):
+            w_ih = p['rnn{}/w_ih'.format(i)].view(gh2, -1)
+            if split_gemm.worthwhile(rows, w_ih.shape[1], gh2):
+                jobs.append(('rnn{}'.format(i), w_ih))
+        k4 = p['dense4/kernel']
+        dense4 = self.split_dense4 and split_gemm.worthwhile(rows, k4.shape[0], k4.shape[1])
+        if not jobs and not dense4:
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        side = self._side_stream
+        bufs = self._w_split_bufs
+        start = torch.cuda.Event()
+        start.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(start)          # the previous step is done with the buffers
+            for name, w_ih in jobs:
+                if name not in bufs:
+                    bufs[name] = (
+                        split_gemm.empty(gh2, w_ih.shape[1], split_gemm.B_ORDER, self.device),
+                        split_gemm.empty(w_ih.shape[1], gh2, split_gemm.A_ORDER, self.device),
+                        torch.empty((w_ih.shape[1], gh2), dtype=torch.float32, device=self.device))
+                fwd, tr, scratch = bufs[name]
+                split_gemm.split(w_ih, split_gemm.B_ORDER, out=fwd)
+                if training:
+                    hip.transpose_batched(w_ih.view(1, gh2, -1), out=scratch.view(1, -1, gh2))
+                    split_gemm.split(scratch, split_gemm.A_ORDER, out=tr)
+                self._w_split[name] = (fwd, tr if training else None)
+            if dense4:
+                if 'dense4' not in bufs:
+                    bufs['dense4'] = (
+                        torch.empty((6,) + tuple(k4.shape), dtype=torch.bfloat16,
+                                    device=self.device),
+                        split_gemm.empty(k4.shape[0], k4.shape[1], split_gemm.A_ORDER,
+                                         self.device))
+                stacked, by_row = bufs['dense4']
+                split_gemm.split_rows_stacked(k4, split_gemm.B_ORDER, out=stacked)
+                if training:
+                    split_gemm.split(k4, split_gemm.A_ORDER, out=by_row)
+                self._w_split['dense4'] = (stacked.view(-1, k4.shape[1]),
+                                           by_row if training else None)
+            self._w_split_ready = torch.cuda.Event()
+            self._w_split_ready.record(side)
+
+    def _weight_split(self, name, backward=False):
+        """(forward pieces, backward pieces) of a weight, or None: fp32 GEMMs for this layer."""
+        got = self._w_split.get(name)
+        if got is None:
+            return None
+        if self._w_split_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._w_split_ready)
+        if backward and got[1] is None:     # a backward pass after an evaluation-mode forward
+            p = self.arena.p
+            if name == 'dense4':
+                back = split_gemm.split(p['dense4/kernel'], split_gemm.A_ORDER)
+            else:
+                w_ih = p[name + '/w_ih']
+                w_ih = w_ih.view(w_ih.shape[0] * w_ih.shape[1], -1)
+                back = split_gemm.split(w_ih.t().contiguous(), split_gemm.A_ORDER)
+            got = self._w_split[name] = (got[0], back)
+        return got
+
     # ------------------------------------------------------------------ forward
     def _next_seed(self):
         self.dropout_seed = (self.dropout_seed * 6364136223846793005 + 1442695040888963407) \
             & 0xFFFFFFFFFFFFFFFF
         return self.dropout_seed
 
-    def _dense_act(self, x2d, name, rate, training):
-        """x2d [rows, in] -> dropout(min(relu(x K + b), cutoff)); returns the activation."""
+    def _dense_act(self, x2d, name, rate, training, xs=None):
+        """x2d [rows, in] -> dropout(min(relu(x K + b), cutoff)); returns the activation.
+        ``xs``: the bf16 pieces of x2d when the product runs as a split GEMM."""
         p = self.arena.p
-        out = torch.mm(x2d, p[name + '/kernel'])
+        if xs is not None:
+            out = split_gemm.mm_nn_stacked(xs, self._weight_split(name)[0])
+        else:
+            out = torch.mm(x2d, p[name + '/kernel'])
         hip.bias_act_fwd(out, p[name + '/bias'], self.cfg.relu_cutoff,
                          rate if training else 0.0, self._next_seed())
         return out
@@ -390,6 +473,7 @@ class CTCModel:
         sequences = sequences.to(self.device, torch.float32).contiguous()
         batch, frames, _ = sequences.shape
         acts = {'training': training, 'batch': batch}
+        self._prepare_weight_splits(cfg.output_time(frames) * batch, training)
         if cfg.used_model == 'ds2':
             # conv dropout: the reference never forwards `training` to conv_layers, so a
             # non-zero conv_dropout_rate fires in evaluation too (asr/model.py:161).
@@ -471,7 +555,7 @@ class CTCModel:
         cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
         rnn_len = None if cfg.cudnn else seq_length
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
-        in_split, w_split = [], []      # bf16 pieces of layer inputs / W_ih (None: fp32 GEMMs)
+        in_split = []                   # bf16 pieces of the layer inputs (None: fp32 GEMM)
         pipelined_xw = None
         x = rnn_in.contiguous()
         workspace = self._rnn_workspace(cell, t_out, batch, hidden)
@@ -492,15 +576,12 @@ class CTCModel:
             xs = ws = None
             if pipelined_xw is not None:       # built beside the previous layer's recurrence
                 xw, pipelined_xw = pipelined_xw, None
-            elif self.split_gemm and split_gemm.worthwhile(t_out * batch, x.shape[-1],
-                                                            w_ih.shape[0]):
+            elif self._weight_split('rnn{}'.format(i)) is not None:
                 xs = split_gemm.split(x.view(t_out * batch, -1), split_gemm.A_ORDER)
-                ws = split_gemm.split(w_ih, split_gemm.B_ORDER)
-                xw = split_gemm.mm_nt(xs, ws)
+                xw = split_gemm.mm_nt(xs, self._weight_split('rnn{}'.format(i))[0])
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
             in_split.append(xs)
-            w_split.append(ws)
             if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
                 y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
                     i, xw, t_out, batch, hidden, gates, workspace)
@@ -519,10 +600,16 @@ class CTCModel:
             drop_seeds.append(seeds)
         acts.update(layer_in=layer_in, layer_out=layer_out, reserves=reserves, rnn_ws=workspace,
                     rnn_len=rnn_len, t_out=t_out, drop_seeds=drop_seeds, rnn_rate=rnn_rate,
-                    in_split=in_split, w_split=w_split)
+                    in_split=in_split)
 
         rnn_flat = x.view(t_out * batch, 2 * hidden)
-        dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training)
+        flat_split = None
+        if self._weight_split('dense4') is not None:
+            # (the top layer's output pieces also serve its recurrent weight gradient)
+            flat_split = split_gemm.split(rnn_flat, split_gemm.A_ORDER)
+        dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training,
+                                 xs=flat_split)
+        acts.update(flat_split=flat_split, flat_of=x)
         logits = torch.mm(dense4, p['logits/kernel'])
         hip.bias_act_fwd(logits, p['logits/bias'], 0.0)
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
@@ -558,6 +645,10 @@ class CTCModel:
         with the NEXT layer's input projection on the other half: pays when that projection is a
         big GEMM (another LSTM layer follows), the steps map to the same time index for every row
         and nothing (dropout) sits between the layers."""
+        if self._weight_split('rnn{}'.format(layer + 1)) is not None:
+            # the split projection of the next layer is a 1.1 ms GEMM at B = 16: not worth slowing
+            # this layer's recurrence to half of the chip for (C2: 21.8 against 22.3 ms per step)
+            return False
         return (self.fwd_chunks > 1 and cell == 'lstm' and hidden == 1024 and
                 batch <= self.fwd_pipeline_max_batch and
                 rnn_len is None and
@@ -777,18 +868,29 @@ class CTCModel:
         # dense4: dz and the data gradient are on the critical path, the kernel gradient is not
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
-        dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
+        k4_split = self._weight_split('dense4', True) if acts['flat_split'] is not None else None
+        if k4_split is not None:
+            dz_split = split_gemm.split(dz, split_gemm.B_ORDER)
+            dy = split_gemm.mm_nt(dz_split, k4_split[1]).view(t_out, batch, 2 * hidden)
+        else:
+            dz_split = None
+            dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
         # `early_hooks` (opt-in, N > 1): a layer's hook - its bucket's all-reduce - fires on the
         # side stream right behind that layer's weight-gradient GEMMs instead of after the whole
         # backlog, so the collective hides behind the layers below (engine.Trainer)
         early = self.early_hooks
 
         def dense4_weight_grad():
-            torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel'])
+            if dz_split is not None:
+                split_gemm.mm_tn_rows(g['dense4/kernel'], acts['flat_split'], dz_split, 0, rows,
+                                      accumulate=False)
+            else:
+                torch.mm(acts['rnn_flat'].t(), dz, out=g['dense4/kernel'])
             if early:
                 done('dense4')
 
-        on_side([dz], dense4_weight_grad, gate=True)
+        on_side([dz] + ([dz_split.buf, acts['flat_split'].buf] if dz_split is not None else []),
+                dense4_weight_grad, gate=True)
         if not early:
             deferred.append('dense4')
 
@@ -826,16 +928,17 @@ class CTCModel:
 
             # bf16-split operands (split_gemm.py): the pieces of this layer's input and W_ih come
             # from the forward pass where it used them; y's are the next layer's input pieces
-            use_split = self.split_gemm and split_gemm.worthwhile(rows, x.shape[-1], 2 * gh)
-            xs = ys = ws = ds = drs = None
+            w_pieces = self._weight_split(name, True)
+            use_split = w_pieces is not None
+            xs = ys = ds = drs = None
             if use_split:
                 xs = acts['in_split'][i] or split_gemm.split(x.view(rows, -1), split_gemm.A_ORDER)
                 acts['in_split'][i] = xs        # (the layer below reads y's pieces from here)
-                ws = acts['w_split'][i] or split_gemm.split(w_ih, split_gemm.B_ORDER)
-                above = i + 1 < cfg.num_layers_rnn and acts['in_split'][i + 1] is not None and \
-                    acts['layer_in'][i + 1] is y
-                ys = acts['in_split'][i + 1] if above else \
-                    split_gemm.split(y.view(rows, 2 * hidden), split_gemm.A_ORDER)
+                if i + 1 < cfg.num_layers_rnn:
+                    above = acts['in_split'][i + 1] if acts['layer_in'][i + 1] is y else None
+                else:
+                    above = acts['flat_split'] if acts['flat_of'] is y else None
+                ys = above or split_gemm.split(y.view(rows, 2 * hidden), split_gemm.A_ORDER)
                 ds = split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
                 drs = ds if cell != 'gru' else \
                     split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
@@ -851,7 +954,7 @@ class CTCModel:
                                        out=drs.buf[rng, :, cols])
 
             def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec, xs=xs,
-                                     ys=ys, ds=ds, drs=drs):
+                                     ys=ys, ds=ds if self.split_wgrad else None, drs=drs):
                 # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
                 x3 = x.view(t_out, batch, -1)
                 for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
@@ -905,13 +1008,21 @@ class CTCModel:
                 split_steps(0, bounds[-2])
                 for event in split_done:
                     main.wait_event(event)
-            # critical path: the gradient w.r.t. this layer's input feeds the layer below
+            # critical path: the gradient w.r.t. this layer's input feeds the layer below.
+            # ONE library GEMM at a time: the weight-gradient GEMMs still queued on the side
+            # stream finish first.  Two stream-K GEMMs of the library in flight at once - each
+            # holding CUs while it waits for partial tiles of workgroups that have no CU yet - can
+            # wait for each other forever (seen at C2: the bf16 data gradient [8000 x 640] on this
+            # stream against a [4096 x 640] weight gradient on the side stream, second training
+            # step); GEMMs beside this package's own kernels are fine, those never wait on them.
             dy_below = None
             if i > 0 or need_dx_first:
+                if side is not main:
+                    main.wait_stream(side)
                 if use_split:
                     dy_below = torch.empty((rows, x.shape[-1]), dtype=torch.float32,
                                            device=dy.device)
-                    split_gemm.mm_pieces(dy_below, ds.piece, ws.piece)
+                    split_gemm.mm_nt_by_order(dy_below, ds, w_pieces[1])
                     dy_below = dy_below.view(t_out, batch, -1)
                 else:
                     dy_below = torch.mm(dxw2d, w_ih).view(t_out, batch, -1)
@@ -971,6 +1082,8 @@ class CTCModel:
                 b_, c_, tt, ff = last.shape
                 # [T', B, F'*C] -> NHWC storage [B, T', F', C] for the gradient as well
                 dact = dy.view(tt, b_, ff, c_).permute(1, 0, 2, 3).contiguous()
+            if side is not main and any(kind is None for kind in acts['conv_own']):
+                main.wait_stream(side)      # MIOpen may run library GEMMs: one at a time
             for i in range(len(cfg.conv_filters) - 1, -1, -1):
                 name = 'conv{}'.format(i)
                 tm = acts['last_time_major'] and i == len(cfg.conv_filters) - 1
@@ -1025,6 +1138,8 @@ class CTCModel:
                         .permute(0, 2, 3, 1).contiguous()
                 done(name)
         else:
+            if side is not main:
+                main.wait_stream(side)      # one library GEMM at a time (see above)
             dact = dy.reshape(rows, -1)
             for i in range(2, -1, -1):
                 name = 'dense{}'.format(i)

@@ -73,15 +73,45 @@ def empty(rows, cols, order, device):
 
 
 def mm_nt(a, b, out=None, rows=None, accumulate=False):
-    """out[M, N] (+)= A[M, K] . B[N, K]^T from a = Split(A, A_ORDER), b = Split(B, B_ORDER) in ONE
-    call; ``rows`` = a slice of A's rows (then out is that slice's product)."""
-    assert a.order == A_ORDER and b.order == B_ORDER and a.cols == b.cols
+    """out[M, N] (+)= A[M, K] . B[N, K]^T from a = Split(A, A_ORDER), b = Split(B, B_ORDER) (or the
+    orders the other way round) in ONE call; ``rows`` = a slice of A's rows (then out is that
+    slice's product)."""
+    assert {a.order, b.order} == {A_ORDER, B_ORDER} and a.cols == b.cols
     lhs = a.concat() if rows is None else a.concat()[rows]
     if out is None:
         return torch.mm(lhs, b.concat().t(), out_dtype=F32)
     if accumulate:
         return torch.addmm(out, lhs, b.concat().t(), out_dtype=F32, out=out)
     return torch.mm(lhs, b.concat().t(), out_dtype=F32, out=out)
+
+
+def mm_nt_by_order(out, a, b):
+    """out[M, N] = A . B^T like `mm_nt`, as three accumulating calls over the block ranges
+    [0, 3), [3, 5), [5, 6) - the terms of order 2, 1, 0.  For a SMALL out beside a long K (the data
+    gradient: N = 2048, K = 6 x 8192) the library's kernels run three K <= 24576 calls 1.4 x
+    faster than one K = 49152 call (tools/gemm_split_probe.py)."""
+    assert {a.order, b.order} == {A_ORDER, B_ORDER} and a.cols == b.cols
+    k = a.cols
+    lhs, rhs = a.concat(), b.concat()
+    torch.mm(lhs[:, :3 * k], rhs[:, :3 * k].t(), out_dtype=F32, out=out)
+    torch.addmm(out, lhs[:, 3 * k:5 * k], rhs[:, 3 * k:5 * k].t(), out_dtype=F32, out=out)
+    return torch.addmm(out, lhs[:, 5 * k:], rhs[:, 5 * k:].t(), out_dtype=F32, out=out)
+
+
+def mm_nn_stacked(a, b_stacked, out=None):
+    """out[M, N] = A[M, K] . B[K, N] from a = Split(A, order) and the pieces of B stacked along its
+    rows, [6 K, N] in the opposite order (`split_rows_stacked`): one call."""
+    return torch.mm(a.concat(), b_stacked, out_dtype=F32) if out is None else \
+        torch.mm(a.concat(), b_stacked, out_dtype=F32, out=out)
+
+
+def split_rows_stacked(x2d, order, out=None):
+    """Pieces of x [K, N] stacked along the rows: bf16 [6 K, N], block k = rows [k K, (k + 1) K)."""
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.empty((len(order), rows, cols), dtype=torch.bfloat16, device=x2d.device)
+    hip.split_bf16(x2d, order, out=out.permute(1, 0, 2))
+    return out.view(len(order) * rows, cols)
 
 
 def mm_pieces(out, lhs, rhs, accumulate=False):
@@ -100,9 +130,9 @@ def mm_tn_rows(out, a, b, lo, hi, a_cols=slice(None), b_cols=slice(None), b_shif
                accumulate=True):
     """out[Ma, Nb] (+)= A[lo:hi, a_cols]^T . B[lo + b_shift:hi + b_shift, b_cols] - a product over
     the ROW axis of both operands (weight gradients) - in ONE call: with a = Split(A, B_ORDER) and
-    b = Split(B, A_ORDER) the buffers read as [rows * 6, cols] matrices pair block k of a row of A
-    with block k of the matching row of B, which is exactly the six products."""
-    assert a.order == B_ORDER and b.order == A_ORDER
+    b = Split(B, A_ORDER) (or the other way round) the buffers read as [rows * 6, cols] matrices
+    pair block k of a row of A with block k of the matching row of B: exactly the six products."""
+    assert {a.order, b.order} == {A_ORDER, B_ORDER}
     lhs = a.buf.view(a.rows * 6, a.cols)[6 * lo:6 * hi, a_cols].t()
     rhs = b.buf.view(b.rows * 6, b.cols)[6 * (lo + b_shift):6 * (hi + b_shift), b_cols]
     if accumulate:

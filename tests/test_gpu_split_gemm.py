@@ -1,0 +1,155 @@
+"""fp32 GEMMs on the bf16 matrix pipe (ctcasr_split_bf16 + ctc_asr_amd/split_gemm.py): the split is
+exact to 24 bits, the six-product GEMMs are at least as close to fp64 as the library's fp32 GEMM,
+and a training step through them equals the fp32-GEMM step to fp32 round-off."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_split(x):
+    a1 = x.to(torch.bfloat16)
+    r = x - a1.float()
+    a2 = r.to(torch.bfloat16)
+    r = r - a2.float()
+    return a1, a2, r.to(torch.bfloat16)
+
+
+def test_split_kernel_is_the_three_piece_rne_split(hip):
+    g = torch.Generator(device='cuda').manual_seed(0)
+    # magnitudes from 1e-30 to 1e+20 in one matrix; exact zeros, negative zero, a denormal
+    x = torch.randn(300, 64, device='cuda', generator=g) * \
+        torch.logspace(-30, 20, 300, device='cuda')[:, None]
+    x[5, :8] = torch.tensor([0.0, -0.0, 1e-40, -1e-40, 1.0, -1.0, 65504.0, 3.0e38], device='cuda')
+    got = hip.split_bf16(x, (0, 1, 2))
+    for piece, want in enumerate(_torch_split(x)):
+        assert torch.equal(got[:, piece].view(torch.int16), want.view(torch.int16)), piece
+    # the pieces carry every one of the 24 mantissa bits of a normal number: the sum IS x
+    normal = x.abs() > 1e-30
+    total = got[:, 0].double() + got[:, 1].double() + got[:, 2].double()
+    assert torch.equal(total[normal].float(), x[normal])
+    # block orders and strided outputs: a row / column range of a bigger [rows, blocks, cols]
+    six = hip.split_bf16(x, (0, 1, 2, 0, 1, 0))
+    for block, piece in enumerate((0, 1, 2, 0, 1, 0)):
+        assert torch.equal(six[:, block], got[:, piece])
+    big = torch.zeros(300, 3, 128, dtype=torch.bfloat16, device='cuda')
+    hip.split_bf16(x[10:50, 32:64], (2, 1, 0), out=big[10:50, :, 64:96])
+    assert torch.equal(big[10:50, 0, 64:96], got[10:50, 2, 32:64])
+    assert torch.equal(big[10:50, 2, 64:96], got[10:50, 0, 32:64])
+    assert float(big[:, :, :64].abs().sum()) == 0 and float(big[50:].abs().sum()) == 0
+    # blocks stacked along the rows (an operand whose K axis is its row axis)
+    stacked = torch.empty(3, 300, 64, dtype=torch.bfloat16, device='cuda')
+    hip.split_bf16(x, (0, 1, 2), out=stacked.permute(1, 0, 2))
+    assert torch.equal(stacked[1], got[:, 1])
+    # argument errors come back as errors, not as launches
+    with pytest.raises(hip.CtcAsrError):
+        hip.split_bf16(x[:, :12], (0, 1, 2))                 # cols % 8
+    with pytest.raises(hip.CtcAsrError):
+        hip.split_bf16(x, (0, 1, 3))                         # no such piece
+    with pytest.raises(hip.CtcAsrError):
+        hip.split_bf16(x, (0,) * 7)                          # too many blocks
+    with pytest.raises(hip.CtcAsrError):
+        hip.split_bf16(x.cpu(), (0, 1, 2))
+
+
+def _errors(got, ref):
+    d = got.double() - ref
+    return float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(d.abs().max())
+
+
+def test_split_products_are_at_least_as_close_to_fp64_as_the_fp32_gemm(hip):
+    """The three product layouts of split_gemm.py on a layer-sized problem (rows scaled down):
+    forward projection, data gradient, weight gradient (with a row range and a shift, as the
+    recurrent weight gradient uses them) against fp64; the plain fp32 GEMM beside them."""
+    from ctc_asr_amd import split_gemm as sg
+    g = torch.Generator(device='cuda').manual_seed(1)
+    rows, feat, gates = 2048, 1024, 4096
+    # ReLU-like activations with exact zeros, weights ~ 1/sqrt(K), gradients spanning 6 decades
+    x = torch.randn(rows, feat, device='cuda', generator=g).clamp_(0, 20)
+    w = torch.randn(gates, feat, device='cuda', generator=g) / feat ** 0.5
+    d = torch.randn(rows, gates, device='cuda', generator=g) * \
+        torch.logspace(-7, -1, rows, device='cuda')[torch.randperm(rows, device='cuda')][:, None]
+    xs, ws = sg.split(x, sg.A_ORDER), sg.split(w, sg.B_ORDER)
+    ds = sg.split(d, sg.B_ORDER)
+    wt = sg.split(w.t().contiguous(), sg.A_ORDER)
+    checks = []
+    ref = x.double() @ w.double().t()
+    checks.append(('forward', sg.mm_nt(xs, ws), torch.mm(x, w.t()), ref))
+    ref = d.double() @ w.double()
+    dx = torch.empty(rows, feat, device='cuda')
+    checks.append(('data gradient', sg.mm_nt_by_order(dx, ds, wt).clone(), torch.mm(d, w), ref))
+    sg.mm_pieces(dx, ds.piece, ws.piece)
+    checks.append(('data gradient, six calls', dx.clone(), torch.mm(d, w), ref))
+    lo, hi, shift = 64, 1984, -32
+    ref = d[lo:hi, 1024:3072].double().t() @ x[lo + shift:hi + shift, 256:768].double()
+    dw = torch.zeros(2048, 512, device='cuda')
+    sg.mm_tn_rows(dw, ds, xs, lo, hi, a_cols=slice(1024, 3072), b_cols=slice(256, 768),
+                  b_shift=shift)
+    checks.append(('weight gradient', dw,
+                   torch.mm(d[lo:hi, 1024:3072].t(), x[lo + shift:hi + shift, 256:768]), ref))
+    stacked = sg.split_rows_stacked(w.t().contiguous(), sg.B_ORDER)       # [6 feat, gates]
+    checks.append(('forward, stacked rows', sg.mm_nn_stacked(xs, stacked), torch.mm(x, w.t()),
+                   x.double() @ w.double().t()))
+    for name, split, plain, ref in checks:
+        s_rms, s_max = _errors(split, ref)
+        p_rms, p_max = _errors(plain, ref)
+        # fp32-grade: rms relative error of a few 1e-7 (fp32 epsilon 6e-8 times sqrt(K) growth),
+        # and not worse than the library's fp32 GEMM on the same operands
+        assert s_rms < 1.5e-6, (name, s_rms)
+        assert s_rms <= 1.25 * p_rms + 1e-8, (name, s_rms, p_rms)
+        assert s_max <= 2.0 * p_max + 1e-12, (name, s_max, p_max)
+
+
+def _train_steps(split, batch, frames, cell, steps=1):
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    os.environ['CTCASR_SPLIT_GEMM'] = split
+    try:
+        cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                          num_layers_rnn=2, num_units_rnn=1024, rnn_cell=cell, cudnn=True,
+                          dense_dropout_rate=0.0, conv_dropout_rate=0.0)
+        model = CTCModel(cfg, 'cuda', seed=5)
+    finally:
+        os.environ.pop('CTCASR_SPLIT_GEMM', None)
+    assert model.split_gemm == (split == '1')
+    rng = np.random.default_rng(1)
+    feats = torch.tensor(rng.normal(size=(batch, frames, 80)).astype(np.float32), device='cuda')
+    flen = torch.full((batch,), frames, dtype=torch.int32)
+    labels = [list(rng.integers(1, 28, size=20)) for _ in range(batch)]
+    for _ in range(steps):
+        loss = model.forward_backward(feats, flen, labels)
+        model.apply_gradients(1e-4)
+    torch.cuda.synchronize()
+    model.check_rnn_error()
+    return float(loss), model.last_logits.clone(), model.arena.grad.clone(), model
+
+
+@pytest.mark.parametrize('cell,batch', [('lstm', 32), ('lstm', 16), ('gru', 24)])
+def test_training_step_equals_the_fp32_gemm_step(hip, cell, batch):
+    """Same weights, same batch: loss, logits and every gradient of the split-GEMM step against the
+    step with the library's fp32 GEMMs (CTCASR_SPLIT_GEMM=0).  Both carry fp32 round-off through
+    200 recurrent steps; the two agree far inside the 1e-3 parity bar."""
+    loss0, logits0, grad0, model0 = _train_steps('0', batch, 400, cell)
+    loss1, logits1, grad1, model1 = _train_steps('1', batch, 400, cell)
+    assert model1._w_split and not model0._w_split          # the split path really ran
+    assert abs(loss0 - loss1) <= 2e-6 * abs(loss0)
+    assert float((logits0 - logits1).abs().max()) < 5e-6
+    for name, a, b in model0.arena.layer_slices:
+        ref = grad0[a:b].double()
+        rel = float((ref - grad1[a:b].double()).pow(2).sum().sqrt() /
+                    ref.pow(2).sum().sqrt().clamp_min(1e-30))
+        assert rel < 5e-4, (name, rel)
+
+
+@pytest.mark.timeout(300)
+def test_c2_shaped_steps_with_one_library_gemm_in_flight(hip):
+    """Regression: at the C2 shape (16 x 10 s, two layers) the bf16 data gradient of the bottom
+    layer [8000 x 640] on the main stream and a [4096 x 640] weight gradient on the side stream
+    - two stream-K GEMMs of the library in flight at once - waited for each other forever in the
+    second training step.  `backward` now lets the side stream's GEMMs finish before a main-stream
+    GEMM starts; six steps run and the loss moves."""
+    loss, _, _, model = _train_steps('1', 16, 1000, 'lstm', steps=6)
+    assert np.isfinite(loss) and model.step_count == 6

@@ -96,6 +96,45 @@ def forward_flops_per_utt(cfg, frames):
     return flops
 
 
+def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1):
+    """Time one step would take with every FLOP at the peak of the pipe it runs on: the fp32
+    matrix pipe (157.3 TF) for the own kernels, six bf16 products per fp32 product at the bf16 peak
+    (2500 / 6 = 417 TF fp32-equivalent) for the split GEMMs."""
+    split, fp32 = training_flops_by_pipe(cfg, frames)
+    if not split_gemm:
+        split, fp32 = 0.0, split + fp32
+    roof_ms = utterances / world * (split * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+                                    fp32 / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+    return {'ms_per_step_at_peak': round(roof_ms, 3), 'frac': round(roof_ms / ms_per_step, 4),
+            'fp32_equiv_tflop_split_gemms': round(utterances / world * split / 1e12, 3),
+            'tflop_fp32_pipe': round(utterances / world * fp32 / 1e12, 3),
+            'note': 'per GPU; split GEMMs priced at 2500 / 6 TF fp32-equivalent, own kernels at '
+                    '157.3 TF'}
+
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
+
+
+def training_flops_by_pipe(cfg, frames):
+    """(fp32-equivalent FLOPs of one utterance's training step that run as bf16-split GEMMs -
+    six bf16 products per fp32 product, ctc_asr_amd/split_gemm.py -, FLOPs that stay on the fp32
+    matrix pipe inside the own kernels).  Split: the input projections and dense4 (forward, data
+    and weight gradient) and the recurrent weight gradient; fp32: the recurrent products inside the
+    persistent kernels (forward and data gradient), the convolutions, the logits layer."""
+    from ctc_asr_amd.model import GATES
+    t_out = cfg.output_time(frames)
+    gates, hidden = GATES[cfg.cell], cfg.num_units_rnn
+    proj, rec, in_size = 0.0, 0.0, cfg.rnn_input_size()
+    for _ in range(cfg.num_layers_rnn):
+        proj += 2.0 * t_out * 2 * gates * hidden * in_size
+        rec += 2.0 * t_out * 2 * gates * hidden * hidden
+        in_size = 2 * hidden
+    dense4 = 2.0 * t_out * 2 * hidden * cfg.num_units_dense
+    total = 3.0 * forward_flops_per_utt(cfg, frames)
+    split = 3.0 * (proj + dense4) + rec
+    return split, total - split
+
+
 # ------------------------------------------------------------------------------ CPU baseline
 def _cpu_baseline_worker(spec):
     """Runs in a child process: time the torch-CPU restatement (fwd + bwd + TF-Adam).  First a
@@ -417,6 +456,12 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
             'step_tflops_fp32': round(value * flops_per_audio_s / 1e12, 2),
             'frac_of_fp32_mfma_peak': round(value * flops_per_audio_s / 1e12 /
                                             (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            'gemm_path': ('bf16x6 split: fp32 operands as three bf16 pieces each, the six products '
+                          'of order <= 2 accumulated in fp32 on the bf16 matrix pipe; closer to fp64 '
+                          'than the fp32 GEMM (profiles/r03_gemm_bf16_split.md); CTCASR_SPLIT_GEMM=0 '
+                          'selects the fp32 library GEMMs') if model.split_gemm else 'fp32 library '
+                         'GEMMs (CTCASR_SPLIT_GEMM=0)',
+            'roof': mixed_roof(cfg, frames, batch * world, ms_per_step, model.split_gemm, world),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),
@@ -636,7 +681,8 @@ def measure_c5(args, rank, local_rank, world):
 
 
 # ------------------------------------------------------------------------------ parity probe
-PROBE_BATCH, PROBE_FRAMES, PROBE_LABEL_LEN = 2, 199, 30        # T' = 100
+# (4 x 100 rows: enough for the model to take its bf16-split GEMM path, model.split_gemm)
+PROBE_BATCH, PROBE_FRAMES, PROBE_LABEL_LEN = 4, 199, 30        # T' = 100
 
 
 def _probe_setup(cfg_kwargs):
@@ -672,7 +718,7 @@ def _parity_probe_worker(spec):
 
 def parity_probe(cfg_kwargs, device, hard_limit_s=300.0):
     """The second half of BASELINE.json's metric ("CTC loss delta vs ref"): one forward + CTC
-    loss of the workload's architecture on a small fixed batch (B = 2, T' = 100, seeded weights
+    loss of the workload's architecture on a small fixed batch (B = 4, T' = 100, seeded weights
     and inputs, dropout off) on the GPU - through the same kernels as the timed steps - against
     the oracle (``oracle/torch_ref.py`` in float64, in a child process on the host).  The oracle
     is the checker here, outside the timed region."""
@@ -684,6 +730,7 @@ def parity_probe(cfg_kwargs, device, hard_limit_s=300.0):
     loss = float(model.loss_fn(logits, seq_len, labels))
     model.check_rnn_error()
     got = logits.cpu().numpy()
+    split_ran = bool(model._w_split)
     del model
     torch.cuda.empty_cache()
     _, physical = host_cores()
@@ -703,7 +750,7 @@ def parity_probe(cfg_kwargs, device, hard_limit_s=300.0):
     return {'ctc_loss_delta': abs(loss - ref_loss),
             'logits_max_abs_delta': float(np.abs(got - ref_logits).max()),
             'loss_gpu': loss, 'loss_oracle': ref_loss, 'tolerance': 1e-3,
-            'batch': PROBE_BATCH, 'ctc_steps': int(got.shape[0]),
+            'batch': PROBE_BATCH, 'ctc_steps': int(got.shape[0]), 'split_gemms': split_ran,
             'note': 'forward + CTC loss of this workload\'s architecture, seeded weights / inputs, '
                     'dropout off, GPU fp32 vs oracle/torch_ref.py float64 on the host (checker, '
                     'outside the timed region)'}

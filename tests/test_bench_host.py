@@ -95,3 +95,19 @@ def test_c5_bucket_sequence_is_fixed_and_bucketed():
         assert (samples.max() - samples.min()) / 16000.0 < 1.0
     longest = [int(s.max()) for s in first]
     assert max(longest) > 2 * min(longest)           # the padded length really varies
+
+
+def test_flops_by_pipe_add_up_and_price_the_mixed_roof():
+    import bench
+    from ctc_asr_amd.model import ModelConfig
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=5, num_units_rnn=1024, rnn_cell='lstm', cudnn=True)
+    split, fp32 = bench.training_flops_by_pipe(cfg, 999)
+    assert abs(split + fp32 - 3.0 * bench.forward_flops_per_utt(cfg, 999)) < 1e-3 * (split + fp32)
+    assert split > 2.0 * fp32 > 0.0         # C3: the projections dominate
+    with_split = bench.mixed_roof(cfg, 999, 32, 86.0, True)
+    without = bench.mixed_roof(cfg, 999, 32, 96.0, False)
+    # same FLOPs; 6 bf16 products at 2500 TF are 2.65 x the fp32 pipe's rate
+    assert with_split['ms_per_step_at_peak'] < without['ms_per_step_at_peak']
+    assert abs(without['ms_per_step_at_peak'] - 32 * (split + fp32) / 157.3e12 * 1e3) < 0.01
+    assert 0.0 < with_split['frac'] < 1.0 and 0.0 < without['frac'] < 1.0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTCASR_ABI_VERSION 3
+#define CTCASR_ABI_VERSION 4
 
 enum {
     CTCASR_OK = 0,

@@ -149,83 +149,71 @@ def main():
     print(json.dumps(report['dgrad']), flush=True)
     del da, wk
 
-    # ---- the HIP split kernel against the torch restatement, and a whole layer's GEMMs in a loop
-    from ctc_asr_amd import hip
+    # ---- the product path (ctc_asr_amd/split_gemm.py): HIP split kernel, final layouts ----------
+    from ctc_asr_amd import hip, split_gemm as sg
     hip.load()
-    A_ORDER, B_ORDER = (0, 1, 2, 0, 1, 0), (2, 1, 0, 1, 0, 0)
-    xs = hip.split_bf16(x, A_ORDER)
-    assert torch.equal(xs.view(R, 6 * F), torch.cat([x1, x2, x3, x1, x2, x1], dim=1))
-    ws = hip.split_bf16(w, B_ORDER)
-    ds = hip.split_bf16(d, (0, 1, 2))
-    assert torch.equal(ds.view(R, 3 * G), torch.cat([d1, d2, d3], dim=1))
+    xs, ws, ds = sg.split(x, sg.A_ORDER), sg.split(w, sg.B_ORDER), sg.split(d, sg.B_ORDER)
+    w_t = w.t().contiguous()
+    wt = sg.split(w_t, sg.A_ORDER)
+    assert torch.equal(xs.concat(), torch.cat([x1, x2, x3, x1, x2, x1], dim=1))
     report['split_kernel_ms'] = {
-        'x_six_blocks': round(timed(lambda: hip.split_bf16(x, A_ORDER, out=xs), 20, 5), 3),
-        'w_six_blocks': round(timed(lambda: hip.split_bf16(w, B_ORDER, out=ws), 20, 5), 3),
-        'd_three_blocks': round(timed(lambda: hip.split_bf16(d, (0, 1, 2), out=ds), 20, 5), 3)}
+        'x [16000 x 2048] -> six blocks': round(timed(lambda: sg.split(x, sg.A_ORDER, out=xs), 20, 5), 3),
+        'w [8192 x 2048] -> six blocks': round(timed(lambda: sg.split(w, sg.B_ORDER, out=ws), 20, 5), 3),
+        'd [16000 x 8192] -> six blocks': round(timed(lambda: sg.split(d, sg.B_ORDER, out=ds), 20, 5), 3)}
     print(json.dumps(report['split_kernel_ms']), flush=True)
-    f32 = torch.float32
-    xw = torch.empty(R, G, device=dev)
-    xpiece = {0: xs[:, 0], 1: xs[:, 1], 2: xs[:, 2]}                # [R, F] views, row stride 6F
-    wpiece = {2: ws[:, 0], 1: ws[:, 1], 0: ws[:, 2]}
-    dpiece = {0: ds[:, 0], 1: ds[:, 1], 2: ds[:, 2]}
     H = F // 2
+    xw = torch.empty(R, G, device=dev)
+    dwh = torch.zeros(2, 4 * H, H, device=dev)
+    dw2 = dw.view(2, 4 * H, F)
+    chunks = [(0, R // 3), (R // 3, 2 * (R // 3)), (2 * (R // 3), R)]
 
     def layer_split():
-        hip.split_bf16(x, A_ORDER, out=xs)
-        torch.mm(xs.view(R, 6 * F), ws.view(G, 6 * F).t(), out_dtype=f32, out=xw)
-        hip.split_bf16(d, (0, 1, 2), out=ds)
-        first = True
-        for i, j in pairs:
-            if first:
-                torch.mm(dpiece[i], wpiece[j], out_dtype=f32, out=dx)
-            else:
-                torch.addmm(dx, dpiece[i], wpiece[j], out_dtype=f32, out=dx)
-            first = False
-        first = True
-        for i, j in pairs:
-            if first:
-                torch.mm(dpiece[i].t(), xpiece[j], out_dtype=f32, out=dw)
-            else:
-                torch.addmm(dw, dpiece[i].t(), xpiece[j], out_dtype=f32, out=dw)
-            first = False
-        for dirn in (0, 1):                 # recurrent weight gradient: [4H, R] x [R, H] per direction
-            out = dwh[dirn]
-            first = True
-            for i, j in pairs:
-                a = dpiece[i][:, dirn * 4 * H:(dirn + 1) * 4 * H].t()
-                b = xpiece[j][:, dirn * H:(dirn + 1) * H]
-                if first:
-                    torch.mm(a, b, out_dtype=f32, out=out)
-                else:
-                    torch.addmm(out, a, b, out_dtype=f32, out=out)
-                first = False
-
-    dwh = torch.empty(2, 4 * H, H, device=dev)
+        sg.split(x, sg.A_ORDER, out=xs)
+        sg.mm_nt(xs, ws, out=xw)
+        sg.split(d, sg.B_ORDER, out=ds)
+        sg.mm_nt_by_order(dx, ds, wt)
+        for lo, hi in chunks:               # weight gradients per third of the steps, as the
+            for dirn in (0, 1):             # backward pass issues them
+                cols = slice(dirn * 4 * H, (dirn + 1) * 4 * H)
+                sg.mm_tn_rows(dw2[dirn], ds, xs, lo, hi, a_cols=cols)
+                sg.mm_tn_rows(dwh[dirn], ds, xs, lo, hi, a_cols=cols,
+                              b_cols=slice(dirn * H, (dirn + 1) * H))
 
     def layer_f32():
         torch.mm(x, w.t(), out=xw)
         torch.mm(d, w, out=dx)
-        torch.mm(d.t(), x, out=dw)
-        for dirn in (0, 1):
-            torch.mm(d[:, dirn * 4 * H:(dirn + 1) * 4 * H].t(), x[:, dirn * H:(dirn + 1) * H],
-                     out=dwh[dirn])
+        for lo, hi in chunks:
+            for dirn in (0, 1):
+                cols = slice(dirn * 4 * H, (dirn + 1) * 4 * H)
+                dw2[dirn].addmm_(d[lo:hi, cols].t(), x[lo:hi])
+                dwh[dirn].addmm_(d[lo:hi, cols].t(), x[lo:hi, dirn * H:(dirn + 1) * H])
 
-    layer_split()
-    check = {'xw': errors(xw[sub], x[sub].double() @ w.double().t()),
-             'dx': errors(dx[sub], d[sub].double() @ w.double()),
-             'dw': errors(dw[sub], d.double().t()[sub] @ x.double()),
-             'dwh': errors(dwh[0][sub], d[:, :4 * H].double().t()[sub] @ x[:, :H].double())}
-    layer_f32()
-    check_f32 = {'xw': errors(xw[sub], x[sub].double() @ w.double().t()),
-                 'dx': errors(dx[sub], d[sub].double() @ w.double()),
-                 'dw': errors(dw[sub], d.double().t()[sub] @ x.double()),
-                 'dwh': errors(dwh[0][sub], d[:, :4 * H].double().t()[sub] @ x[:, :H].double())}
+    def layer_errors(fn):
+        dw.zero_(); dwh.zero_()
+        fn()
+        return {'xw': errors(xw[sub], x[sub].double() @ w.double().t()),
+                'dx': errors(dx[sub], d[sub].double() @ w.double()),
+                'dW_ih': errors(dw[sub], d.double().t()[sub] @ x.double()),
+                'dW_hh': errors(dwh[0][sub], d[:, :4 * H].double().t()[sub] @ x[:, :H].double())}
+
     report['layer'] = {
-        'gemms': 'xw, dx, dW_ih, 2 x dW_hh of one C3 layer, 60 layers back to back',
+        'gemms': 'xw, dx, dW_ih and dW_hh (in thirds of the steps, per direction) of one C3 layer, '
+                 '60 layers back to back',
+        'split_err': layer_errors(layer_split), 'f32_err': layer_errors(layer_f32),
         'f32_ms': round(timed(layer_f32, 60, 10), 3),
         'split_ms': round(timed(layer_split, 60, 10), 3),
-        'f32_ms_again': round(timed(layer_f32, 60, 10), 3),
-        'split_err': check, 'f32_err': check_f32}
+        'f32_ms_again': round(timed(layer_f32, 60, 10), 3)}
+    one = {}
+    for name, fn, flops_ in (
+            ('forward one call K = 6 x 2048', lambda: sg.mm_nt(xs, ws, out=xw), 6 * flops),
+            ('data gradient, three NT calls', lambda: sg.mm_nt_by_order(dx, ds, wt), 6 * flops),
+            ('data gradient, six NN calls', lambda: sg.mm_pieces(dx, ds.piece, ws.piece), 6 * flops),
+            ('W_ih gradient, one third of the steps, one direction',
+             lambda: sg.mm_tn_rows(dw2[0], ds, xs, 0, R // 3, a_cols=slice(0, 4 * H)),
+             6 * flops / 6)):
+        ms = timed(fn, 40, 10)
+        one[name] = {'ms': round(ms, 3), 'raw_bf16_tflops': round(flops_ / ms / 1e9, 0)}
+    report['split_calls'] = one
     print(json.dumps(report['layer']), flush=True)
     print(json.dumps(report, indent=1))
 

@@ -70,6 +70,8 @@ SIGNATURES = {
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_split_bf16': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_int, _c_p, _c_i64, _c_i64,
                                    _c_p]),
+    'ctcasr_gemm_split_nt': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
+                                      _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
     'ctcasr_features_init_tables': (_c_int, [_c_p, _c_int, _c_p]),
@@ -472,6 +474,33 @@ def split_bf16(x, order, out=None):
                                     out.stride(0) if rows > 1 else len(order) * cols,
                                     out.stride(1) if len(order) > 1 else cols, _stream()),
            'split_bf16')
+    return out
+
+
+@_on_tensor_device
+def gemm_split_nt(a, b, out=None, accumulate=False):
+    """out[M, N] (+)= a[M, K] . b[N, K]^T, fp32 matrices with unit column stride (row strides
+    free), computed on the bf16 matrix pipe from in-register three-piece splits
+    (include/ctcasr.h: ctcasr_gemm_split_nt)."""
+    for name, t in (('a', a), ('b', b)):
+        if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+            raise CtcAsrError('gemm_split_nt: {} must be an f32 matrix in HBM with unit column '
+                              'stride.'.format(name))
+    m, k = a.shape
+    n = b.shape[0]
+    if b.shape[1] != k:
+        raise CtcAsrError('gemm_split_nt: a [M, K] and b [N, K] disagree on K.')
+    if out is None:
+        if accumulate:
+            raise CtcAsrError('gemm_split_nt: accumulate needs out.')
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    elif (out.dtype != torch.float32 or tuple(out.shape) != (m, n) or out.stride(1) != 1 or
+          out.device != a.device):
+        raise CtcAsrError('gemm_split_nt: out must be an f32 [M, N] view with unit column stride.')
+    _check(load().ctcasr_gemm_split_nt(a.data_ptr(), a.stride(0) if m > 1 else k, b.data_ptr(),
+                                       b.stride(0) if n > 1 else k, out.data_ptr(),
+                                       out.stride(0) if m > 1 else n, m, n, k, int(accumulate),
+                                       _stream()), 'gemm_split_nt')
     return out
 
 

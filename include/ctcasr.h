@@ -314,6 +314,14 @@ int ctcasr_split_bf16(const float *x, int64_t rows, int cols, int64_t ld_x, cons
                       int blocks, void *out, int64_t ld_out, int64_t block_stride,
                       ctcasr_stream_t stream);
 
+/* The same product with the split done in registers by an own kernel (csrc/split_gemm.hip): no
+ * split pass, no K-concatenated copies, no inter-workgroup waits.
+ *   C[M, N] (+)= A[M, K] . B[N, K]^T    all fp32, row-major with leading dimensions lda / ldb / ldc
+ *   (elements); K % 16 == 0, lda % 4 == ldb % 4 == 0, A and B 16-byte aligned; accumulate != 0 adds
+ *   to C.  Result: the six bf16 piece products of order <= 2 in fp32 accumulation, as above. */
+int ctcasr_gemm_split_nt(const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                         int64_t ldc, int m, int n, int k, int accumulate, ctcasr_stream_t stream);
+
 /* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
  * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):
  *   lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step);  m, v updated in place;

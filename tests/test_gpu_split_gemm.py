@@ -153,3 +153,34 @@ def test_c2_shaped_steps_with_one_library_gemm_in_flight(hip):
     GEMM starts; six steps run and the loss moves."""
     loss, _, _, model = _train_steps('1', 16, 1000, 'lstm', steps=6)
     assert np.isfinite(loss) and model.step_count == 6
+
+
+@pytest.mark.parametrize('m,n,k', [(300, 270, 48), (256, 256, 16), (1, 5, 32), (700, 513, 2048),
+                                   (2048, 1024, 640)])
+def test_own_split_gemm_kernel(hip, m, n, k):
+    """`ctcasr_gemm_split_nt` - fp32 tiles split in registers, six bf16 MFMAs per fragment pair,
+    no library call - against fp64: partial tiles in both directions, K from one step to many,
+    strided operands and output, accumulation.  fp32-grade: its error stays within 1.5 x of the
+    library fp32 GEMM's on the same operands (it adds all six products into ONE fp32 accumulator,
+    where the K-concatenated library form sums the small terms first)."""
+    g = torch.Generator(device='cuda').manual_seed(m + n + k)
+    big_a = torch.randn(m, k + 8, device='cuda', generator=g)
+    big_b = torch.randn(n, k + 4, device='cuda', generator=g) / k ** 0.5
+    a, b = big_a[:, 4:4 + k], big_b[:, :k]                 # row strides k + 8 / k + 4
+    ref = a.double() @ b.double().t()
+    got = hip.gemm_split_nt(a, b)
+    plain = torch.mm(a, b.t())
+    scale = float(ref.abs().max()) + 1e-30
+    assert float((got.double() - ref).abs().max()) <= \
+        1.5 * float((plain.double() - ref).abs().max()) + 2e-7 * scale
+    # into a column range of a wider matrix, accumulating
+    wide = torch.ones(m, n + 6, device='cuda')
+    hip.gemm_split_nt(a, b, out=wide[:, 3:3 + n], accumulate=True)
+    assert torch.equal(wide[:, :3], torch.ones(m, 3, device='cuda'))
+    assert torch.equal(wide[:, 3 + n:], torch.ones(m, 3, device='cuda'))
+    assert float((wide[:, 3:3 + n].double() - 1.0 - ref).abs().max()) <= \
+        1.5 * float((plain.double() - ref).abs().max()) + 4e-7 * (scale + 1.0)
+    with pytest.raises(hip.CtcAsrError):
+        hip.gemm_split_nt(a[:, :k - 4], b[:, :k - 4])        # K % 16
+    with pytest.raises(hip.CtcAsrError):
+        hip.gemm_split_nt(a, b[:, :k - 16])                  # K mismatch

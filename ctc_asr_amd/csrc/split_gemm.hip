@@ -57,7 +57,11 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4 &p1, bf16x4 &p2, b
     }
 }
 
-__global__ void __launch_bounds__(SG_THREADS) split_gemm_nt_kernel(SgArgs p) {
+// TN = false: A [M, K], B [N, K] (K is the column axis of both: projections, data gradient)
+// TN = true:  A [K, M], B [K, N] (K is the row axis of both: weight gradients); any K, rows past
+//             it count as zeros
+template <bool TN>
+__global__ void __launch_bounds__(SG_THREADS) split_gemm_kernel(SgArgs p) {
     // Two separate arrays, not one dynamic block: the compiler then knows that the LDS writes of
     // the next stage cannot alias the fragment reads of this one and is free to move them (and
     // the VALU work that feeds them) in between the MFMAs.
@@ -79,30 +83,52 @@ __global__ void __launch_bounds__(SG_THREADS) split_gemm_nt_kernel(SgArgs p) {
     const int tm = group * GROUP + within % rows_here, tn = within / rows_here;
     const int m0 = tm * SG_BM, n0 = tn * SG_BN;
 
-    // global -> register staging: thread t, unit i: row (t >> 2) + 64 i, columns 4 (t & 3) ..
+    // global -> register staging.  NT: thread t, unit i: row (t >> 2) + 64 i of the tile, columns
+    // 4 (t & 3) .. of the K step (16-byte loads).  TN: thread t owns COLUMN t of both tiles and
+    // loads its 16 K rows one by one (a wave reads 256 contiguous bytes per row).
+    // (Rows / columns past the matrix are clamped to its last one: they only feed rows / columns of
+    // C that are never stored, so those loads need no predicate.)
     const int lrow = tid >> 2, lkq = tid & 3;
-    // (rows past the matrix are clamped to its last row: they only feed rows / columns of C
-    // that are never stored, so the loads need no predicate)
     const float *ga[4], *gb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ga[i] = p.a + (int64_t)min(m0 + lrow + 64 * i, p.m - 1) * p.lda + 4 * lkq;
-        gb[i] = p.b + (int64_t)min(n0 + lrow + 64 * i, p.n - 1) * p.ldb + 4 * lkq;
-    }
     float4 ra[4], rb[4];
-    auto load_stage = [&](int k0) {
+    if (TN) {
+        ga[0] = p.a + min(m0 + tid, p.m - 1);
+        gb[0] = p.b + min(n0 + tid, p.n - 1);
+    } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const float4 *>(ga[i] + k0);
-            rb[i] = *reinterpret_cast<const float4 *>(gb[i] + k0);
+            ga[i] = p.a + (int64_t)min(m0 + lrow + 64 * i, p.m - 1) * p.lda + 4 * lkq;
+            gb[i] = p.b + (int64_t)min(n0 + lrow + 64 * i, p.n - 1) * p.ldb + 4 * lkq;
+        }
+    }
+    auto load_stage = [&](int k0) {
+        if (TN) {
+            float *fa = reinterpret_cast<float *>(ra), *fbv = reinterpret_cast<float *>(rb);
+#pragma unroll
+            for (int kk = 0; kk < SG_BK; ++kk) {
+                const int row = k0 + kk;
+                const float keep = row < p.k ? 1.f : 0.f;        // (wave-uniform)
+                const int64_t r = min(row, p.k - 1);
+                fa[kk] = keep * ga[0][r * p.lda];
+                fbv[kk] = keep * gb[0][r * p.ldb];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const float4 *>(ga[i] + k0);
+                rb[i] = *reinterpret_cast<const float4 *>(gb[i] + k0);
+            }
         }
     };
+    // piece layout in LDS: [k group of 8][row][8] - the 32 rows a half-wave reads are 512
+    // contiguous bytes (row-major [row][16] makes lanes r and r + 8 share banks)
     auto store_stage = [&](__bf16 *base) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // piece layout [k group of 8][row][8]: the 32 rows a half-wave reads are 512
-            // contiguous bytes (row-major [row][16] makes lanes r and r + 8 share banks)
-            const int off = (lkq >> 1) * (SG_BM * 8) + (lrow + 64 * i) * 8 + 4 * (lkq & 1);
+            // NT: unit i = 4 columns (k) of row lrow + 64 i;  TN: unit i = k rows 4 i .. 4 i + 3
+            // of column tid
+            const int off = TN ? (i >> 1) * (SG_BM * 8) + tid * 8 + 4 * (i & 1)
+                               : (lkq >> 1) * (SG_BM * 8) + (lrow + 64 * i) * 8 + 4 * (lkq & 1);
             bf16x4 p1, p2, p3;
             split4(ra[i], p1, p2, p3);
             *reinterpret_cast<bf16x4 *>(base + 0 * SG_PIECE + off) = p1;
@@ -123,7 +149,7 @@ __global__ void __launch_bounds__(SG_THREADS) split_gemm_nt_kernel(SgArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int steps = p.k / SG_BK;
+    const int steps = (p.k + SG_BK - 1) / SG_BK;
     load_stage(0);
     store_stage(stage0);
     load_stage(min(1, steps - 1) * SG_BK);
@@ -176,7 +202,7 @@ __global__ void __launch_bounds__(SG_THREADS) split_gemm_nt_kernel(SgArgs p) {
                 SG_GROUP(0x002, SG_VALU);
                 if ((g - SG_QUIET) % SG_UNIT == SG_UNIT - 1) {
                     SG_GROUP(0x200, 2);
-                    SG_GROUP(0x020, 1);
+                    SG_GROUP(0x020, TN ? 4 : 1);
                 }
             }
             if (g == 14 || g == 38 || g == 62) SG_GROUP(0x100, 3);
@@ -210,6 +236,20 @@ __global__ void __launch_bounds__(SG_THREADS) split_gemm_nt_kernel(SgArgs p) {
 
 }  // namespace
 
+static int launch_split_gemm(bool tn, const float *a, int64_t lda, const float *b, int64_t ldb,
+                             float *c, int64_t ldc, int m, int n, int k, int accumulate,
+                             hipStream_t stream) {
+    SgArgs args{a, b, c, lda, ldb, ldc, m, n, k, accumulate,
+                (m + SG_BM - 1) / SG_BM, (n + SG_BN - 1) / SG_BN};
+    const int tiles = args.tiles_m * args.tiles_n;
+    const int grid = 8 * ((tiles + 7) / 8);
+    if (tn)
+        split_gemm_kernel<true><<<grid, SG_THREADS, 0, stream>>>(args);
+    else
+        split_gemm_kernel<false><<<grid, SG_THREADS, 0, stream>>>(args);
+    return ctcasr_launch_status();
+}
+
 extern "C" int ctcasr_gemm_split_nt(const float *a, int64_t lda, const float *b, int64_t ldb,
                                     float *c, int64_t ldc, int m, int n, int k, int accumulate,
                                     ctcasr_stream_t stream) {
@@ -218,10 +258,15 @@ extern "C" int ctcasr_gemm_split_nt(const float *a, int64_t lda, const float *b,
         return CTCASR_ERR_BAD_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 != 0)
         return CTCASR_ERR_BAD_ARGUMENT;
-    SgArgs args{a, b, c, lda, ldb, ldc, m, n, k, accumulate,
-                (m + SG_BM - 1) / SG_BM, (n + SG_BN - 1) / SG_BN};
-    const int tiles = args.tiles_m * args.tiles_n;
-    const int grid = 8 * ((tiles + 7) / 8);
-    split_gemm_nt_kernel<<<grid, SG_THREADS, 0, (hipStream_t)stream>>>(args);
-    return ctcasr_launch_status();
+    return launch_split_gemm(false, a, lda, b, ldb, c, ldc, m, n, k, accumulate,
+                             (hipStream_t)stream);
+}
+
+extern "C" int ctcasr_gemm_split_tn(const float *a, int64_t lda, const float *b, int64_t ldb,
+                                    float *c, int64_t ldc, int m, int n, int k, int accumulate,
+                                    ctcasr_stream_t stream) {
+    if (!a || !b || !c || m <= 0 || n <= 0 || k <= 0 || lda < m || ldb < n || ldc < n)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    return launch_split_gemm(true, a, lda, b, ldb, c, ldc, m, n, k, accumulate,
+                             (hipStream_t)stream);
 }

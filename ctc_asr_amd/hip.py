@@ -72,6 +72,8 @@ SIGNATURES = {
                                    _c_p]),
     'ctcasr_gemm_split_nt': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
                                       _c_int, _c_p]),
+    'ctcasr_gemm_split_tn': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
+                                      _c_int, _c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
     'ctcasr_features_init_tables': (_c_int, [_c_p, _c_int, _c_p]),
@@ -501,6 +503,26 @@ def gemm_split_nt(a, b, out=None, accumulate=False):
                                        b.stride(0) if n > 1 else k, out.data_ptr(),
                                        out.stride(0) if m > 1 else n, m, n, k, int(accumulate),
                                        _stream()), 'gemm_split_nt')
+    return out
+
+
+@_on_tensor_device
+def gemm_split_tn(a, b, out, accumulate=True):
+    """out[M, N] (+)= a[K, M]^T . b[K, N] - a product over the ROW axis of both fp32 operands
+    (weight gradients) - on the bf16 matrix pipe from in-register three-piece splits
+    (include/ctcasr.h: ctcasr_gemm_split_tn).  Unit column strides, any row strides, any K."""
+    for name, t in (('a', a), ('b', b), ('out', out)):
+        if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+            raise CtcAsrError('gemm_split_tn: {} must be an f32 matrix in HBM with unit column '
+                              'stride.'.format(name))
+    k, m = a.shape
+    n = b.shape[1]
+    if b.shape[0] != k or tuple(out.shape) != (m, n):
+        raise CtcAsrError('gemm_split_tn: a [K, M], b [K, N] and out [M, N] disagree.')
+    _check(load().ctcasr_gemm_split_tn(a.data_ptr(), a.stride(0) if k > 1 else m, b.data_ptr(),
+                                       b.stride(0) if k > 1 else n, out.data_ptr(),
+                                       out.stride(0) if m > 1 else n, m, n, k, int(accumulate),
+                                       _stream()), 'gemm_split_tn')
     return out
 
 

@@ -321,6 +321,10 @@ int ctcasr_split_bf16(const float *x, int64_t rows, int cols, int64_t ld_x, cons
  *   to C.  Result: the six bf16 piece products of order <= 2 in fp32 accumulation, as above. */
 int ctcasr_gemm_split_nt(const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
                          int64_t ldc, int m, int n, int k, int accumulate, ctcasr_stream_t stream);
+/*   C[M, N] (+)= A[K, M]^T . B[K, N]   (K = the ROW axis of both operands: the weight gradients
+ *   dW = dxw^T x of asr/model.py:203-214's layers); any K, no alignment requirement. */
+int ctcasr_gemm_split_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                         int64_t ldc, int m, int n, int k, int accumulate, ctcasr_stream_t stream);
 
 /* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
  * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):

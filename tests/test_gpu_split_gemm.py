@@ -184,3 +184,27 @@ def test_own_split_gemm_kernel(hip, m, n, k):
         hip.gemm_split_nt(a[:, :k - 4], b[:, :k - 4])        # K % 16
     with pytest.raises(hip.CtcAsrError):
         hip.gemm_split_nt(a, b[:, :k - 16])                  # K mismatch
+
+
+@pytest.mark.parametrize('m,n,k', [(300, 270, 48), (256, 256, 16), (5, 1, 7), (513, 700, 1000),
+                                   (4096, 640, 5344)])
+def test_own_split_gemm_kernel_over_the_row_axis(hip, m, n, k):
+    """`ctcasr_gemm_split_tn`: out (+)= a[K, M]^T b[K, N] - the weight-gradient form - for any K
+    (rows past K count as zeros), column ranges of wider operands, accumulation into a zeroed or
+    a filled out."""
+    g = torch.Generator(device='cuda').manual_seed(m * 7 + n + k)
+    wide_a = torch.randn(k, m + 5, device='cuda', generator=g) * \
+        torch.logspace(-4, 0, k, device='cuda')[:, None]
+    wide_b = torch.randn(k, n + 3, device='cuda', generator=g).clamp_(0, 20)
+    a, b = wide_a[:, 2:2 + m], wide_b[:, 1:1 + n]
+    ref = a.double().t() @ b.double()
+    plain = torch.mm(a.t(), b)
+    scale = float(ref.abs().max()) + 1e-30
+    out = torch.full((m, n), 3.0, device='cuda')
+    hip.gemm_split_tn(a, b, out, accumulate=False)
+    bound = 1.5 * float((plain.double() - ref).abs().max()) + 2e-7 * scale
+    assert float((out.double() - ref).abs().max()) <= bound
+    hip.gemm_split_tn(a, b, out, accumulate=True)
+    assert float((out.double() - 2.0 * ref).abs().max()) <= 2.5 * bound
+    with pytest.raises(hip.CtcAsrError):
+        hip.gemm_split_tn(a, b[:-1], out)

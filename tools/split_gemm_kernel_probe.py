@@ -67,3 +67,23 @@ for name, m, n, k in (('forward projection', 16000, 8192, 2048),
     row['library fp32 GEMM'] = {'ms': round(t, 3), 'err': err(out[sub], ref)}
     report['{} [{} x {}] x [{} x {}]^T'.format(name, m, k, n, k)] = row
     print(json.dumps({name: row}), flush=True)
+
+# weight-gradient form: one third of the C3 steps, one direction
+from ctc_asr_amd import split_gemm as sg2
+rows = 5344
+d = torch.randn(16000, 8192, device='cuda', generator=g) * 1e-3
+x = torch.randn(16000, 2048, device='cuda', generator=g).clamp_(0, 20)
+ds, xs = sg2.split(d, sg2.B_ORDER), sg2.split(x, sg2.A_ORDER)
+for name, ncols in (('W_ih gradient [5344 x 4096]^T x [5344 x 2048]', 2048),
+                    ('W_hh gradient [5344 x 4096]^T x [5344 x 1024]', 1024)):
+    dw = torch.zeros(4096, ncols, device='cuda')
+    ref = d[:rows, :4096].double().t()[:256] @ x[:rows, :ncols].double()
+    row = {}
+    t = timed(lambda: hip.gemm_split_tn(d[:rows, :4096], x[:rows, :ncols], dw, accumulate=False))
+    row['own kernel (fp32 operands)'] = {'ms': round(t, 3), 'err': err(dw[:256], ref)}
+    t = timed(lambda: sg2.mm_tn_rows(dw, ds, xs, 0, rows, a_cols=slice(0, 4096),
+                                     b_cols=slice(0, ncols), accumulate=False))
+    row['library bf16 GEMM on six-block pieces'] = {'ms': round(t, 3), 'err': err(dw[:256], ref)}
+    t = timed(lambda: torch.mm(d[:rows, :4096].t(), x[:rows, :ncols], out=dw))
+    row['library fp32 GEMM'] = {'ms': round(t, 3), 'err': err(dw[:256], ref)}
+    print(json.dumps({name: row}), flush=True)

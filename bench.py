@@ -267,7 +267,8 @@ def pmc_traffic(workload, which, launch_steps):
                             'profiles/pmc_traffic.json'.format(workload, which, launch_steps)}
 
 
-def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=True):
+def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=True,
+            split_gemm=None):
     """Build the workload ``name`` on this rank's GPU, run warm-up + timed steps under the
     contract's protocol and return the result dict (rank 0) or None.  ``allreduce_early``
     selects the release mode of the gradient buckets (None: the environment / default),
@@ -287,6 +288,8 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
     trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True,
                       allreduce_early=allreduce_early, reduce=reduce)
     model = trainer.model
+    if split_gemm is not None:          # (None: the model's default / CTCASR_SPLIT_GEMM)
+        model.split_gemm = bool(split_gemm)
     if args.rnn_bwd_whole_chip:
         model.rnn_bwd_flags = hip.RNN_WHOLE_CHIP
 
@@ -899,6 +902,14 @@ def main():
                                                   'kernel_ms_per_step', 'roofline')}
         except Exception as err:        # noqa: BLE001 - anything: keep the headline line
             other['c2'] = {'error': '{}: {}'.format(type(err).__name__, err)}
+        try:
+            # the headline workload once more with the library's fp32 GEMMs (no bf16 split): what
+            # the split buys, on this box, in this run
+            plain, _ = measure('c3', args, rank, local_rank, world, split_gemm=False)
+            other['c3_fp32_library_gemms'] = {k: plain[k] for k in (
+                'value', 'unit', 'ms_per_step', 'gemm_path', 'roof', 'kernel_ms_per_step')}
+        except Exception as err:        # noqa: BLE001
+            other['c3_fp32_library_gemms'] = {'error': '{}: {}'.format(type(err).__name__, err)}
         try:
             c5_args = argparse.Namespace(**vars(args))
             c5_args.steps = args.c5_batches

@@ -11,7 +11,8 @@ if roof.get('us_per_time_step'):
     out.append('dominant kernel {} us/time step (other pass {})'.format(
         roof['us_per_time_step'], roof.get('other_pass', {}).get('us_per_time_step')))
 for name, other in (d.get('other_workloads') or {}).items():
-    out.append('{}: {} ({} ms/step)'.format(name, other['value'], other['ms_per_step']))
+    out.append('{}: {} ({} ms/step)'.format(name, other.get('value', other.get('error')),
+                                            other.get('ms_per_step')))
 if 'ctc_loss_delta' in d:
     out.append('loss delta {} logits delta {}'.format(d['ctc_loss_delta'],
                                                       d['logits_max_abs_delta']))

@@ -129,7 +129,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get('CTCASR_LIB') or LIB_PATH      # (A/B builds: tools/build_alt.sh)
     if not os.path.exists(path):
         raise CtcAsrError('{} is missing - build it with `python -m ctc_asr_amd.build`; the '
                           'MI355X path has no CPU fallback.'.format(path))

@@ -6,7 +6,7 @@ faulthandler.dump_traceback_later(60, exit=True)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ctc_asr_amd import hip
-hip.load()
+hip.load(os.environ.get("CTCASR_LIB"))
 F32 = torch.float32
 T, B, H = 500, int(sys.argv[1]) if len(sys.argv) > 1 else 16, 1024
 kind = sys.argv[2] if len(sys.argv) > 2 else 'bf16'

@@ -70,6 +70,8 @@ SIGNATURES = {
     'ctcasr_transpose_batched': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_split_bf16': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_int, _c_p, _c_i64, _c_i64,
                                    _c_p]),
+    'ctcasr_split_f16': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_f, _c_p, _c_int, _c_p, _c_i64,
+                                  _c_i64, _c_p]),
     'ctcasr_gemm_split_nt': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
                                       _c_int, _c_p]),
     'ctcasr_gemm_split_tn': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
@@ -476,6 +478,30 @@ def split_bf16(x, order, out=None):
                                     out.stride(0) if rows > 1 else len(order) * cols,
                                     out.stride(1) if len(order) > 1 else cols, _stream()),
            'split_bf16')
+    return out
+
+
+@_on_tensor_device
+def split_f16(x, scale, order, out=None):
+    """x f32 [rows, cols] -> fp16 ``out[rows, len(order), cols]``: block b holds piece ``order[b]``
+    (0 / 1) of the two-piece fp16 split of x * scale (include/ctcasr.h: ctcasr_split_f16).  The
+    caller guarantees |x| * scale < 65504."""
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1:
+        raise CtcAsrError('split_f16: x must be an f32 matrix in HBM with unit column stride.')
+    rows, cols = x.shape
+    order = [int(v) for v in order]
+    if out is None:
+        out = torch.empty((rows, len(order), cols), dtype=torch.float16, device=x.device)
+    elif (out.dtype != torch.float16 or tuple(out.shape) != (rows, len(order), cols) or
+          out.stride(2) != 1 or out.device != x.device):
+        raise CtcAsrError('split_f16: out must be an fp16 [rows, blocks, cols] view with unit '
+                          'column stride on the device of x.')
+    arr = (ctypes.c_int * len(order))(*order)
+    _check(load().ctcasr_split_f16(x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols,
+                                   float(scale), arr, len(order), out.data_ptr(),
+                                   out.stride(0) if rows > 1 else len(order) * cols,
+                                   out.stride(1) if len(order) > 1 else cols, _stream()),
+           'split_f16')
     return out
 
 

@@ -341,6 +341,9 @@ class CTCModel:
         # splits on the bf16 matrix pipe: fp32-grade results (split_gemm.py), 1.2x the GEMM rate
         self.split_gemm = os.environ.get('CTCASR_SPLIT_GEMM', '1') == '1'
         self.split_dense4 = os.environ.get('CTCASR_SPLIT_DENSE4', '1') == '1'
+        # forward projections of bounded layer inputs (behind a clipped ReLU, |h| <= 1) as TWO
+        # fp16 pieces and three products: the fp32 GEMM's accuracy at half the bf16 form's cost
+        self.fwd_f16 = os.environ.get('CTCASR_FWD_F16', '1') == '1'
         self.split_wgrad = os.environ.get('CTCASR_SPLIT_WGRAD', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
         self._side_stream = None
@@ -406,13 +409,17 @@ class CTCModel:
                     bufs[name] = (
                         split_gemm.empty(gh2, w_ih.shape[1], split_gemm.B_ORDER, self.device),
                         split_gemm.empty(w_ih.shape[1], gh2, split_gemm.A_ORDER, self.device),
-                        torch.empty((w_ih.shape[1], gh2), dtype=torch.float32, device=self.device))
-                fwd, tr, scratch = bufs[name]
+                        torch.empty((w_ih.shape[1], gh2), dtype=torch.float32, device=self.device),
+                        split_gemm.empty16(gh2, w_ih.shape[1], split_gemm.H_B, self.device))
+                fwd, tr, scratch, fwd16 = bufs[name]
                 split_gemm.split(w_ih, split_gemm.B_ORDER, out=fwd)
+                if self.fwd_f16:
+                    split_gemm.split16(w_ih, split_gemm.W_SCALE, split_gemm.H_B, out=fwd16)
                 if training:
                     hip.transpose_batched(w_ih.view(1, gh2, -1), out=scratch.view(1, -1, gh2))
                     split_gemm.split(scratch, split_gemm.A_ORDER, out=tr)
-                self._w_split[name] = (fwd, tr if training else None)
+                self._w_split[name] = (fwd, tr if training else None,
+                                       fwd16 if self.fwd_f16 else None)
             if dense4:
                 if 'dense4' not in bufs:
                     bufs['dense4'] = (
@@ -425,7 +432,7 @@ class CTCModel:
                 if training:
                     split_gemm.split(k4, split_gemm.A_ORDER, out=by_row)
                 self._w_split['dense4'] = (stacked.view(-1, k4.shape[1]),
-                                           by_row if training else None)
+                                           by_row if training else None, None)
             self._w_split_ready = torch.cuda.Event()
             self._w_split_ready.record(side)
 
@@ -444,7 +451,7 @@ class CTCModel:
                 w_ih = p[name + '/w_ih']
                 w_ih = w_ih.view(w_ih.shape[0] * w_ih.shape[1], -1)
                 back = split_gemm.split(w_ih.t().contiguous(), split_gemm.A_ORDER)
-            got = self._w_split[name] = (got[0], back)
+            got = self._w_split[name] = (got[0], back, got[2])
         return got
 
     # ------------------------------------------------------------------ forward
@@ -540,6 +547,9 @@ class CTCModel:
             acts.update(conv_in=conv_in, conv_out=conv_out, pads=pads, conv_own=own_kind,
                         last_time_major=last_time_major)
             seq_length = torch.full((batch,), t_out, dtype=torch.int32, device=self.device)
+            # every element of the front end's output lies in [0, bound] (clip, then the dropout
+            # scale): what the fp16 split of the first projection's input relies on
+            in_bound = cfg.relu_cutoff / (1.0 - cfg.conv_dropout_rate)
         else:
             t_out = frames
             x2d = sequences.transpose(0, 1).reshape(t_out * batch, -1)
@@ -549,6 +559,7 @@ class CTCModel:
                 x2d = self._dense_act(x2d, 'dense{}'.format(i), cfg.dense_dropout_rate, training)
                 dense_out.append(x2d)
             rnn_in = x2d.view(t_out, batch, -1)
+            in_bound = cfg.relu_cutoff / (1.0 - (cfg.dense_dropout_rate if training else 0.0))
             acts.update(dense_in=dense_in, dense_out=dense_out)
             seq_length = torch.as_tensor(seq_length).to(self.device, torch.int32).contiguous()
 
@@ -568,6 +579,7 @@ class CTCModel:
             if rnn_rate > 0.0 and (i > 0 or not cfg.cudnn):
                 seeds[0] = self._next_seed()
                 x = hip.dropout(x, rnn_rate, seeds[0])
+                in_bound = in_bound / (1.0 - rnn_rate) if in_bound is not None else None
             w_ih = p['rnn{}/w_ih'.format(i)].view(2 * gates * hidden, -1)
             # biases that are plain additive terms (LSTM / RNN: both vectors; GRU: everything but
             # the recurrent bias of the candidate gate) are added to xw INSIDE the recurrence
@@ -577,8 +589,16 @@ class CTCModel:
             if pipelined_xw is not None:       # built beside the previous layer's recurrence
                 xw, pipelined_xw = pipelined_xw, None
             elif self._weight_split('rnn{}'.format(i)) is not None:
-                xs = split_gemm.split(x.view(t_out * batch, -1), split_gemm.A_ORDER)
-                xw = split_gemm.mm_nt(xs, self._weight_split('rnn{}'.format(i))[0])
+                w_pieces = self._weight_split('rnn{}'.format(i))
+                scale = split_gemm.f16_scale(in_bound) if w_pieces[2] is not None else None
+                if scale is not None:
+                    # bounded input: two fp16 pieces, three products (the bf16 pieces the weight
+                    # gradients want are made in the backward pass, on the side stream)
+                    x16 = split_gemm.split16(x.view(t_out * batch, -1), scale, split_gemm.H_A)
+                    xw = split_gemm.mm_nt16(x16, w_pieces[2], scale * split_gemm.W_SCALE)
+                else:
+                    xs = split_gemm.split(x.view(t_out * batch, -1), split_gemm.A_ORDER)
+                    xw = split_gemm.mm_nt(xs, w_pieces[0])
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
             in_split.append(xs)
@@ -594,13 +614,16 @@ class CTCModel:
             layer_out.append(y)
             reserves.append(reserve)
             x = y
+            # |h| <= 1 for the gated cells and tanh; the ReLU cell's output has no bound
+            in_bound = None if cell == 'rnn_relu' else 1.0
             if rnn_rate > 0.0 and not cfg.cudnn:
                 seeds[1] = self._next_seed()
                 x = hip.dropout(x, rnn_rate, seeds[1])
+                in_bound = in_bound / (1.0 - rnn_rate) if in_bound is not None else None
             drop_seeds.append(seeds)
         acts.update(layer_in=layer_in, layer_out=layer_out, reserves=reserves, rnn_ws=workspace,
                     rnn_len=rnn_len, t_out=t_out, drop_seeds=drop_seeds, rnn_rate=rnn_rate,
-                    in_split=in_split)
+                    in_split=in_split, out_split=[None] * cfg.num_layers_rnn)
 
         rnn_flat = x.view(t_out * batch, 2 * hidden)
         flat_split = None
@@ -930,19 +953,35 @@ class CTCModel:
             # from the forward pass where it used them; y's are the next layer's input pieces
             w_pieces = self._weight_split(name, True)
             use_split = w_pieces is not None
-            xs = ys = ds = drs = None
+            ds = drs = None
             if use_split:
-                xs = acts['in_split'][i] or split_gemm.split(x.view(rows, -1), split_gemm.A_ORDER)
-                acts['in_split'][i] = xs        # (the layer below reads y's pieces from here)
-                if i + 1 < cfg.num_layers_rnn:
-                    above = acts['in_split'][i + 1] if acts['layer_in'][i + 1] is y else None
-                else:
-                    above = acts['flat_split'] if acts['flat_of'] is y else None
-                ys = above or split_gemm.split(y.view(rows, 2 * hidden), split_gemm.A_ORDER)
                 ds = split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
                 drs = ds if cell != 'gru' else \
                     split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
-            side_tensors = [dxw] + [t.buf for t in (xs, ys, ds, drs) if t is not None]
+
+            def input_pieces(layer=i, x=x):
+                # bf16 pieces of this layer's input: from the forward pass if it made them, else
+                # made here - on the stream that runs the weight gradients - and kept: the layer
+                # below reads its output's pieces (this very tensor's) from the same place
+                if acts['in_split'][layer] is None:
+                    acts['in_split'][layer] = split_gemm.split(x.view(rows, -1),
+                                                               split_gemm.A_ORDER)
+                return acts['in_split'][layer]
+
+            def output_pieces(layer=i, y=y):
+                if layer + 1 < cfg.num_layers_rnn and acts['layer_in'][layer + 1] is y and \
+                        acts['in_split'][layer + 1] is not None:
+                    return acts['in_split'][layer + 1]
+                if layer + 1 == cfg.num_layers_rnn and acts['flat_of'] is y and \
+                        acts['flat_split'] is not None:
+                    return acts['flat_split']
+                if acts['out_split'][layer] is None:
+                    acts['out_split'][layer] = split_gemm.split(y.view(rows, 2 * hidden),
+                                                                split_gemm.A_ORDER)
+                return acts['out_split'][layer]
+
+            side_tensors = [dxw] + [t.buf for t in (ds, drs, acts['in_split'][i],
+                                                    acts['flat_split']) if t is not None]
 
             def split_steps(lo, hi, ds=ds, drs=drs, dxw2d=dxw2d, drec=drec):
                 # pieces of dxw (GRU: and drec) for steps [lo, hi) of both directions
@@ -953,10 +992,13 @@ class CTCModel:
                         hip.split_bf16(drec.view(rows, 2 * gh)[rng, cols], split_gemm.B_ORDER,
                                        out=drs.buf[rng, :, cols])
 
-            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec, xs=xs,
-                                     ys=ys, ds=ds if self.split_wgrad else None, drs=drs):
+            def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec,
+                                     ds=ds if self.split_wgrad else None, drs=drs,
+                                     input_pieces=input_pieces, output_pieces=output_pieces):
                 # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
                 x3 = x.view(t_out, batch, -1)
+                xs = input_pieces() if ds is not None else None
+                ys = output_pieces() if ds is not None else None
                 for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
                     cols = slice(d * gh, (d + 1) * gh)
                     if ds is not None:

@@ -140,6 +140,41 @@ def mm_tn_rows(out, a, b, lo, hi, a_cols=slice(None), b_cols=slice(None), b_shif
     return torch.mm(lhs, rhs, out_dtype=F32, out=out)
 
 
+# ---- forward projections of bounded operands: two fp16 pieces, three products ------------------
+H_A, H_B = (0, 0, 1), (0, 1, 0)            # h1 k1 + h1 k2 + h2 k1
+F16_MAX = 60000.0                          # (fp16's largest finite value is 65504)
+W_SCALE = 2.0 ** 11                        # weights: |w| < 29
+
+
+def f16_scale(bound):
+    """The power of two that maps [-bound, bound] into fp16's range, or None if there is none
+    worth using (the split then keeps too few bits of the small elements)."""
+    if bound is None or not bound > 0.0 or bound > 64.0:
+        return None
+    scale = 2.0 ** 15
+    while bound * scale > F16_MAX:
+        scale /= 2.0
+    return scale
+
+
+def split16(x2d, scale, order, out=None):
+    return Split(hip.split_f16(x2d, scale, order, out=None if out is None else out.buf), order)
+
+
+def empty16(rows, cols, order, device):
+    return Split(torch.empty((rows, len(order), cols), dtype=torch.float16, device=device), order)
+
+
+def mm_nt16(a, b, scale_product, out=None):
+    """out[M, N] = A . B^T from a = split16(A, sa, H_A), b = split16(B, sb, H_B), scale_product =
+    sa * sb: one fp16 GEMM over 3 K with 1 / (sa sb) as its alpha."""
+    assert {a.order, b.order} == {H_A, H_B} and a.cols == b.cols
+    if out is None:
+        out = torch.empty((a.rows, b.rows), dtype=F32, device=a.buf.device)
+    return torch.addmm(out, a.concat(), b.concat().t(), out_dtype=F32, beta=0.0,
+                       alpha=1.0 / scale_product, out=out)
+
+
 def worthwhile(m, k, n):
     """Shapes the split pays for: a big product (the splits are HBM passes over the operands)
     whose dimensions suit the 8-element vectors of the split kernel."""

@@ -314,6 +314,17 @@ int ctcasr_split_bf16(const float *x, int64_t rows, int cols, int64_t ld_x, cons
                       int blocks, void *out, int64_t ld_out, int64_t block_stride,
                       ctcasr_stream_t stream);
 
+/* Forward projections of BOUNDED operands (activations behind a clipped ReLU, |h| <= 1 of an LSTM /
+ * GRU / tanh cell, weights) also go in TWO fp16 pieces of x * scale - h1 = rne_f16(x scale),
+ * h2 = rne_f16(x scale - h1), 11 + 11 mantissa bits - and three products h1 k1 + h1 k2 + h2 k1
+ * (dropped: h2 k2 <= 2^-22): measured error = the fp32 GEMM's, at half the bf16 form's cost.
+ *   scale  a power of two with |x| * scale < 65504 for every element (the caller knows the bound);
+ *   order  host int[blocks] of 0 (h1) / 1 (h2); out / ld_out / block_stride as above, fp16.
+ * The product of two such operands carries scale_x * scale_w: fold 1 / that into the GEMM's alpha. */
+int ctcasr_split_f16(const float *x, int64_t rows, int cols, int64_t ld_x, float scale,
+                     const int *order, int blocks, void *out, int64_t ld_out,
+                     int64_t block_stride, ctcasr_stream_t stream);
+
 /* The same product with the split done in registers by an own kernel (csrc/split_gemm.hip): no
  * split pass, no K-concatenated copies, no inter-workgroup waits.
  *   C[M, N] (+)= A[M, K] . B[N, K]^T    all fp32, row-major with leading dimensions lda / ldb / ldc

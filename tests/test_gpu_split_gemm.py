@@ -208,3 +208,46 @@ def test_own_split_gemm_kernel_over_the_row_axis(hip, m, n, k):
     assert float((out.double() - 2.0 * ref).abs().max()) <= 2.5 * bound
     with pytest.raises(hip.CtcAsrError):
         hip.gemm_split_tn(a, b[:-1], out)
+
+
+def test_fp16_two_piece_split_and_the_forward_product(hip):
+    """`ctcasr_split_f16`: h1 = rne_f16(x s), h2 = rne_f16(x s - h1) bit for bit, and the three
+    products h1 k1 + h1 k2 + h2 k1 with 1 / (s_x s_w) as the GEMM's alpha against fp64 - for the
+    bounded operands the model feeds it (|h| <= 1 outputs of gated cells, activations behind the
+    clipped ReLU): as close as the library's fp32 GEMM, by assertion."""
+    from ctc_asr_amd import split_gemm as sg
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(300, 64, device='cuda', generator=g).clamp_(-1, 1) * \
+        torch.logspace(-9, 0, 300, device='cuda')[:, None]
+    x[7, :4] = torch.tensor([1.0, -1.0, 0.0, 2.0 ** -20], device='cuda')
+    scale = sg.f16_scale(1.0)
+    assert scale == 2.0 ** 15 and sg.f16_scale(20.0) == 2.0 ** 11 and sg.f16_scale(22.3) == 2.0 ** 11
+    assert sg.f16_scale(65.0) is None and sg.f16_scale(None) is None
+    got = hip.split_f16(x, scale, (0, 1, 0))
+    s = x * scale
+    h1 = s.to(torch.float16)
+    h2 = (s - h1.float()).to(torch.float16)
+    assert torch.equal(got[:, 0].view(torch.int16), h1.view(torch.int16))
+    assert torch.equal(got[:, 1].view(torch.int16), h2.view(torch.int16))
+    assert torch.equal(got[:, 2], got[:, 0]) and bool(torch.isfinite(got.float()).all())
+    with pytest.raises(hip.CtcAsrError):
+        hip.split_f16(x, 0.0, (0, 1))
+    with pytest.raises(hip.CtcAsrError):
+        hip.split_f16(x, scale, (0, 2))
+    rows, k, n = 2048, 2048, 4096
+    w = torch.randn(n, k, device='cuda', generator=g) / k ** 0.5
+    ws = sg.split16(w, sg.W_SCALE, sg.H_B)
+    cases = {
+        'gated-cell outputs': (torch.sigmoid(torch.randn(rows, k, device='cuda', generator=g) * 2) *
+                               torch.tanh(torch.randn(rows, k, device='cuda', generator=g) * 1.5),
+                               1.0),
+        'clipped ReLU with dropout scale': ((torch.randn(rows, k, device='cuda', generator=g) * 6)
+                                            .clamp_(0, 20) / 0.9, 20.0 / 0.9)}
+    for name, (a, bound) in cases.items():
+        sa = sg.f16_scale(bound)
+        ref = a.double() @ w.double().t()
+        got = sg.mm_nt16(sg.split16(a, sa, sg.H_A), ws, sa * sg.W_SCALE)
+        s_rms, s_max = _errors(got, ref)
+        p_rms, p_max = _errors(torch.mm(a, w.t()), ref)
+        assert s_rms <= 1.3 * p_rms + 1e-8, (name, s_rms, p_rms)
+        assert s_max <= 2.0 * p_max + 1e-12, (name, s_max, p_max)

@@ -426,13 +426,20 @@ class CTCModel:
                         torch.empty((6,) + tuple(k4.shape), dtype=torch.bfloat16,
                                     device=self.device),
                         split_gemm.empty(k4.shape[0], k4.shape[1], split_gemm.A_ORDER,
-                                         self.device))
-                stacked, by_row = bufs['dense4']
+                                         self.device),
+                        torch.empty((3,) + tuple(k4.shape), dtype=torch.float16,
+                                    device=self.device))
+                stacked, by_row, stacked16 = bufs['dense4']
                 split_gemm.split_rows_stacked(k4, split_gemm.B_ORDER, out=stacked)
+                if self.fwd_f16:
+                    split_gemm.split16_rows_stacked(k4, split_gemm.W_SCALE, split_gemm.H_B,
+                                                    out=stacked16)
                 if training:
                     split_gemm.split(k4, split_gemm.A_ORDER, out=by_row)
                 self._w_split['dense4'] = (stacked.view(-1, k4.shape[1]),
-                                           by_row if training else None, None)
+                                           by_row if training else None,
+                                           stacked16.view(-1, k4.shape[1]) if self.fwd_f16
+                                           else None)
             self._w_split_ready = torch.cuda.Event()
             self._w_split_ready.record(side)
 
@@ -626,13 +633,23 @@ class CTCModel:
                     in_split=in_split, out_split=[None] * cfg.num_layers_rnn)
 
         rnn_flat = x.view(t_out * batch, 2 * hidden)
-        flat_split = None
-        if self._weight_split('dense4') is not None:
-            # (the top layer's output pieces also serve its recurrent weight gradient)
-            flat_split = split_gemm.split(rnn_flat, split_gemm.A_ORDER)
-        dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training,
-                                 xs=flat_split)
-        acts.update(flat_split=flat_split, flat_of=x)
+        flat_split, k4_pieces = None, self._weight_split('dense4')
+        flat_scale = split_gemm.f16_scale(in_bound) \
+            if k4_pieces is not None and k4_pieces[2] is not None else None
+        if flat_scale is not None:
+            # bounded input (the recurrent stack's output): fp16 pieces, three products
+            flat16 = split_gemm.split16(rnn_flat, flat_scale, split_gemm.H_A)
+            dense4 = split_gemm.mm_nn16_stacked(flat16, k4_pieces[2],
+                                                flat_scale * split_gemm.W_SCALE)
+            hip.bias_act_fwd(dense4, p['dense4/bias'], cfg.relu_cutoff,
+                             cfg.dense_dropout_rate if training else 0.0, self._next_seed())
+        else:
+            if k4_pieces is not None:
+                # (the top layer's output pieces also serve its recurrent weight gradient)
+                flat_split = split_gemm.split(rnn_flat, split_gemm.A_ORDER)
+            dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training,
+                                     xs=flat_split)
+        acts.update(flat_split=flat_split, flat_of=x, flat_uses_split=k4_pieces is not None)
         logits = torch.mm(dense4, p['logits/kernel'])
         hip.bias_act_fwd(logits, p['logits/bias'], 0.0)
         acts.update(rnn_flat=rnn_flat, dense4=dense4)
@@ -891,7 +908,7 @@ class CTCModel:
         # dense4: dz and the data gradient are on the critical path, the kernel gradient is not
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
-        k4_split = self._weight_split('dense4', True) if acts['flat_split'] is not None else None
+        k4_split = self._weight_split('dense4', True) if acts['flat_uses_split'] else None
         if k4_split is not None:
             dz_split = split_gemm.split(dz, split_gemm.B_ORDER)
             dy = split_gemm.mm_nt(dz_split, k4_split[1]).view(t_out, batch, 2 * hidden)
@@ -905,6 +922,8 @@ class CTCModel:
 
         def dense4_weight_grad():
             if dz_split is not None:
+                if acts['flat_split'] is None:      # (the forward pass used fp16 pieces)
+                    acts['flat_split'] = split_gemm.split(acts['rnn_flat'], split_gemm.A_ORDER)
                 split_gemm.mm_tn_rows(g['dense4/kernel'], acts['flat_split'], dz_split, 0, rows,
                                       accumulate=False)
             else:
@@ -912,7 +931,8 @@ class CTCModel:
             if early:
                 done('dense4')
 
-        on_side([dz] + ([dz_split.buf, acts['flat_split'].buf] if dz_split is not None else []),
+        on_side([dz] + ([dz_split.buf] if dz_split is not None else []) +
+                ([acts['flat_split'].buf] if acts['flat_split'] is not None else []),
                 dense4_weight_grad, gate=True)
         if not early:
             deferred.append('dense4')

@@ -175,6 +175,24 @@ def mm_nt16(a, b, scale_product, out=None):
                        alpha=1.0 / scale_product, out=out)
 
 
+def split16_rows_stacked(x2d, scale, order, out=None):
+    """fp16 pieces of x [K, N] * scale stacked along the rows: [3 K, N]."""
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.empty((len(order), rows, cols), dtype=torch.float16, device=x2d.device)
+    hip.split_f16(x2d, scale, order, out=out.permute(1, 0, 2))
+    return out.view(len(order) * rows, cols)
+
+
+def mm_nn16_stacked(a, b_stacked, scale_product, out=None):
+    """out[M, N] = A[M, K] . B[K, N] from a = split16(A, sa, H_A) and the fp16 pieces of B stacked
+    along its rows in the order H_B: one call, 1 / (sa sb) as its alpha."""
+    if out is None:
+        out = torch.empty((a.rows, b_stacked.shape[1]), dtype=F32, device=a.buf.device)
+    return torch.addmm(out, a.concat(), b_stacked, out_dtype=F32, beta=0.0,
+                       alpha=1.0 / scale_product, out=out)
+
+
 def worthwhile(m, k, n):
     """Shapes the split pays for: a big product (the splits are HBM passes over the operands)
     whose dimensions suit the 8-element vectors of the split kernel."""

@@ -96,20 +96,29 @@ def forward_flops_per_utt(cfg, frames):
     return flops
 
 
-def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1):
+def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f16=True):
     """Time one step would take with every FLOP at the peak of the pipe it runs on: the fp32
-    matrix pipe (157.3 TF) for the own kernels, six bf16 products per fp32 product at the bf16 peak
-    (2500 / 6 = 417 TF fp32-equivalent) for the split GEMMs."""
+    matrix pipe (157.3 TF) for the own kernels; for the split GEMMs the 16-bit matrix pipe
+    (2500 TF) divided by the products per fp32 product - six bf16 products for the gradient GEMMs,
+    three fp16 products for the forward projections of bounded inputs (a third of the split
+    FLOPs except the recurrent weight gradient's share)."""
     split, fp32 = training_flops_by_pipe(cfg, frames)
     if not split_gemm:
         split, fp32 = 0.0, split + fp32
-    roof_ms = utterances / world * (split * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
-                                    fp32 / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+    from ctc_asr_amd.model import GATES
+    t_out = cfg.output_time(frames)
+    rec = 2.0 * t_out * 2 * GATES[cfg.cell] * cfg.num_units_rnn ** 2 * cfg.num_layers_rnn
+    forward = (split - rec) / 3.0 if (split_gemm and fwd_f16 and cfg.cell != 'rnn_relu') else 0.0
+    roof_ms = utterances / world * (
+        forward * 3.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+        (split - forward) * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+        fp32 / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
     return {'ms_per_step_at_peak': round(roof_ms, 3), 'frac': round(roof_ms / ms_per_step, 4),
             'fp32_equiv_tflop_split_gemms': round(utterances / world * split / 1e12, 3),
+            'of_which_forward_fp16x3': round(utterances / world * forward / 1e12, 3),
             'tflop_fp32_pipe': round(utterances / world * fp32 / 1e12, 3),
-            'note': 'per GPU; split GEMMs priced at 2500 / 6 TF fp32-equivalent, own kernels at '
-                    '157.3 TF'}
+            'note': 'per GPU; split GEMMs priced at 2500 TF / 6 (bf16 pieces, gradients) and '
+                    '2500 TF / 3 (fp16 pieces, forward projections), own kernels at 157.3 TF'}
 
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
@@ -459,12 +468,15 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
             'step_tflops_fp32': round(value * flops_per_audio_s / 1e12, 2),
             'frac_of_fp32_mfma_peak': round(value * flops_per_audio_s / 1e12 /
                                             (FP32_MFMA_PEAK_TFLOPS * world), 4),
-            'gemm_path': ('bf16x6 split: fp32 operands as three bf16 pieces each, the six products '
-                          'of order <= 2 accumulated in fp32 on the bf16 matrix pipe; closer to fp64 '
-                          'than the fp32 GEMM (profiles/r03_gemm_bf16_split.md); CTCASR_SPLIT_GEMM=0 '
-                          'selects the fp32 library GEMMs') if model.split_gemm else 'fp32 library '
-                         'GEMMs (CTCASR_SPLIT_GEMM=0)',
-            'roof': mixed_roof(cfg, frames, batch * world, ms_per_step, model.split_gemm, world),
+            'gemm_path': ('split: fp32 operands as three bf16 pieces each, the six products of '
+                          'order <= 2 accumulated in fp32 on the 16-bit matrix pipe (gradient GEMMs; '
+                          'closer to fp64 than the fp32 GEMM){}; profiles/r03_gemm_bf16_split.md; '
+                          'CTCASR_SPLIT_GEMM=0 selects the fp32 library GEMMs'.format(
+                              '; forward projections of bounded inputs as two fp16 pieces and '
+                              'three products (the fp32 GEMM\'s error)' if model.fwd_f16 else ''))
+                         if model.split_gemm else 'fp32 library GEMMs (CTCASR_SPLIT_GEMM=0)',
+            'roof': mixed_roof(cfg, frames, batch * world, ms_per_step, model.split_gemm, world,
+                               model.fwd_f16),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),

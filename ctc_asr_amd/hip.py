@@ -72,6 +72,13 @@ SIGNATURES = {
                                    _c_p]),
     'ctcasr_split_f16': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_f, _c_p, _c_int, _c_p, _c_i64,
                                   _c_i64, _c_p]),
+    'ctcasr_colmax_scale': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+    'ctcasr_split_f16_cols': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_f, _c_p, _c_int, _c_p,
+                                       _c_i64, _c_i64, _c_p]),
+    'ctcasr_split_f16_rows': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_int, _c_p, _c_i64,
+                                       _c_i64, _c_p, _c_p]),
+    'ctcasr_rescale_rows': (_c_int, [_c_p, _c_i64, _c_p, _c_f, _c_p, _c_i64, _c_i64, _c_int, _c_int,
+                                     _c_p]),
     'ctcasr_gemm_split_nt': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
                                       _c_int, _c_p]),
     'ctcasr_gemm_split_tn': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
@@ -502,6 +509,86 @@ def split_f16(x, scale, order, out=None):
                                    out.stride(0) if rows > 1 else len(order) * cols,
                                    out.stride(1) if len(order) > 1 else cols, _stream()),
            'split_f16')
+    return out
+
+
+def _f32_matrix(t, name):
+    if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+        raise CtcAsrError('{} must be an f32 matrix in HBM with unit column stride.'.format(name))
+
+
+def _f16_out(out, rows, blocks, cols, device):
+    if out is None:
+        return torch.empty((rows, blocks, cols), dtype=torch.float16, device=device)
+    if (out.dtype != torch.float16 or tuple(out.shape) != (rows, blocks, cols) or
+            out.stride(2) != 1 or out.device != device):
+        raise CtcAsrError('out must be an fp16 [rows, blocks, cols] view with unit column stride.')
+    return out
+
+
+@_on_tensor_device
+def colmax_scale(x, scale=None, inv_scale=None):
+    """Power-of-two scale per column of x f32 [rows, cols] (largest magnitude -> [2^13, 2^14)) and
+    its inverse: (scale f32[cols], inv_scale f32[cols]) (ctcasr_colmax_scale)."""
+    _f32_matrix(x, 'colmax_scale: x')
+    rows, cols = x.shape
+    scale = torch.empty(cols, dtype=torch.float32, device=x.device) if scale is None else scale
+    inv_scale = torch.empty(cols, dtype=torch.float32, device=x.device) \
+        if inv_scale is None else inv_scale
+    work = torch.empty(cols, dtype=torch.int32, device=x.device)
+    _check(load().ctcasr_colmax_scale(x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols,
+                                      work.data_ptr(), _dev(scale, name='scale'),
+                                      _dev(inv_scale, name='inv_scale'), _stream()), 'colmax_scale')
+    return scale, inv_scale
+
+
+@_on_tensor_device
+def split_f16_cols(x, col_scale, scale, order, out=None):
+    """Two fp16 pieces of x[r][c] * col_scale[c] * scale -> fp16 [rows, len(order), cols]."""
+    _f32_matrix(x, 'split_f16_cols: x')
+    rows, cols = x.shape
+    order = [int(v) for v in order]
+    out = _f16_out(out, rows, len(order), cols, x.device)
+    arr = (ctypes.c_int * len(order))(*order)
+    _check(load().ctcasr_split_f16_cols(
+        x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols, _dev(col_scale, name='scale'),
+        float(scale), arr, len(order), out.data_ptr(),
+        out.stride(0) if rows > 1 else len(order) * cols,
+        out.stride(1) if len(order) > 1 else cols, _stream()), 'split_f16_cols')
+    return out
+
+
+@_on_tensor_device
+def split_f16_rows(x, order, out=None, inv_scale=None):
+    """Two fp16 pieces of every row of x scaled by that row's own power of two -> (fp16 [rows,
+    len(order), cols], inv_scale f32[rows])."""
+    _f32_matrix(x, 'split_f16_rows: x')
+    rows, cols = x.shape
+    order = [int(v) for v in order]
+    out = _f16_out(out, rows, len(order), cols, x.device)
+    inv_scale = torch.empty(rows, dtype=torch.float32, device=x.device) \
+        if inv_scale is None else inv_scale
+    arr = (ctypes.c_int * len(order))(*order)
+    _check(load().ctcasr_split_f16_rows(
+        x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols, arr, len(order),
+        out.data_ptr(), out.stride(0) if rows > 1 else len(order) * cols,
+        out.stride(1) if len(order) > 1 else cols, _dev(inv_scale, name='inv_scale'), _stream()),
+        'split_f16_rows')
+    return out, inv_scale
+
+
+@_on_tensor_device
+def rescale_rows(t, row_factor, alpha, out, accumulate=False):
+    """out[r][c] (+)= t[r][c] * row_factor[r] * alpha."""
+    _f32_matrix(t, 'rescale_rows: t')
+    _f32_matrix(out, 'rescale_rows: out')
+    rows, cols = t.shape
+    if tuple(out.shape) != (rows, cols) or row_factor.numel() != rows:
+        raise CtcAsrError('rescale_rows: shapes disagree.')
+    _check(load().ctcasr_rescale_rows(
+        t.data_ptr(), t.stride(0) if rows > 1 else cols, _dev(row_factor, name='row_factor'),
+        float(alpha), out.data_ptr(), out.stride(0) if rows > 1 else cols, rows, cols,
+        int(accumulate), _stream()), 'rescale_rows')
     return out
 
 

@@ -344,6 +344,9 @@ class CTCModel:
         # forward projections of bounded layer inputs (behind a clipped ReLU, |h| <= 1) as TWO
         # fp16 pieces and three products: the fp32 GEMM's accuracy at half the bf16 form's cost
         self.fwd_f16 = os.environ.get('CTCASR_FWD_F16', '1') == '1'
+        # ... and the gradient GEMMs of those layers in the same form, the unbounded operand (dxw)
+        # scaled per column (weight gradients) / per row (data gradient) on the device
+        self.bwd_f16 = os.environ.get('CTCASR_BWD_F16', '1') == '1'
         self.split_wgrad = os.environ.get('CTCASR_SPLIT_WGRAD', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
         self._side_stream = None
@@ -415,11 +418,18 @@ class CTCModel:
                 split_gemm.split(w_ih, split_gemm.B_ORDER, out=fwd)
                 if self.fwd_f16:
                     split_gemm.split16(w_ih, split_gemm.W_SCALE, split_gemm.H_B, out=fwd16)
+                tr16 = None
                 if training:
                     hip.transpose_batched(w_ih.view(1, gh2, -1), out=scratch.view(1, -1, gh2))
                     split_gemm.split(scratch, split_gemm.A_ORDER, out=tr)
+                    if self.fwd_f16 and self.bwd_f16:
+                        if name + '/t16' not in bufs:
+                            bufs[name + '/t16'] = split_gemm.empty16(w_ih.shape[1], gh2,
+                                                                     split_gemm.H_B, self.device)
+                        tr16 = split_gemm.split16(scratch, split_gemm.W_SCALE, split_gemm.H_B,
+                                                  out=bufs[name + '/t16'])
                 self._w_split[name] = (fwd, tr if training else None,
-                                       fwd16 if self.fwd_f16 else None)
+                                       fwd16 if self.fwd_f16 else None, tr16)
             if dense4:
                 if 'dense4' not in bufs:
                     bufs['dense4'] = (
@@ -439,7 +449,7 @@ class CTCModel:
                 self._w_split['dense4'] = (stacked.view(-1, k4.shape[1]),
                                            by_row if training else None,
                                            stacked16.view(-1, k4.shape[1]) if self.fwd_f16
-                                           else None)
+                                           else None, None)
             self._w_split_ready = torch.cuda.Event()
             self._w_split_ready.record(side)
 
@@ -458,7 +468,7 @@ class CTCModel:
                 w_ih = p[name + '/w_ih']
                 w_ih = w_ih.view(w_ih.shape[0] * w_ih.shape[1], -1)
                 back = split_gemm.split(w_ih.t().contiguous(), split_gemm.A_ORDER)
-            got = self._w_split[name] = (got[0], back, got[2])
+            got = self._w_split[name] = (got[0], back, got[2], got[3])
         return got
 
     # ------------------------------------------------------------------ forward
@@ -574,6 +584,7 @@ class CTCModel:
         rnn_len = None if cfg.cudnn else seq_length
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
         in_split = []                   # bf16 pieces of the layer inputs (None: fp32 GEMM)
+        in_split16 = []                 # (fp16 pieces, scale) where the forward used them
         pipelined_xw = None
         x = rnn_in.contiguous()
         workspace = self._rnn_workspace(cell, t_out, batch, hidden)
@@ -592,7 +603,7 @@ class CTCModel:
             # the recurrent bias of the candidate gate) are added to xw INSIDE the recurrence
             # kernel (`xw_bias`): the GEMM then is a plain product without a bias epilogue
             # (3.93 instead of 4.16 ms per layer at C3) and no pass over xw is spent on it
-            xs = ws = None
+            xs = ws = pieces16 = None
             if pipelined_xw is not None:       # built beside the previous layer's recurrence
                 xw, pipelined_xw = pipelined_xw, None
             elif self._weight_split('rnn{}'.format(i)) is not None:
@@ -603,12 +614,14 @@ class CTCModel:
                     # gradients want are made in the backward pass, on the side stream)
                     x16 = split_gemm.split16(x.view(t_out * batch, -1), scale, split_gemm.H_A)
                     xw = split_gemm.mm_nt16(x16, w_pieces[2], scale * split_gemm.W_SCALE)
+                    pieces16 = (x16, scale)
                 else:
                     xs = split_gemm.split(x.view(t_out * batch, -1), split_gemm.A_ORDER)
                     xw = split_gemm.mm_nt(xs, w_pieces[0])
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
             in_split.append(xs)
+            in_split16.append(pieces16)
             if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
                 y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
                     i, xw, t_out, batch, hidden, gates, workspace)
@@ -630,15 +643,18 @@ class CTCModel:
             drop_seeds.append(seeds)
         acts.update(layer_in=layer_in, layer_out=layer_out, reserves=reserves, rnn_ws=workspace,
                     rnn_len=rnn_len, t_out=t_out, drop_seeds=drop_seeds, rnn_rate=rnn_rate,
-                    in_split=in_split, out_split=[None] * cfg.num_layers_rnn)
+                    in_split=in_split, out_split=[None] * cfg.num_layers_rnn,
+                    in_split16=in_split16)
 
         rnn_flat = x.view(t_out * batch, 2 * hidden)
         flat_split, k4_pieces = None, self._weight_split('dense4')
+        acts['flat16'] = None
         flat_scale = split_gemm.f16_scale(in_bound) \
             if k4_pieces is not None and k4_pieces[2] is not None else None
         if flat_scale is not None:
             # bounded input (the recurrent stack's output): fp16 pieces, three products
             flat16 = split_gemm.split16(rnn_flat, flat_scale, split_gemm.H_A)
+            acts['flat16'] = (flat16, flat_scale)
             dense4 = split_gemm.mm_nn16_stacked(flat16, k4_pieces[2],
                                                 flat_scale * split_gemm.W_SCALE)
             hip.bias_act_fwd(dense4, p['dense4/bias'], cfg.relu_cutoff,
@@ -973,8 +989,19 @@ class CTCModel:
             # from the forward pass where it used them; y's are the next layer's input pieces
             w_pieces = self._weight_split(name, True)
             use_split = w_pieces is not None
+            # fp16 form of this layer's gradient GEMMs: when the forward pass left fp16 pieces of
+            # the layer's input AND of its output (the next layer's input / dense4's), dxw is
+            # split with per-column scales for the weight gradients (chunk by chunk) and with
+            # per-row scales for the data gradient - no bf16 pieces of anything are needed
+            x16 = acts['in_split16'][i]
+            if i + 1 < cfg.num_layers_rnn:
+                y16 = acts['in_split16'][i + 1] if acts['layer_in'][i + 1] is y else None
+            else:
+                y16 = acts['flat16'] if acts['flat_of'] is y else None
+            g16 = (self.bwd_f16 and use_split and x16 is not None and y16 is not None and
+                   w_pieces[3] is not None and 2 * gh <= 16384 and self.split_wgrad)
             ds = drs = None
-            if use_split:
+            if use_split and not g16:
                 ds = split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
                 drs = ds if cell != 'gru' else \
                     split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
@@ -1001,7 +1028,8 @@ class CTCModel:
                 return acts['out_split'][layer]
 
             side_tensors = [dxw] + [t.buf for t in (ds, drs, acts['in_split'][i],
-                                                    acts['flat_split']) if t is not None]
+                                                    acts['flat_split']) if t is not None] + \
+                [t[0].buf for t in (x16, y16) if t is not None]
 
             def split_steps(lo, hi, ds=ds, drs=drs, dxw2d=dxw2d, drec=drec):
                 # pieces of dxw (GRU: and drec) for steps [lo, hi) of both directions
@@ -1012,9 +1040,33 @@ class CTCModel:
                         hip.split_bf16(drec.view(rows, 2 * gh)[rng, cols], split_gemm.B_ORDER,
                                        out=drs.buf[rng, :, cols])
 
+            def partial_weight_grads_f16(lo, hi, name=name, dxw2d=dxw2d, drec=drec, x16=x16,
+                                         y16=y16):
+                # steps [lo, hi) in the fp16 form: per direction one column-scaled split of the
+                # finished rows of dxw (GRU: and of drec) feeds both W_ih's and W_hh's product
+                for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
+                    cols = slice(d * gh, (d + 1) * gh)
+                    d16, inv = split_gemm.wgrad16_operand(dxw2d[a * batch:b * batch, cols])
+                    split_gemm.wgrad16(g[name + '/w_ih'][d], d16, inv, x16[0], x16[1], a * batch)
+                    if d == 0:
+                        a2, b2, shift, hcols = max(a, 1), b, -1, slice(0, hidden)
+                    else:
+                        a2, b2, shift, hcols = a, min(b, t_out - 1), 1, slice(hidden, 2 * hidden)
+                    if b2 <= a2:
+                        continue
+                    if cell == 'gru':
+                        d16, inv = split_gemm.wgrad16_operand(
+                            drec.view(rows, 2 * gh)[a * batch:b * batch, cols])
+                    split_gemm.wgrad16(g[name + '/w_hh'][d], d16, inv, y16[0], y16[1],
+                                       (a2 + shift) * batch, x_cols=hcols,
+                                       d_rows=slice((a2 - a) * batch, (b2 - a) * batch))
+
             def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec,
                                      ds=ds if self.split_wgrad else None, drs=drs,
-                                     input_pieces=input_pieces, output_pieces=output_pieces):
+                                     input_pieces=input_pieces, output_pieces=output_pieces,
+                                     g16=g16, f16_form=partial_weight_grads_f16):
+                if g16:
+                    return f16_form(lo, hi)
                 # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
                 x3 = x.view(t_out, batch, -1)
                 xs = input_pieces() if ds is not None else None
@@ -1060,13 +1112,13 @@ class CTCModel:
                             else 0)
                 if c + 1 < chunks:
                     def finished_steps(lo=bounds[c + 1], hi=bounds[c]):
-                        if use_split:       # these steps' pieces: beside the next launch as well
+                        if ds is not None:  # these steps' pieces: beside the next launch as well
                             split_steps(lo, hi)
                             split_done.append(torch.cuda.Event())
                             split_done[-1].record(torch.cuda.current_stream(self.device))
                         partial_weight_grads(lo, hi)
                     on_side(side_tensors, finished_steps, gate=True)
-            if use_split:
+            if ds is not None:
                 split_steps(0, bounds[-2])
                 for event in split_done:
                     main.wait_event(event)
@@ -1081,7 +1133,10 @@ class CTCModel:
             if i > 0 or need_dx_first:
                 if side is not main:
                     main.wait_stream(side)
-                if use_split:
+                if g16:
+                    dy_below = split_gemm.dgrad16(dxw2d, w_pieces[3], split_gemm.W_SCALE) \
+                        .view(t_out, batch, -1)
+                elif use_split:
                     dy_below = torch.empty((rows, x.shape[-1]), dtype=torch.float32,
                                            device=dy.device)
                     split_gemm.mm_nt_by_order(dy_below, ds, w_pieces[1])

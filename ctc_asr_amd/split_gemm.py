@@ -193,6 +193,39 @@ def mm_nn16_stacked(a, b_stacked, scale_product, out=None):
                        alpha=1.0 / scale_product, out=out)
 
 
+# ---- gradient GEMMs in the fp16 form: scales per column (weight gradients) / per row (data
+# gradient) of dxw, found on the device; the bounded operand keeps its fixed scale ----------------
+def wgrad16_operand(d2d):
+    """fp16 pieces [rows, 3, cols] (order H_B) of a block of gradient rows, scaled per column, and
+    the inverse scales f32[cols]."""
+    scale, inv = hip.colmax_scale(d2d)
+    return hip.split_f16_cols(d2d, scale, 1.0, H_B), inv
+
+
+def wgrad16(out, d16, inv, x16, x_scale, x_lo, x_cols=slice(None), d_rows=slice(None)):
+    """out[M, N] += D^T X for D = the rows ``d_rows`` of the block whose pieces are ``d16`` (from
+    `wgrad16_operand`) and X = rows [x_lo, x_lo + len) x ``x_cols`` of the operand whose forward
+    pieces are ``x16`` (split16(..., x_scale, H_A)): one fp16 GEMM over 3 x rows, then the
+    per-column scales of D - per row of out - and 1 / x_scale come back out."""
+    d16 = d16[d_rows]
+    rows, _, m = d16.shape
+    lhs = d16.reshape(rows * 3, m).t()
+    rhs = x16.buf.view(x16.rows * 3, x16.cols)[3 * x_lo:3 * (x_lo + rows), x_cols]
+    tmp = torch.mm(lhs, rhs, out_dtype=F32)
+    return hip.rescale_rows(tmp, inv, 1.0 / x_scale, out, accumulate=True)
+
+
+def dgrad16(d2d, wt16, w_scale, out=None):
+    """out[R, N] = D[R, K] . W[K, N] from the fp16 pieces of W^T [N, 3, K] (order H_B, scale
+    w_scale): D is split with a scale per ROW found on the fly; the row scales and 1 / w_scale
+    come back out of the product in place."""
+    d16, inv = hip.split_f16_rows(d2d, H_A)
+    rows, _, k = d16.shape
+    tmp = torch.mm(d16.view(rows, 3 * k), wt16.concat().t(), out_dtype=F32) if out is None else \
+        torch.mm(d16.view(rows, 3 * k), wt16.concat().t(), out_dtype=F32, out=out)
+    return hip.rescale_rows(tmp, inv, 1.0 / w_scale, tmp, accumulate=False)
+
+
 def worthwhile(m, k, n):
     """Shapes the split pays for: a big product (the splits are HBM passes over the operands)
     whose dimensions suit the 8-element vectors of the split kernel."""

@@ -325,6 +325,33 @@ int ctcasr_split_f16(const float *x, int64_t rows, int cols, int64_t ld_x, float
                      const int *order, int blocks, void *out, int64_t ld_out,
                      int64_t block_stride, ctcasr_stream_t stream);
 
+/* Operands WITHOUT a bound (the gradients dxw: 1e-13 .. 1e-2 inside one matrix) take the same
+ * two-piece form with a power-of-two scale per column or per row - along whichever axis is NOT the
+ * product's K axis, so that the scale factors out of the sum: per column of dxw (per gate unit)
+ * for the weight gradients dW = dxw^T x, per row (per frame) for the data gradient dx = dxw W.
+ * The largest magnitude of a column / row lands in [2^13, 2^14); smaller elements keep 22 bits down
+ * to 2^-18 of it, never less than 2^-40 of it in absolute terms - measured on the operands of real
+ * training steps the weight gradients come out with the fp32 GEMM's error (1.03e-6 vs 1.07e-6 rms
+ * relative, profiles/r03_gemm_bf16_split.md).
+ *   ctcasr_colmax_scale   scale[c] = 2^(13 - exponent(max_r |x[r][c]|)) (1 for an all-zero column)
+ *                         and inv_scale[c] = 1 / scale[c]; workspace: 4 * cols bytes
+ *   ctcasr_split_f16_cols two fp16 pieces of x[r][c] * col_scale[c] * scale (layout as above)
+ *   ctcasr_split_f16_rows the same with the scale of each ROW found on the fly (one workgroup per
+ *                         row, cols <= 16384); inv_scale[r] = 1 / scale of row r
+ *   ctcasr_rescale_rows   out[r][c] (+)= t[r][c] * row_factor[r] * alpha: takes the scales back out
+ *                         of a product (cols % 4 == 0, 16-byte aligned) */
+int ctcasr_colmax_scale(const float *x, int64_t rows, int cols, int64_t ld_x, void *workspace,
+                        float *scale, float *inv_scale, ctcasr_stream_t stream);
+int ctcasr_split_f16_cols(const float *x, int64_t rows, int cols, int64_t ld_x,
+                          const float *col_scale, float scale, const int *order, int blocks,
+                          void *out, int64_t ld_out, int64_t block_stride, ctcasr_stream_t stream);
+int ctcasr_split_f16_rows(const float *x, int64_t rows, int cols, int64_t ld_x, const int *order,
+                          int blocks, void *out, int64_t ld_out, int64_t block_stride,
+                          float *inv_scale, ctcasr_stream_t stream);
+int ctcasr_rescale_rows(const float *t, int64_t ld_t, const float *row_factor, float alpha,
+                        float *out, int64_t ld_out, int64_t rows, int cols, int accumulate,
+                        ctcasr_stream_t stream);
+
 /* The same product with the split done in registers by an own kernel (csrc/split_gemm.hip): no
  * split pass, no K-concatenated copies, no inter-workgroup waits.
  *   C[M, N] (+)= A[M, K] . B[N, K]^T    all fp32, row-major with leading dimensions lda / ldb / ldc

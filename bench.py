@@ -96,29 +96,37 @@ def forward_flops_per_utt(cfg, frames):
     return flops
 
 
-def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f16=True):
+def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f16=True,
+               bwd_f16=True):
     """Time one step would take with every FLOP at the peak of the pipe it runs on: the fp32
     matrix pipe (157.3 TF) for the own kernels; for the split GEMMs the 16-bit matrix pipe
-    (2500 TF) divided by the products per fp32 product - six bf16 products for the gradient GEMMs,
-    three fp16 products for the forward projections of bounded inputs (a third of the split
-    FLOPs except the recurrent weight gradient's share)."""
+    (2500 TF) divided by the products per fp32 product - three fp16 products where the layer's
+    input is bounded (forward projections; with `bwd_f16` their gradient GEMMs too, dxw scaled per
+    column / row), six bf16 products for the rest (dense4's gradients; everything behind a
+    ReLU-RNN cell)."""
     split, fp32 = training_flops_by_pipe(cfg, frames)
     if not split_gemm:
         split, fp32 = 0.0, split + fp32
     from ctc_asr_amd.model import GATES
     t_out = cfg.output_time(frames)
     rec = 2.0 * t_out * 2 * GATES[cfg.cell] * cfg.num_units_rnn ** 2 * cfg.num_layers_rnn
-    forward = (split - rec) / 3.0 if (split_gemm and fwd_f16 and cfg.cell != 'rnn_relu') else 0.0
+    dense4 = 2.0 * t_out * 2 * cfg.num_units_rnn * cfg.num_units_dense
+    three = 0.0
+    if split_gemm and fwd_f16 and cfg.cell != 'rnn_relu':
+        three = (split - rec) / 3.0                       # the forward products
+        if bwd_f16:
+            three = split - 2.0 * dense4                  # + every gradient GEMM but dense4's
     roof_ms = utterances / world * (
-        forward * 3.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
-        (split - forward) * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+        three * 3.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+        (split - three) * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
         fp32 / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
     return {'ms_per_step_at_peak': round(roof_ms, 3), 'frac': round(roof_ms / ms_per_step, 4),
             'fp32_equiv_tflop_split_gemms': round(utterances / world * split / 1e12, 3),
-            'of_which_forward_fp16x3': round(utterances / world * forward / 1e12, 3),
+            'of_which_fp16x3': round(utterances / world * three / 1e12, 3),
             'tflop_fp32_pipe': round(utterances / world * fp32 / 1e12, 3),
-            'note': 'per GPU; split GEMMs priced at 2500 TF / 6 (bf16 pieces, gradients) and '
-                    '2500 TF / 3 (fp16 pieces, forward projections), own kernels at 157.3 TF'}
+            'note': 'per GPU; split GEMMs priced at 2500 TF / 3 (fp16 pieces: bounded layer inputs, '
+                    'their gradient GEMMs with per-column / per-row scales of dxw) and 2500 TF / 6 '
+                    '(bf16 pieces), own kernels at 157.3 TF'}
 
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
@@ -472,11 +480,14 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                           'order <= 2 accumulated in fp32 on the 16-bit matrix pipe (gradient GEMMs; '
                           'closer to fp64 than the fp32 GEMM){}; profiles/r03_gemm_bf16_split.md; '
                           'CTCASR_SPLIT_GEMM=0 selects the fp32 library GEMMs'.format(
-                              '; forward projections of bounded inputs as two fp16 pieces and '
-                              'three products (the fp32 GEMM\'s error)' if model.fwd_f16 else ''))
+                              '; where the layer input is bounded (|h| <= 1, clipped ReLU): two '
+                              'fp16 pieces and three products, the fp32 GEMM\'s error - forward '
+                              'projections{}'.format(
+                                  ' and their gradient GEMMs (dxw scaled per column / per row on '
+                                  'the device)' if model.bwd_f16 else '') if model.fwd_f16 else ''))
                          if model.split_gemm else 'fp32 library GEMMs (CTCASR_SPLIT_GEMM=0)',
             'roof': mixed_roof(cfg, frames, batch * world, ms_per_step, model.split_gemm, world,
-                               model.fwd_f16),
+                               model.fwd_f16, model.bwd_f16),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),

@@ -8,6 +8,7 @@ import json
 import os
 import sys
 
+os.environ['CTCASR_BWD_F16'] = '0'      # the capture below hooks the bf16 form's weight-gradient call
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -75,6 +75,23 @@ HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
+def dtype_label(model):
+    """The arithmetic the step computes in, spelled out: tensors, accumulation and the own kernels
+    are fp32; the big GEMMs multiply fp16 / bf16 PIECES of the fp32 operands on the 16-bit matrix
+    pipe unless CTCASR_SPLIT_GEMM=0."""
+    if not model.split_gemm:
+        return 'f32'
+    gemms = 'bf16x6 split (24 significand bits)'
+    if model.fwd_f16:
+        gemms = 'fp16x3 split (22 significand bits) where the layer input is bounded - {} - ' \
+                'bf16x6 split (24 bits) elsewhere'.format(
+                    'forward projections and their gradient GEMMs' if model.bwd_f16
+                    else 'forward projections')
+    rec = '; forward recurrence h x W_hh as fp16x3 split, fp32 accumulate' \
+        if getattr(model, 'rnn_fwd_f16', False) else ''
+    return 'f32 tensors / accumulate / own kernels; projection GEMMs: ' + gemms + rec
+
+
 def forward_flops_per_utt(cfg, frames):
     """SURVEY.md 8d formula: conv + input/recurrent projections + dense4 + logits."""
     from ctc_asr_amd.model import CONV_KERNEL_SIZES, GATES
@@ -285,11 +302,13 @@ def pmc_traffic(workload, which, launch_steps):
 
 
 def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=True,
-            split_gemm=None):
+            model_attrs=None):
     """Build the workload ``name`` on this rank's GPU, run warm-up + timed steps under the
     contract's protocol and return the result dict (rank 0) or None.  ``allreduce_early``
     selects the release mode of the gradient buckets (None: the environment / default),
-    ``reduce=False`` runs the same step without any collective (to price the all-reduce)."""
+    ``reduce=False`` runs the same step without any collective (to price the all-reduce),
+    ``model_attrs`` overrides attributes of the CTCModel (which arithmetic the GEMMs run in:
+    PROBE_VARIANTS)."""
     from ctc_asr_amd import hip
     from ctc_asr_amd.engine import Trainer
     from ctc_asr_amd.model import CTCModel, GATES, ModelConfig
@@ -305,8 +324,8 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
     trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True,
                       allreduce_early=allreduce_early, reduce=reduce)
     model = trainer.model
-    if split_gemm is not None:          # (None: the model's default / CTCASR_SPLIT_GEMM)
-        model.split_gemm = bool(split_gemm)
+    for key, value in (model_attrs or {}).items():    # (None: the defaults / CTCASR_* switches)
+        setattr(model, key, value)
     if args.rnn_bwd_whole_chip:
         model.rnn_bwd_flags = hip.RNN_WHOLE_CHIP
 
@@ -461,7 +480,7 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
             'value': round(value, 2), 'unit': 'audio-s/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic (16 kHz int16 Gaussian-noise PCM of fixed-length '
+            'dtype': dtype_label(model), 'data': 'synthetic (16 kHz int16 Gaussian-noise PCM of fixed-length '
                                     'utterances resident in HBM, random labels at 15 chars/s)',
             'config': {'workload': '{}: DS2 {}-conv + {}xBi{}-{}, '
                                    'batch {}/GPU, {:.0f} s utterances'.format(
@@ -707,11 +726,18 @@ def measure_c5(args, rank, local_rank, world):
 
 
 # ------------------------------------------------------------------------------ parity probe
-# (4 x 100 rows: enough for the model to take its bf16-split GEMM path, model.split_gemm)
+# small shape: 4 x 100 rows - enough for the model to take its split-GEMM path; the fall-back when
+# the host cannot finish the full-size oracle in time
 PROBE_BATCH, PROBE_FRAMES, PROBE_LABEL_LEN = 4, 199, 30        # T' = 100
+# which GEMM arithmetic a probe variant runs: attributes of CTCModel
+PROBE_VARIANTS = (
+    ('default', {}),
+    ('bf16x6', {'fwd_f16': False, 'bwd_f16': False, 'rnn_fwd_f16': False}),
+    ('fp32_library_gemms', {'split_gemm': False, 'rnn_fwd_f16': False}),
+)
 
 
-def _probe_setup(cfg_kwargs):
+def _probe_setup(cfg_kwargs, batch=PROBE_BATCH, frames=PROBE_FRAMES, label_len=PROBE_LABEL_LEN):
     """Model, parameters and inputs of the parity probe - deterministic, so that the GPU process
     and the CPU child build the same thing independently."""
     from ctc_asr_amd.model import ModelConfig, init_params
@@ -720,10 +746,9 @@ def _probe_setup(cfg_kwargs):
     rng = np.random.default_rng(2024)
     for name in flat:       # the initialiser's biases are zero: give every term something to do
         flat[name] = (flat[name] + rng.normal(size=flat[name].shape) * 0.01).astype(np.float32)
-    feats = rng.normal(size=(PROBE_BATCH, PROBE_FRAMES, 80)).astype(np.float32)
-    lengths = np.full(PROBE_BATCH, PROBE_FRAMES, dtype=np.int32)
-    labels = [[int(v) for v in rng.integers(1, 28, size=PROBE_LABEL_LEN)]
-              for _ in range(PROBE_BATCH)]
+    feats = rng.normal(size=(batch, frames, 80)).astype(np.float32)
+    lengths = np.full(batch, frames, dtype=np.int32)
+    labels = [[int(v) for v in rng.integers(1, 28, size=label_len)] for _ in range(batch)]
     return cfg, flat, feats, lengths, labels
 
 
@@ -731,55 +756,85 @@ def _parity_probe_worker(spec):
     """Child process: the oracle's side of the probe (float64 torch restatement on the CPU)."""
     from ctc_asr_amd.model import to_oracle_layout
     from oracle import torch_ref
-    cfg, flat, feats, lengths, labels = _probe_setup(spec['cfg'])
+    cfg, flat, feats, lengths, labels = _probe_setup(spec['cfg'], spec['batch'], spec['frames'],
+                                                     spec['label_len'])
     torch.set_num_threads(spec['threads'])
     ref = torch_ref.TorchRefModel(to_oracle_layout(flat, cfg), cfg.used_model, cfg.rnn_cell,
                                   cfg.cudnn, dtype=torch.float64)
+    t0 = time.perf_counter()
     with torch.no_grad():
         logits, seq_len = ref(torch.tensor(feats, dtype=torch.float64), lengths)
         loss, _ = ref.loss(logits, seq_len, labels)
     np.save(spec['logits_path'], logits.numpy())
-    print(json.dumps({'loss': float(loss)}))
+    print(json.dumps({'loss': float(loss), 'seconds': time.perf_counter() - t0}))
 
 
-def parity_probe(cfg_kwargs, device, hard_limit_s=300.0):
-    """The second half of BASELINE.json's metric ("CTC loss delta vs ref"): one forward + CTC
-    loss of the workload's architecture on a small fixed batch (B = 4, T' = 100, seeded weights
-    and inputs, dropout off) on the GPU - through the same kernels as the timed steps - against
-    the oracle (``oracle/torch_ref.py`` in float64, in a child process on the host).  The oracle
-    is the checker here, outside the timed region."""
-    import tempfile
+def _probe_gpu_side(cfg_kwargs, device, batch, frames, label_len, variants):
+    """Forward + CTC loss on the GPU for every GEMM-arithmetic variant: {name: (loss, logits,
+    what ran)}."""
     from ctc_asr_amd.model import CTCModel
-    cfg, flat, feats, lengths, labels = _probe_setup(cfg_kwargs)
-    model = CTCModel(cfg, device, params=flat)
-    logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(lengths), training=True)
-    loss = float(model.loss_fn(logits, seq_len, labels))
-    model.check_rnn_error()
-    got = logits.cpu().numpy()
-    split_ran = bool(model._w_split)
-    del model
-    torch.cuda.empty_cache()
+    cfg, flat, feats, lengths, labels = _probe_setup(cfg_kwargs, batch, frames, label_len)
+    out = {}
+    for name, attrs in variants:
+        model = CTCModel(cfg, device, params=flat)
+        for key, value in attrs.items():
+            setattr(model, key, value)
+        logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(lengths),
+                                             training=True)
+        loss = float(model.loss_fn(logits, seq_len, labels))
+        model.check_rnn_error()
+        out[name] = (loss, logits.cpu().numpy(), model.arithmetic())
+        del model
+        torch.cuda.empty_cache()
+    return out
+
+
+def parity_probe(cfg_kwargs, device, batch=PROBE_BATCH, frames=PROBE_FRAMES,
+                 label_len=PROBE_LABEL_LEN, variants=PROBE_VARIANTS[:1], hard_limit_s=300.0):
+    """The second half of BASELINE.json's metric ("CTC loss delta vs ref"): one forward + CTC
+    loss of the workload's architecture on a fixed batch (seeded weights and inputs, dropout off)
+    on the GPU - through the same kernels as the timed steps, once per GEMM-arithmetic variant -
+    against the oracle (``oracle/torch_ref.py`` in float64, in a child process on the host that
+    runs while the GPU does its side).  The oracle is the checker here, outside the timed
+    region."""
+    import tempfile
     _, physical = host_cores()
     with tempfile.TemporaryDirectory() as tmp:
-        spec = {'cfg': cfg_kwargs, 'threads': min(32, physical),
-                'logits_path': os.path.join(tmp, 'logits.npy')}
+        spec = {'cfg': cfg_kwargs, 'threads': min(32, physical), 'batch': batch, 'frames': frames,
+                'label_len': label_len, 'logits_path': os.path.join(tmp, 'logits.npy')}
         code = ('import json,sys; sys.path.insert(0, {!r}); import bench; '
                 'bench._parity_probe_worker(json.loads(sys.argv[1]))').format(ROOT)
+        child = subprocess.Popen([sys.executable, '-c', code, json.dumps(spec)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         try:
-            out = subprocess.run([sys.executable, '-c', code, json.dumps(spec)],
-                                 capture_output=True, text=True, timeout=hard_limit_s)
-            ref_loss = json.loads(out.stdout.strip().splitlines()[-1])['loss']
+            gpu = _probe_gpu_side(cfg_kwargs, device, batch, frames, label_len, variants)
+            stdout, _ = child.communicate(timeout=hard_limit_s)
+            answer = json.loads(stdout.strip().splitlines()[-1])
+            ref_loss = answer['loss']
             ref_logits = np.load(spec['logits_path'])
-        except Exception as err:
+        except Exception as err:        # noqa: BLE001 - report, never take the line down
+            child.kill()
+            child.communicate()
             return {'ctc_loss_delta': None, 'logits_max_abs_delta': None,
+                    'batch': batch, 'frames': frames,
                     'note': 'oracle child failed: {}'.format(type(err).__name__)}
-    return {'ctc_loss_delta': abs(loss - ref_loss),
-            'logits_max_abs_delta': float(np.abs(got - ref_logits).max()),
-            'loss_gpu': loss, 'loss_oracle': ref_loss, 'tolerance': 1e-3,
-            'batch': PROBE_BATCH, 'ctc_steps': int(got.shape[0]), 'split_gemms': split_ran,
-            'note': 'forward + CTC loss of this workload\'s architecture, seeded weights / inputs, '
-                    'dropout off, GPU fp32 vs oracle/torch_ref.py float64 on the host (checker, '
-                    'outside the timed region)'}
+    per_variant = {}
+    for name, (loss, logits, what) in gpu.items():
+        per_variant[name] = {'ctc_loss_delta': abs(loss - ref_loss),
+                             'ctc_loss_rel_delta': abs(loss - ref_loss) / max(1.0, abs(ref_loss)),
+                             'logits_max_abs_delta': float(np.abs(logits - ref_logits).max()),
+                             'loss_gpu': loss, 'arithmetic': what}
+    first = per_variant[variants[0][0]]
+    return {'ctc_loss_delta': first['ctc_loss_delta'],
+            'logits_max_abs_delta': first['logits_max_abs_delta'],
+            'loss_gpu': first['loss_gpu'], 'loss_oracle': ref_loss, 'tolerance': 1e-3,
+            'batch': batch, 'frames': frames, 'ctc_steps': int(ref_logits.shape[0]),
+            'labels_per_utterance': label_len, 'variants': per_variant,
+            'oracle_seconds': round(answer.get('seconds', 0.0), 1), 'oracle_threads': spec['threads'],
+            'note': 'forward + CTC loss of this workload\'s architecture at the shape named here, '
+                    'seeded weights / inputs, dropout off, GPU vs oracle/torch_ref.py float64 on '
+                    'the host (checker, outside the timed region); one GPU pass per GEMM '
+                    'arithmetic (`variants`), the top-level deltas are the default path\'s'}
 
 
 def merge_release_modes(legs, stub):
@@ -841,6 +896,11 @@ def main():
                     help='persistent backward recurrence on all 256 CUs (default: 128)')
     ap.add_argument('--no-parity-probe', action='store_true',
                     help='skip the CTC-loss / logits delta against the oracle (N = 1)')
+    ap.add_argument('--parity-probe', default='full', choices=('full', 'small'),
+                    help='shape of the parity probe: the timed workload\'s own (default) or '
+                         'batch 4 x T\' = 100')
+    ap.add_argument('--parity-probe-limit', type=float, default=420.0,
+                    help='seconds the float64 oracle child may take at full size')
     ap.add_argument('--no-step-checks', action='store_true',
                     help='train_step(check=False): without the deferred per-step error checks')
     ap.add_argument('--c5-batches', type=int, default=24,
@@ -922,17 +982,20 @@ def main():
             second, _ = measure('c2', args, rank, local_rank, world)
             other['c2'] = {k: second[k] for k in ('value', 'unit', 'ms_per_step', 'config',
                                                   'step_tflops_fp32', 'frac_of_fp32_mfma_peak',
-                                                  'kernel_ms_per_step', 'roofline')}
+                                                  'kernel_ms_per_step', 'roofline',
+                                                  'host_enqueue_ms_per_step')}
         except Exception as err:        # noqa: BLE001 - anything: keep the headline line
             other['c2'] = {'error': '{}: {}'.format(type(err).__name__, err)}
         try:
             # the headline workload once more with the library's fp32 GEMMs (no bf16 split): what
             # the split buys, on this box, in this run
-            plain, _ = measure('c3', args, rank, local_rank, world, split_gemm=False)
-            other['c3_fp32_library_gemms'] = {k: plain[k] for k in (
-                'value', 'unit', 'ms_per_step', 'gemm_path', 'roof', 'kernel_ms_per_step')}
+            for label, attrs in PROBE_VARIANTS[1:]:
+                plain, _ = measure('c3', args, rank, local_rank, world, model_attrs=attrs)
+                other['c3_' + label] = {k: plain[k] for k in (
+                    'value', 'unit', 'ms_per_step', 'dtype', 'gemm_path', 'roof',
+                    'kernel_ms_per_step', 'host_enqueue_ms_per_step')}
         except Exception as err:        # noqa: BLE001
-            other['c3_fp32_library_gemms'] = {'error': '{}: {}'.format(type(err).__name__, err)}
+            other['c3_variants'] = {'error': '{}: {}'.format(type(err).__name__, err)}
         try:
             c5_args = argparse.Namespace(**vars(args))
             c5_args.steps = args.c5_batches
@@ -951,10 +1014,26 @@ def main():
         if other:
             result['other_workloads'] = other
         if world == 1 and not args.no_parity_probe:
-            # BASELINE.json's metric, second half: CTC loss (and logits) delta vs the oracle
+            # BASELINE.json's metric, second half: CTC loss (and logits) delta vs the oracle, AT
+            # THE SHAPE THE NUMBER ABOVE WAS MEASURED ON (C3: 5 layers, batch 32, 999 frames ->
+            # T' = 500), once per GEMM arithmetic; the small shape only if the host cannot finish
+            # the float64 oracle in time (or with --parity-probe small)
+            probe_kwargs = workload_cfg_kwargs(args.workload)
+            probe = None
             try:
-                probe = parity_probe(workload_cfg_kwargs(args.workload),
-                                     'cuda:{}'.format(local_rank))
+                if args.parity_probe == 'full' and args.workload != 'c5':
+                    probe = parity_probe(probe_kwargs, 'cuda:{}'.format(local_rank), batch=batch,
+                                         frames=frames, label_len=int(round(15 * seconds)),
+                                         variants=PROBE_VARIANTS,
+                                         hard_limit_s=args.parity_probe_limit)
+                    probe['shape'] = 'the timed workload\'s own'
+                if probe is None or probe['ctc_loss_delta'] is None:
+                    full = probe
+                    probe = parity_probe(probe_kwargs, 'cuda:{}'.format(local_rank),
+                                         variants=PROBE_VARIANTS)
+                    probe['shape'] = 'small (batch 4, T\' = 100)'
+                    if full is not None:
+                        probe['full_size_attempt'] = full['note']
             except Exception as err:    # noqa: BLE001
                 probe = {'ctc_loss_delta': None, 'logits_max_abs_delta': None,
                          'note': 'probe failed: {}: {}'.format(type(err).__name__, err)}
@@ -962,10 +1041,14 @@ def main():
             result['logits_max_abs_delta'] = probe['logits_max_abs_delta']
             result['parity_probe'] = probe
             # (an oracle child that could not run - a host without the time for it - leaves the
-            # deltas null and says why; only a MEASURED delta above the bar fails the run)
-            if probe['ctc_loss_delta'] is not None and (
-                    probe['ctc_loss_delta'] > 1e-3 or probe['logits_max_abs_delta'] > 1e-3):
-                exit_code = 3                    # the line is printed, the run fails
+            # deltas null and says why; only a MEASURED delta above the bar fails the run: any
+            # variant's, since every one of them is a number this line quotes)
+            for variant in (probe.get('variants') or {'default': probe}).values():
+                if variant['ctc_loss_delta'] is not None and (
+                        variant['ctc_loss_delta'] > 1e-3 * max(1.0, abs(probe.get('loss_oracle')
+                                                                       or 1.0)) or
+                        variant['logits_max_abs_delta'] > 1e-3):
+                    exit_code = 3                    # the line is printed, the run fails
         if world == 1 and not args.no_cpu_baseline and args.workload != 'c5':
             result['cpu_baseline'] = cpu_baseline(workload_cfg_kwargs(args.workload), batch,
                                                   seconds, frames)

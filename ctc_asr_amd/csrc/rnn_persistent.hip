@@ -711,6 +711,320 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward on the fp16 matrix pipe (round 4; LSTM / GRU, `flags` bit CTCASR_RNN_F16).
+//
+// prnn_fwd_kernel is bound by the issue rate of v_mfma_f32_16x16x4_f32 (3.4 of its 6.1 us per
+// step at B = 32: 256 MFMAs of 32 cycles per wave), and gfx950 runs the 16-bit MFMAs at 16 x that
+// rate.  Both operands of THIS product are bounded - |h| <= 1, and a workgroup's slice of W_hh by
+// its own largest magnitude - so each is held as TWO fp16 pieces after a power-of-two scale,
+//     x s = x1 + x2,   x1 = rne_f16(x s),  x2 = rne_f16(x s - x1)        (11 + 11 mantissa bits)
+// and the product is the three piece products h1 w1 + h1 w2 + h2 w1 accumulated in fp32 by
+// v_mfma_f32_16x16x32_f16 (dropped: h2 w2 <= 2^-22 |h w|; the same form as the forward projection
+// GEMMs) - 3 MFMAs of K = 32 where the fp32 kernel issues 8 of K = 4.
+// Nothing else changes size: W_hh as two fp16 pieces is the 4 bytes per weight of the fp32 slice
+// (same LDS / register split), and h is PUBLISHED as its two pieces - the 16-byte granule that
+// carried 4 floats of 4 consecutive units now carries their 4 first pieces and 4 second pieces -
+// so the exchange moves the same bytes and the consumer needs no conversion: the granules of two
+// 16-unit chunks are, register for register, the A fragments (first pieces: dwords x, y of both
+// granules; second pieces: z, w) of one K = 32 step.
+//   scale of h: 2^15 (|h| <= 1); scale of W_hh: per workgroup, found while staging - the largest
+//   magnitude of the slice lands in [2^14, 2^15) - so no weight can overflow whatever its size
+//   (a per-workgroup scale is a per-output-column scale: it leaves through the accumulator).
+// K chunk c of wave w (32 units) = exchange chunks 2c, 2c + 1 of the wave's range; lane l of a
+// fragment holds units 4 (l >> 4) + e (e < 4) of the first and + e - 4 of the second chunk - A and
+// B use the same map, which is all an MFMA needs.
+// B-fragment slots per wave: (c * NT + nt) * 2 + piece; the last REGW of them live in registers.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union Frag16 {
+    u32x4 u;
+    f16x8 h;
+};
+#define PRNN_F16_H_SCALE 32768.0f
+// the two pieces of s (already scaled): first piece in the low half, second in the high half
+__device__ __forceinline__ unsigned f16_pieces(float s) {
+    const _Float16 h1 = (_Float16)s;
+    const _Float16 h2 = (_Float16)(s - (float)h1);
+    return (unsigned)__builtin_bit_cast(unsigned short, h1) |
+           ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+}
+__device__ __forceinline__ u32x4 load16u(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+}
+
+template <int CELL, int NT, int KC, int REGW = 0>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
+    constexpr bool GRU = CELL == CTCASR_CELL_GRU;
+    constexpr int G = 4;
+    constexpr int GR = GRU ? 3 : G;
+    constexpr int COLS = 16 * NT;
+    constexpr int UPB = COLS / G;
+    constexpr int QS = KC * NT * 2;      // B-fragment slots per wave (two pieces per tile and chunk)
+    constexpr int QL = QS - REGW;        // ... of which in LDS
+    constexpr int QW = 2 * KC;           // 16-unit exchange chunks per wave
+    static_assert(16 * UPB <= PRNN_THREADS, "one item per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(u32x4));
+    float *wave_top = red + 4 * NT * 16 * 17;
+
+    const int chain = p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
+    const int row0 = chain * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int H = p.H, B = p.B, T = p.T, BS = p.BS;
+    const int u0 = slice * UPB;
+
+    // ---- stage this workgroup's slice of R as scaled fp16 pieces, in fragment order (once) -----
+    // the 8 floats of fragment (chunk c, tile nt) of this lane
+    auto wload = [&](int c, int nt, float (&v)[8]) {
+        const int col = nt * 16 + (lane & 15);
+        if (GRU && col / UPB >= GR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            return;
+        }
+        const float *wrow = p.w + ((size_t)dir * GR * H + (col / UPB) * H + u0 + (col % UPB)) * H +
+                            wave * (H / 4) + 32 * c + 4 * (lane >> 4);
+        const float4 lo = ldg4(wrow), hi = ldg4(wrow + 16);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+        v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    float w_scale;
+    {
+        float m = 0.f;
+        for (int c = 0; c < KC; ++c)
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[8];
+                wload(c, nt, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+            }
+        m = wave_max(m);
+        if (lane == 0) wave_top[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wave_top[0], wave_top[1]), fmaxf(wave_top[2], wave_top[3]));
+        const unsigned bits = __float_as_uint(m);
+        const int e = (int)((bits >> 23) & 0xFF) - 127;
+        const int se = bits == 0u ? 0 : min(max(14 - e, -60), 60);
+        w_scale = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+    const float out_scale = 1.0f / (w_scale * PRNN_F16_H_SCALE);      // exact: powers of two
+    u32x4 wreg[REGW > 0 ? REGW : 1];
+    {
+        // pieces (first, second) of fragment (c, nt): slots (c * NT + nt) * 2 + {0, 1}
+        auto pieces = [&](int c, int nt, u32x4 &first, u32x4 &second) {
+            float v[8];
+            wload(c, nt, v);
+            unsigned q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = f16_pieces(v[e] * w_scale);
+            first = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                            (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+            second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                             (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+        };
+        for (int pr = 0; pr < QL / 2; ++pr) {
+            u32x4 first, second;
+            pieces(pr / NT, pr % NT, first, second);
+            frag[(wave * QL + 2 * pr) * 64 + lane] = first;
+            frag[(wave * QL + 2 * pr + 1) * 64 + lane] = second;
+        }
+#pragma unroll
+        for (int pr = 0; pr < REGW / 2; ++pr) {
+            pieces((QL / 2 + pr) / NT, (QL / 2 + pr) % NT, wreg[2 * pr], wreg[2 * pr + 1]);
+        }
+    }
+    __syncthreads();
+
+    // exchange buffer: the layout of prnn_fwd_kernel, every 16-byte granule = the first pieces of
+    // 4 consecutive units (8 bytes) followed by their second pieces; the all-zero block in front
+    const size_t x_base = (size_t)2 * B * GR * H;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((x_base + (size_t)T * 2 * B * H) * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * H;
+    const int rot = REGW == 0 ? (slice % KC) : 0;
+
+    // ---- the item of this thread: row tid / UPB of the tile, unit tid % UPB -------------------
+    const bool has_item = tid < 16 * UPB;
+    const int ib = tid / UPB, iu = tid % UPB;
+    const int brow = row0 + ib, unit = u0 + iu;
+    const int steps = has_item && brow < B ? row_steps(p.seq_len, brow, T) : 0;
+    float c_state = 0.f;
+    if (p.s_lo > 0 && steps > 0) c_state = p.carry[((size_t)dir * B + brow) * H + unit];
+    const int arow = row0 + (lane & 15);
+    const int a_steps = arow < B ? row_steps(p.seq_len, arow, T) : 0;
+    float xb[GR], bq = 0.f;
+#pragma unroll
+    for (int g = 0; g < GR; ++g)
+        xb[g] = p.bias && has_item ? p.bias[(size_t)dir * GR * H + (size_t)g * H + unit] : 0.f;
+    if (GRU && has_item) bq = p.b_hh[(size_t)dir * 3 * H + 2 * H + unit];
+
+    unsigned long long pt[5] = {0, 0, 0, 0, 0};
+    const bool prof = p.prof && tid == 0;
+    for (int s = p.s_lo; s < p.s_hi; ++s) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
+        float xw[GR];
+        int it_t = -1;
+        if (s < steps) {
+            it_t = row_time(dir, s, steps);
+            const float *x = p.xw + (((size_t)it_t * BS + brow) * 2 + dir) * GR * H + unit;
+#pragma unroll
+            for (int g = 0; g < GR; ++g) xw[g] = x[(size_t)g * H] + xb[g];
+        }
+
+        // three accumulators per tile: h1 w1, h1 w2, h2 w1 - independent chains for the matrix
+        // pipe, and the small terms are summed apart from the big one
+        f32x4 acc[3][NT];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        if (s > 0) {
+            if (s > p.s_lo) {
+                dir_wait<1>(p.sync, nullptr, dir, chain, group_size, (unsigned)(s - 1 - p.s_lo),
+                            tid);
+                if (s == p.s_hi - 1 && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
+            const bool ok = s < a_steps;
+            const unsigned aoff = (unsigned)(((ok ? x_base + (size_t)(s - 1) * x_step : 0) +
+                                              (size_t)dir * B * H +
+                                              (size_t)(wave * QW) * B * 16 +
+                                              (size_t)(lane >> 4) * B * 4 +
+                                              (size_t)(ok ? arow : 0) * 4) * sizeof(float));
+            u32x4 a[KC][2];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int cc = (c + rot) % KC;
+                a[c][0] = load16u(x_rsrc, aoff + (unsigned)((2 * cc) * B * 64));
+                a[c][1] = load16u(x_rsrc, aoff + (unsigned)((2 * cc + 1) * B * 64));
+            }
+            __builtin_amdgcn_sched_barrier(0);      // every exchange load above the first MFMA
+            auto bfrag = [&](int c, int nt, int piece) -> u32x4 {
+                if constexpr (REGW == 0) {
+                    return frag[(wave * QL + (((c + rot) % KC) * NT + nt) * 2 + piece) * 64 + lane];
+                } else {
+                    const int sl = (c * NT + nt) * 2 + piece;
+                    return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                Frag16 h1, h2;
+                h1.u = (u32x4){a[c][0].x, a[c][0].y, a[c][1].x, a[c][1].y};
+                h2.u = (u32x4){a[c][0].z, a[c][0].w, a[c][1].z, a[c][1].w};
+                Frag16 w1[NT], w2[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    w1[nt].u = bfrag(c, nt, 0);
+                    w2[nt].u = bfrag(c, nt, 1);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1.h, w1[nt].h, acc[0][nt],
+                                                                        0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1.h, w2[nt].h, acc[1][nt],
+                                                                        0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2.h, w1[nt].h, acc[2][nt],
+                                                                        0, 0, 0);
+            }
+        }
+        if (prof) {
+            asm volatile("" ::"v"(acc[0][0][0]));
+            unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
+        }
+        // cross-wave reduction of the K split (the scales leave here)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((wave * NT + nt) * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] =
+                    (acc[0][nt][r] + (acc[1][nt][r] + acc[2][nt][r])) * out_scale;
+        __syncthreads();
+        if (prof) { unsigned long long c = wall_clock64(); pt[4] += c - c0; }
+
+        float hv = 0.f, rsv[5];
+        if (it_t >= 0) {
+            float rec[GR];
+#pragma unroll
+            for (int g = 0; g < GR; ++g) {
+                const int c = g * UPB + iu;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    sum += red[((w * NT + (c >> 4)) * 16 + ib) * 17 + (c & 15)];
+                rec[g] = sum;
+            }
+            if constexpr (!GRU) {
+                const float gi = sigmoidf_(xw[0] + rec[0]);
+                const float gf = sigmoidf_(xw[1] + rec[1]);
+                const float gg = tanhf_(xw[2] + rec[2]);
+                const float go = sigmoidf_(xw[3] + rec[3]);
+                const float c = gf * c_state + gi * gg;
+                c_state = c;
+                hv = go * tanhf_(c);
+                rsv[0] = gi; rsv[1] = gf; rsv[2] = gg; rsv[3] = go; rsv[4] = c;
+            } else {
+                const float gr_ = sigmoidf_(xw[0] + rec[0]);
+                const float gz = sigmoidf_(xw[1] + rec[1]);
+                const float q = rec[2] + bq;
+                const float gn = tanhf_(xw[2] + gr_ * q);
+                hv = (1.f - gz) * gn + gz * c_state;
+                c_state = hv;
+                rsv[0] = gr_; rsv[1] = gz; rsv[2] = gn; rsv[3] = q;
+            }
+        }
+        // publish h as its two fp16 pieces: lanes of 4 consecutive units gather into one 16-byte
+        // sc1 store (first pieces, then second pieces)
+        const unsigned q0 = f16_pieces(hv * PRNN_F16_H_SCALE);
+        const unsigned q1 = __shfl_down(q0, 1, 64), q2 = __shfl_down(q0, 2, 64),
+                       q3 = __shfl_down(q0, 3, 64);
+        if (it_t >= 0 && (tid & 3) == 0) {
+            const u32x4 v = {(q0 & 0xFFFFu) | (q1 << 16), (q2 & 0xFFFFu) | (q3 << 16),
+                             (q0 >> 16) | (q1 & 0xFFFF0000u), (q2 >> 16) | (q3 & 0xFFFF0000u)};
+            __builtin_amdgcn_raw_buffer_store_b128(
+                v, x_rsrc,
+                (int)(unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * H +
+                                 (size_t)(unit >> 4) * B * 16 + (size_t)((unit & 15) >> 2) * B * 4 +
+                                 (size_t)brow * 4) * sizeof(float)),
+                0, 16);
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
+        if (s + 1 < p.s_hi) {
+            unsigned unused = 0;
+            dir_arrive<1>(p.sync, nullptr, dir, chain, grp, tid, unused);
+        }
+        // y and the reserve for the backward pass: nobody inside this launch reads them
+        if (it_t >= 0) {
+            p.y[((size_t)it_t * BS + brow) * 2 * H + dir * H + unit] = hv;
+            float *gr = p.gates + (((size_t)it_t * BS + brow) * 2 + dir) * 4 * H + unit;
+            gr[0] = rsv[0]; gr[H] = rsv[1]; gr[2 * H] = rsv[2]; gr[3 * H] = rsv[3];
+            if constexpr (!GRU)
+                p.cells[(((size_t)it_t * BS + brow) * 2 + dir) * H + unit] = rsv[4];
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if (p.s_hi < T && has_item && brow < B)
+        p.carry[((size_t)dir * B + brow) * H + unit] = c_state;
+    if (prof) {
+        for (int i = 0; i < 4; ++i) {
+            if (blockIdx.x == 0) p.sync->prof[chain * 8 + i] = pt[i];
+            if (blockIdx.x < 256 && chain == 0) p.sync->prof_all[blockIdx.x][i] = pt[i];
+        }
+        if (blockIdx.x == 0) p.sync->prof[chain * 8 + 4] = pt[4];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward.  Each workgroup owns UPB hidden units (output columns of dh_rec = dgates x R); the K
 // dimension is G*H (all gates of all units), split over the 4 waves: QW chunks each.
 //   UPB = 8, REGW = 0  : 128 workgroups per direction = the whole chip; the slice (128 KB) is in
@@ -1506,6 +1820,38 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
     p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
     const int mt = (B + 15) / 16;
     const bool one_barrier = (flags & CTCASR_RNN_ONE_BARRIER) != 0;
+    // fp16 matrix pipe (CTCASR_RNN_F16): the same geometries as the fp32 kernels below - H = 2048
+    // one direction per launch on 256 workgroups; H = 1024 on 64 workgroups per direction and
+    // batch tile (16 units, weights half in LDS, half in registers) for B > 16 or on half of the
+    // chip, else 128 workgroups per direction with the 128 KB slice in LDS
+    if ((flags & CTCASR_RNN_F16) && (cell == CTCASR_CELL_LSTM || cell == CTCASR_CELL_GRU) &&
+        !(mt == 2 && one_barrier)) {
+        const bool lstm = cell == CTCASR_CELL_LSTM;
+        if (H == 2048) {
+            p.nwg = 256; p.ndir = 1;
+            const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 + 32;
+            for (int tile = 0; tile < mt; ++tile)
+                for (int dir = 0; dir < 2; ++dir) {
+                    p.chain0 = tile; p.dir0 = dir;
+                    const int rc = lstm
+                        ? launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_LSTM, 2, 16, 32>, p, lds, s)
+                        : launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_GRU, 2, 16, 32>, p, lds, s);
+                    if (rc != CTCASR_OK) return rc;
+                }
+            return CTCASR_OK;
+        }
+        if (mt == 2 || fwd_half_chip) {
+            p.nwg = 64;
+            const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 4 * 16 * 17 * 4 + 32;
+            return lstm
+                ? launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_LSTM, 4, 8, 32>, p, lds, s, 1, mt)
+                : launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_GRU, 4, 8, 32>, p, lds, s, 1, mt);
+        }
+        p.nwg = 128;
+        const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 + 32;
+        return lstm ? launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_LSTM, 2, 8, 0>, p, lds, s)
+                    : launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_GRU, 2, 8, 0>, p, lds, s);
+    }
     // 128 workgroups per direction, 16 * NT gate columns each, QW = H / 64 K chunks per wave
 #define PRNN_FWD(CELL_, NT_, QW_, MT_)                                                        \
     return launch_persistent(prnn_fwd_kernel<CELL_, NT_, QW_, MT_>, p,                         \

@@ -348,6 +348,10 @@ class CTCModel:
         # scaled per column (weight gradients) / per row (data gradient) on the device
         self.bwd_f16 = os.environ.get('CTCASR_BWD_F16', '1') == '1'
         self.split_wgrad = os.environ.get('CTCASR_SPLIT_WGRAD', '1') == '1'
+        # the forward recurrence's own product h_(t-1) W_hh^T as two fp16 pieces per operand and
+        # three products on the fp16 matrix pipe (LSTM-1024 persistent kernel; |h| <= 1, W_hh
+        # scaled per workgroup inside the kernel) instead of fp32 MFMAs
+        self.rnn_fwd_f16 = os.environ.get('CTCASR_RNN_FWD_F16', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
         self._side_stream = None
         self.early_hooks = False        # see backward(); set by engine.Trainer
@@ -583,6 +587,12 @@ class CTCModel:
         cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
         rnn_len = None if cfg.cudnn else seq_length
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
+        arithmetic = acts['arithmetic'] = {}
+        # h W_hh^T of the forward recurrence on the fp16 matrix pipe (persistent LSTM / GRU kernels)
+        f16_rec = (self.rnn_fwd_f16 and cell in ('lstm', 'gru') and
+                   hip.rnn_persistent_supported(cell, t_out, batch, hidden))
+        rnn_flags = hip.RNN_F16 if f16_rec else hip.RNN_DEFAULT
+        rnn_form = 'fp16x3' if f16_rec else 'fp32'
         in_split = []                   # bf16 pieces of the layer inputs (None: fp32 GEMM)
         in_split16 = []                 # (fp16 pieces, scale) where the forward used them
         pipelined_xw = None
@@ -604,6 +614,7 @@ class CTCModel:
             # kernel (`xw_bias`): the GEMM then is a plain product without a bias epilogue
             # (3.93 instead of 4.16 ms per layer at C3) and no pass over xw is spent on it
             xs = ws = pieces16 = None
+            form = 'fp32'
             if pipelined_xw is not None:       # built beside the previous layer's recurrence
                 xw, pipelined_xw = pipelined_xw, None
             elif self._weight_split('rnn{}'.format(i)) is not None:
@@ -615,13 +626,16 @@ class CTCModel:
                     x16 = split_gemm.split16(x.view(t_out * batch, -1), scale, split_gemm.H_A)
                     xw = split_gemm.mm_nt16(x16, w_pieces[2], scale * split_gemm.W_SCALE)
                     pieces16 = (x16, scale)
+                    form = 'fp16x3'
                 else:
                     xs = split_gemm.split(x.view(t_out * batch, -1), split_gemm.A_ORDER)
                     xw = split_gemm.mm_nt(xs, w_pieces[0])
+                    form = 'bf16x6'
             else:
                 xw = torch.mm(x.view(t_out * batch, -1), w_ih.t())
             in_split.append(xs)
             in_split16.append(pieces16)
+            arithmetic['rnn{}/input_projection'.format(i)] = form
             if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
                 y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
                     i, xw, t_out, batch, hidden, gates, workspace)
@@ -629,7 +643,8 @@ class CTCModel:
                 y, reserve, workspace = hip.rnn_fwd(
                     cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
                     rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,
-                    workspace=workspace, xw_bias=self._rnn_bias(i))
+                    workspace=workspace, xw_bias=self._rnn_bias(i), flags=rnn_flags)
+            arithmetic['rnn{}/recurrence_fwd'.format(i)] = rnn_form
             layer_in.append(x)
             layer_out.append(y)
             reserves.append(reserve)
@@ -657,6 +672,7 @@ class CTCModel:
             acts['flat16'] = (flat16, flat_scale)
             dense4 = split_gemm.mm_nn16_stacked(flat16, k4_pieces[2],
                                                 flat_scale * split_gemm.W_SCALE)
+            arithmetic['dense4'] = 'fp16x3'
             hip.bias_act_fwd(dense4, p['dense4/bias'], cfg.relu_cutoff,
                              cfg.dense_dropout_rate if training else 0.0, self._next_seed())
         else:
@@ -665,6 +681,7 @@ class CTCModel:
                 flat_split = split_gemm.split(rnn_flat, split_gemm.A_ORDER)
             dense4 = self._dense_act(rnn_flat, 'dense4', cfg.dense_dropout_rate, training,
                                      xs=flat_split)
+            arithmetic['dense4'] = 'bf16x6' if flat_split is not None else 'fp32'
         acts.update(flat_split=flat_split, flat_of=x, flat_uses_split=k4_pieces is not None)
         logits = torch.mm(dense4, p['logits/kernel'])
         hip.bias_act_fwd(logits, p['logits/bias'], 0.0)
@@ -673,6 +690,13 @@ class CTCModel:
         logits = logits.view(t_out, batch, cfg.num_classes)
         self.last_logits, self.last_seq_length = logits, seq_length     # for logging / summaries
         return logits, seq_length
+
+    def arithmetic(self):
+        """What the GEMM-shaped work of the LAST forward pass multiplied in (tensors and
+        accumulation are fp32 everywhere): per layer 'fp16x3' / 'bf16x6' (pieces of the fp32
+        operands on the 16-bit matrix pipe, split_gemm.py) or 'fp32'."""
+        acts = self._acts or {}
+        return dict(acts.get('arithmetic', {}))
 
     def _rnn_workspace(self, cell, t_out, batch, hidden):
         """The recurrence workspace shared by every layer and pass of this model: zero-filled
@@ -748,7 +772,8 @@ class CTCModel:
             lo, hi = bounds[c], bounds[c + 1]
             hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
                         reserve=reserve, workspace=workspace, steps=(lo, hi),
-                        flags=hip.RNN_HALF_CHIP, xw_bias=bias_here, ticket=self._take_ticket())
+                        flags=hip.RNN_HALF_CHIP | (hip.RNN_F16 if self.rnn_fwd_f16 else 0),
+                        xw_bias=bias_here, ticket=self._take_ticket())
             if c + 1 < chunks:
                 ready = torch.cuda.Event()
                 ready.record(main)

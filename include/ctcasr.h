@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTCASR_ABI_VERSION 4
+#define CTCASR_ABI_VERSION 5
 
 enum {
     CTCASR_OK = 0,
@@ -176,6 +176,15 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
  * multiplies the dgates of its OWN units into partial dh tiles for all units, consumers sum 64
  * tiles) instead of the all-gather form (every workgroup reads the dgates of all units) */
 #define CTCASR_RNN_REDUCE_SCATTER 8
+/* forward, LSTM / GRU on the persistent kernels (ABI v5): the recurrent product h W_hh^T on the
+ * fp16 matrix pipe - h (|h| <= 1) and the workgroup's slice of W_hh (scaled by a power of two found
+ * inside the kernel from the slice's largest magnitude, so no weight can overflow) as TWO fp16
+ * pieces each, three piece products, fp32 accumulation: fp32-grade (22 significand bits, the
+ * dropped term <= 2^-22 of a product), not bit-equal to the fp32-MFMA kernel.  Every launch of one
+ * pass (step ranges) must carry the same value of this bit: the exchange buffer then holds h as
+ * its two pieces.  The backward kernels and everything else are unaffected (y, the reserve and
+ * the carry stay fp32).  Other cells / shapes / CTCASR_RNN_ONE_BARRIER ignore the bit. */
+#define CTCASR_RNN_F16 16
 /* Residency ticket (bits 8..31 of `flags`, 0 = none): a persistent launch that carries one posts
  * it in the workspace once ALL of its workgroups are running; ctcasr_rnn_resident_gate() makes
  * another stream wait for exactly that (bounded).  Use: work for the CUs a half-chip launch

@@ -226,6 +226,123 @@ def test_rnn_fwd_bwd(hip, cell, use_len, dims):
         assert np.abs(dw0.numpy() - w_t.grad[0].numpy()).max() < 1e-3
 
 
+def _recurrence_float64(cell, xw, w_hh, b_hh, seq_len):
+    """Forward recurrence in float64 with batched torch ops on the GPU: y [T, B, 2H]."""
+    num_steps, batch, _, _ = xw.shape
+    hidden = w_hh.shape[2]
+    x64, w64 = xw.double(), w_hh.double()
+    steps = torch.full((batch,), num_steps, device=xw.device, dtype=torch.long) \
+        if seq_len is None else seq_len.long()
+    rows = torch.arange(batch, device=xw.device)
+    y = torch.zeros(num_steps, batch, 2 * hidden, dtype=torch.float64, device=xw.device)
+    for d in (0, 1):
+        h = torch.zeros(batch, hidden, dtype=torch.float64, device=xw.device)
+        c = torch.zeros_like(h)
+        for s in range(num_steps):
+            active = s < steps
+            t = torch.where(active, torch.full_like(steps, s) if d == 0 else steps - 1 - s,
+                            torch.zeros_like(steps))
+            x = x64[t, rows, d]
+            rec = h @ w64[d].t()
+            if cell == 'lstm':
+                i, f, g, o = (x + rec).split(hidden, dim=1)
+                c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h_new = torch.sigmoid(o) * torch.tanh(c_new)
+                c = torch.where(active[:, None], c_new, c)
+            else:
+                xr, xz, xn = x.split(hidden, dim=1)
+                rr, rz, rn = rec.split(hidden, dim=1)
+                r, z = torch.sigmoid(xr + rr), torch.sigmoid(xz + rz)
+                n = torch.tanh(xn + r * (rn + b_hh[d, 2 * hidden:].double()))
+                h_new = (1 - z) * n + z * h
+            h = torch.where(active[:, None], h_new, h)
+            y[t[active], rows[active], d * hidden:(d + 1) * hidden] = h[active]
+    return y
+
+
+@pytest.mark.parametrize('cell', ['lstm', 'gru'])
+@pytest.mark.parametrize('use_len', [False, True])
+@pytest.mark.parametrize('dims', [(12, 16, 1024), (40, 7, 1024), (9, 19, 1024), (7, 32, 1024),
+                                  (5, 35, 1024), (6, 16, 2048), (4, 21, 2048)])
+def test_rnn_fwd_on_the_fp16_matrix_pipe(hip, cell, use_len, dims):
+    """CTCASR_RNN_F16: h W_hh^T of the persistent LSTM / GRU forward kernels as two fp16 pieces
+    per operand and three products.  y against a float64 recurrence inside the bar of the fp32
+    kernel's own test (2e-5), next to the fp32 kernel on the same inputs; step ranges and the
+    half-chip variant bit-identical / equal; the backward pass from ITS reserve."""
+    num_steps, batch, hidden = dims
+    gates = onn.GATES[cell]
+    g = torch.Generator(device=DEV).manual_seed(31)
+    xw = torch.randn(num_steps, batch, 2, gates * hidden, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, gates * hidden, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    b_hh = torch.randn(2, gates * hidden, device=DEV, generator=g) * 0.3 if cell == 'gru' else None
+    bias = torch.randn(2 * gates * hidden, device=DEV, generator=g) * 0.1
+    sl = None
+    if use_len:
+        sl = torch.randint(1, num_steps + 1, (batch,), device=DEV, generator=g).int()
+        sl[0] = num_steps
+    assert hip.rnn_persistent_supported(cell, num_steps, batch, hidden)
+    ref = _recurrence_float64(cell, xw + bias.view(1, 1, 2, -1), w_hh, b_hh, sl)
+    y32, _, ws32 = hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias)
+    y16, reserve, ws = hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias,
+                                   flags=hip.RNN_F16)
+    hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
+    hip.rnn_poll_error(cell, ws32, num_steps, batch, hidden)
+    err16 = float((y16.double() - ref).abs().max())
+    err32 = float((y32.double() - ref).abs().max())
+    assert err16 < 2e-5, (err16, err32)
+    assert err16 < 3 * err32 + 2e-6, (err16, err32)
+    assert not torch.equal(y16, y32)             # (it IS another kernel)
+    # step ranges: bit-identical to the single launch (h crosses launches as its fp16 pieces)
+    if num_steps >= 5:
+        cuts = [0, 2, num_steps // 2 + 1, num_steps]
+        y_cut = torch.full_like(y16, float('nan'))
+        reserve_cut, ws_cut = torch.zeros_like(reserve), torch.zeros_like(ws)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias, y=y_cut,
+                        reserve=reserve_cut, workspace=ws_cut, steps=(lo, hi), flags=hip.RNN_F16)
+        hip.rnn_poll_error(cell, ws_cut, num_steps, batch, hidden)
+        assert torch.equal(y_cut, y16)
+        assert torch.equal(reserve_cut, reserve)
+    if cell == 'lstm' and hidden == 1024 and batch <= 16:
+        # half of the chip: another split of the same sums (16 units per workgroup: other scales)
+        y_half, _, ws_half = hip.rnn_fwd(cell, xw, w_hh, sl, xw_bias=bias,
+                                         flags=hip.RNN_F16 | hip.RNN_HALF_CHIP)
+        hip.rnn_poll_error(cell, ws_half, num_steps, batch, hidden)
+        assert float((y_half - y16).abs().max()) < 2e-6
+    # the backward pass (fp32 kernels) from this forward pass's reserve: dxw against autograd
+    # through the float64 recurrence is covered by test_rnn_fwd_bwd for the fp32 reserve; here:
+    # the two reserves differ by the forward kernels' rounding only
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g)
+    w_hh_t = hip.transpose_batched(w_hh)
+    _, reserve32, _ = hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias)
+    dxw16 = hip.rnn_bwd(cell, dy, y16, w_hh_t, reserve, sl, workspace=ws)
+    dxw32 = hip.rnn_bwd(cell, dy, y32, w_hh_t, reserve32, sl, workspace=ws)
+    hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
+    assert float((dxw16 - dxw32).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('magnitude', [1e-6, 3.0, 40.0, 3000.0])
+def test_rnn_fwd_f16_scales_its_weights_itself(hip, magnitude):
+    """No assumption about the size of W_hh: every workgroup scales its slice by the power of
+    two that puts the slice's largest magnitude below fp16's range.  One unit's weights are
+    `magnitude` times livelier than the rest (a weight of 40 or 3000 would be inf in fp16 under
+    any fixed scale that keeps the precision of the others)."""
+    num_steps, batch, hidden = 6, 16, 1024
+    g = torch.Generator(device=DEV).manual_seed(32)
+    xw = torch.randn(num_steps, batch, 2, 4 * hidden, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, 4 * hidden, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    w_hh[:, 5] *= magnitude
+    w_hh[:, 2 * hidden + 77, 3] = magnitude
+    ref = _recurrence_float64('lstm', xw, w_hh, None, None)
+    y16, _, ws = hip.rnn_fwd('lstm', xw, w_hh, flags=hip.RNN_F16)
+    y32, _, _ = hip.rnn_fwd('lstm', xw, w_hh)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    assert torch.isfinite(y16).all()
+    err16 = float((y16.double() - ref).abs().max())
+    err32 = float((y32.double() - ref).abs().max())
+    assert err16 < 3 * err32 + 2e-6, (magnitude, err16, err32)
+
+
 @pytest.mark.parametrize('cell,dims', [('lstm', (12, 16, 1024)), ('lstm', (9, 32, 1024)),
                                        ('rnn_relu', (8, 16, 2048))])
 def test_streaming_kernels_on_persistent_shapes(hip, cell, dims, monkeypatch):

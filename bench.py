@@ -87,8 +87,10 @@ def dtype_label(model):
                 'bf16x6 split (24 bits) elsewhere'.format(
                     'forward projections and their gradient GEMMs' if model.bwd_f16
                     else 'forward projections')
-    rec = '; forward recurrence h x W_hh as fp16x3 split, fp32 accumulate' \
-        if getattr(model, 'rnn_fwd_f16', False) else ''
+    which = [name for name, on in (('forward', model.rnn_fwd_f16), ('backward', model.rnn_bwd_f16))
+             if on]
+    rec = '; {} recurrence (h x W_hh / dgates x W_hh) as fp16x3 split, fp32 accumulate'.format(
+        ' and '.join(which)) if which else ''
     return 'f32 tensors / accumulate / own kernels; projection GEMMs: ' + gemms + rec
 
 
@@ -114,7 +116,7 @@ def forward_flops_per_utt(cfg, frames):
 
 
 def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f16=True,
-               bwd_f16=True):
+               bwd_f16=True, rec_f16=(False, False)):
     """Time one step would take with every FLOP at the peak of the pipe it runs on: the fp32
     matrix pipe (157.3 TF) for the own kernels; for the split GEMMs the 16-bit matrix pipe
     (2500 TF) divided by the products per fp32 product - three fp16 products where the layer's
@@ -133,17 +135,23 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
         three = (split - rec) / 3.0                       # the forward products
         if bwd_f16:
             three = split - 2.0 * dense4                  # + every gradient GEMM but dense4's
+    # the recurrences' own products (h W_hh^T forward, dgates W_hh backward: `rec` each) leave the
+    # fp32 pipe for three fp16 products where the fp16-pipe persistent kernels run them
+    rec16 = rec * sum(1 for on in rec_f16 if on) if cfg.cell == 'lstm' else 0.0
+    fp32 -= rec16
     roof_ms = utterances / world * (
-        three * 3.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+        (three + rec16) * 3.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
         (split - three) * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
         fp32 / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * 1e3
     return {'ms_per_step_at_peak': round(roof_ms, 3), 'frac': round(roof_ms / ms_per_step, 4),
             'fp32_equiv_tflop_split_gemms': round(utterances / world * split / 1e12, 3),
             'of_which_fp16x3': round(utterances / world * three / 1e12, 3),
+            'tflop_recurrences_fp16x3': round(utterances / world * rec16 / 1e12, 3),
             'tflop_fp32_pipe': round(utterances / world * fp32 / 1e12, 3),
             'note': 'per GPU; split GEMMs priced at 2500 TF / 3 (fp16 pieces: bounded layer inputs, '
-                    'their gradient GEMMs with per-column / per-row scales of dxw) and 2500 TF / 6 '
-                    '(bf16 pieces), own kernels at 157.3 TF'}
+                    'their gradient GEMMs with per-column / per-row scales of dxw; the recurrences\' '
+                    'own products where the fp16-pipe kernels run) and 2500 TF / 6 (bf16 pieces), '
+                    'the other own kernels at 157.3 TF'}
 
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
@@ -436,13 +444,34 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                 # fwd_chunks); a launch then covers T' / chunks time steps
                 launch_steps = t_out * args.steps * cfg.num_layers_rnn / float(calls)
                 achieved = flops_per_step * launch_steps / avg_s / 1e12
+                # which matrix pipe the kernel's product runs on: fp32 MFMA, or - the fp16-pipe
+                # kernels - three fp16 products per fp32 product (peak 2500 / 3 fp32-equivalent)
+                f16_kernel = model.arithmetic().get(
+                    'rnn0/recurrence_{}'.format(dom[4:])) == 'fp16x3'
+                peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if f16_kernel else FP32_MFMA_PEAK_TFLOPS
                 roofline = {
-                    'kernel': 'prnn_{}_kernel<{}> (persistent, LDS-resident recurrent weights; '
+                    'kernel': 'prnn_{}{}_kernel<{}> (persistent, LDS-resident recurrent weights; '
                               'one launch = {:.0f} time steps x 2 directions, batch {})'.format(
-                                  dom[4:], rnn_cell.upper(), launch_steps, batch),
+                                  dom[4:], '16' if f16_kernel else '', rnn_cell.upper(),
+                                  launch_steps, batch),
                     'bound': 'mfma', 'achieved': round(achieved, 2),
-                    'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
+                    'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(achieved / peak, 4),
+                    'pipe': 'fp16 MFMA, 3 piece products per fp32 product (peak = 2500 / 3 '
+                            'fp32-equivalent TFLOP/s)' if f16_kernel else 'fp32 MFMA',
+                    'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
+                if dom == 'rnn_bwd':
+                    # what actually bounds the all-gather backward recurrence: every workgroup
+                    # pulls the dgates of ALL 4H gate columns of its rows through its CU's load
+                    # path every step: bytes per CU and time step, and the rate
+                    rows_per_cu = batch if not args.rnn_bwd_whole_chip else min(batch, 16)
+                    per_cu = rows_per_cu * gates * hidden * 4.0
+                    roofline['exchange_load_path'] = {
+                        'bytes_per_cu_per_time_step': per_cu,
+                        'gb_per_s_per_cu': round(per_cu * launch_steps / avg_s / 1e9, 1),
+                        'note': 'all-gather of dgates: B x 4H x 4 bytes per workgroup and step '
+                                'whatever the decomposition; a CU sustains ~100 - 125 GB/s on '
+                                'freshly written cross-XCD data (L1 path peak 64 B/clk = 150)'}
                 roofline.update(pmc_traffic(name, dom, round(launch_steps)))
                 # the H=1024 backward kernel runs on half the chip by default: the weight-gradient
                 # GEMMs of the steps it has finished fill the other 128 CUs
@@ -506,7 +535,9 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                                   'the device)' if model.bwd_f16 else '') if model.fwd_f16 else ''))
                          if model.split_gemm else 'fp32 library GEMMs (CTCASR_SPLIT_GEMM=0)',
             'roof': mixed_roof(cfg, frames, batch * world, ms_per_step, model.split_gemm, world,
-                               model.fwd_f16, model.bwd_f16),
+                               model.fwd_f16, model.bwd_f16,
+                               (model.arithmetic().get('rnn0/recurrence_fwd') == 'fp16x3',
+                                model.arithmetic().get('rnn0/recurrence_bwd') == 'fp16x3')),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),
@@ -732,8 +763,8 @@ PROBE_BATCH, PROBE_FRAMES, PROBE_LABEL_LEN = 4, 199, 30        # T' = 100
 # which GEMM arithmetic a probe variant runs: attributes of CTCModel
 PROBE_VARIANTS = (
     ('default', {}),
-    ('bf16x6', {'fwd_f16': False, 'bwd_f16': False, 'rnn_fwd_f16': False}),
-    ('fp32_library_gemms', {'split_gemm': False, 'rnn_fwd_f16': False}),
+    ('bf16x6', {'fwd_f16': False, 'bwd_f16': False, 'rnn_fwd_f16': False, 'rnn_bwd_f16': False}),
+    ('fp32_library_gemms', {'split_gemm': False, 'rnn_fwd_f16': False, 'rnn_bwd_f16': False}),
 )
 
 

@@ -97,7 +97,9 @@ struct PArgs {
     int chain0;            // first batch tile of this launch
     int s_lo, s_hi;        // backward: this launch runs steps s_hi-1 ... s_lo (a whole pass: 0, T)
     float *carry;          // backward, LSTM: dc [2, B, H] handed from one launch to the next
-    float *rs;             // backward, reduce-scatter form: the exchange ring (prnn_rs_ring_bytes)
+    float *rs;             // backward, reduce-scatter form: the exchange ring (prnn_rs_ring_bytes);
+                           // fp16 form: the inverse scales (prnn_b16_scale_bytes)
+    unsigned *colmax;      // backward, fp16 form (optional): [2][G * H] maxima of |dxw| (bit patterns)
     int prof;              // record phase timings of workgroup 0
     unsigned ticket;       // != 0: post it once every workgroup of this launch is running
 };
@@ -722,17 +724,16 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
 // v_mfma_f32_16x16x32_f16 (dropped: h2 w2 <= 2^-22 |h w|; the same form as the forward projection
 // GEMMs) - 3 MFMAs of K = 32 where the fp32 kernel issues 8 of K = 4.
 // Nothing else changes size: W_hh as two fp16 pieces is the 4 bytes per weight of the fp32 slice
-// (same LDS / register split), and h is PUBLISHED as its two pieces - the 16-byte granule that
-// carried 4 floats of 4 consecutive units now carries their 4 first pieces and 4 second pieces -
-// so the exchange moves the same bytes and the consumer needs no conversion: the granules of two
-// 16-unit chunks are, register for register, the A fragments (first pieces: dwords x, y of both
-// granules; second pieces: z, w) of one K = 32 step.
+// (same LDS / register split), and h is PUBLISHED as its two pieces - per 32 units one 1 KB block
+// of first pieces and one of second pieces, [k group of 8 units][b][8 halves], where the fp32
+// kernel has two blocks of 16 units - so the exchange moves the same bytes, and a lane's 16-byte
+// load from a block IS the A-fragment register quadruple of a K = 32 MFMA: no conversion and no
+// re-arranging at the consumer.
 //   scale of h: 2^15 (|h| <= 1); scale of W_hh: per workgroup, found while staging - the largest
 //   magnitude of the slice lands in [2^14, 2^15) - so no weight can overflow whatever its size
 //   (a per-workgroup scale is a per-output-column scale: it leaves through the accumulator).
-// K chunk c of wave w (32 units) = exchange chunks 2c, 2c + 1 of the wave's range; lane l of a
-// fragment holds units 4 (l >> 4) + e (e < 4) of the first and + e - 4 of the second chunk - A and
-// B use the same map, which is all an MFMA needs.
+// K chunk c of wave w = 32 units; lane l of a fragment holds units 8 (l >> 4) + e of it, for A
+// and B alike.
 // B-fragment slots per wave: (c * NT + nt) * 2 + piece; the last REGW of them live in registers.
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -750,6 +751,28 @@ __device__ __forceinline__ unsigned f16_pieces(float s) {
 }
 __device__ __forceinline__ u32x4 load16u(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+}
+// per-lane offset + wave-uniform offset (an SGPR: no address arithmetic or register per load)
+__device__ __forceinline__ u32x4 load16u(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
+                                         unsigned uniform_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)uniform_off, 0);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// q = f16_pieces() of this lane's value; in the first lane of every group of 8 (lanes of 8
+// consecutive units): the 8 first pieces and the 8 second pieces of the group as two 16-byte
+// granules - each one IS the fragment register quadruple of an MFMA operand (lane l of a K = 32
+// step holds 8 consecutive k), so the consumer loads operands, not data to re-arrange
+__device__ __forceinline__ void gather8_pieces(unsigned q0, u32x4 &first, u32x4 &second) {
+    const unsigned q1 = dpp_u32<0x101>(q0), q2 = dpp_u32<0x102>(q0), q3 = dpp_u32<0x103>(q0),
+                   q4 = dpp_u32<0x104>(q0), q5 = dpp_u32<0x105>(q0), q6 = dpp_u32<0x106>(q0),
+                   q7 = dpp_u32<0x107>(q0);                       // row_shl: lane i <- lane i + n
+    first = (u32x4){(q0 & 0xFFFFu) | (q1 << 16), (q2 & 0xFFFFu) | (q3 << 16),
+                    (q4 & 0xFFFFu) | (q5 << 16), (q6 & 0xFFFFu) | (q7 << 16)};
+    second = (u32x4){(q0 >> 16) | (q1 & 0xFFFF0000u), (q2 >> 16) | (q3 & 0xFFFF0000u),
+                     (q4 >> 16) | (q5 & 0xFFFF0000u), (q6 >> 16) | (q7 & 0xFFFF0000u)};
 }
 
 template <int CELL, int NT, int KC, int REGW = 0>
@@ -788,8 +811,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
             return;
         }
         const float *wrow = p.w + ((size_t)dir * GR * H + (col / UPB) * H + u0 + (col % UPB)) * H +
-                            wave * (H / 4) + 32 * c + 4 * (lane >> 4);
-        const float4 lo = ldg4(wrow), hi = ldg4(wrow + 16);
+                            wave * (H / 4) + 32 * c + 8 * (lane >> 4);
+        const float4 lo = ldg4(wrow), hi = ldg4(wrow + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
         v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     };
@@ -840,8 +863,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
     }
     __syncthreads();
 
-    // exchange buffer: the layout of prnn_fwd_kernel, every 16-byte granule = the first pieces of
-    // 4 consecutive units (8 bytes) followed by their second pieces; the all-zero block in front
+    // exchange buffer: [step][dir][32-unit chunk][piece][k group of 8 units][b][8 halves] behind
+    // the all-zero block (the size of prnn_fwd_kernel's)
     const size_t x_base = (size_t)2 * B * GR * H;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         p.xchg, 0, (int)((x_base + (size_t)T * 2 * B * H) * sizeof(float)), 0x00020000);
@@ -916,8 +939,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 Frag16 h1, h2;
-                h1.u = (u32x4){a[c][0].x, a[c][0].y, a[c][1].x, a[c][1].y};
-                h2.u = (u32x4){a[c][0].z, a[c][0].w, a[c][1].z, a[c][1].w};
+                h1.u = a[c][0];
+                h2.u = a[c][1];
                 Frag16 w1[NT], w2[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -983,20 +1006,19 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
                 rsv[0] = gr_; rsv[1] = gz; rsv[2] = gn; rsv[3] = q;
             }
         }
-        // publish h as its two fp16 pieces: lanes of 4 consecutive units gather into one 16-byte
-        // sc1 store (first pieces, then second pieces)
-        const unsigned q0 = f16_pieces(hv * PRNN_F16_H_SCALE);
-        const unsigned q1 = __shfl_down(q0, 1, 64), q2 = __shfl_down(q0, 2, 64),
-                       q3 = __shfl_down(q0, 3, 64);
-        if (it_t >= 0 && (tid & 3) == 0) {
-            const u32x4 v = {(q0 & 0xFFFFu) | (q1 << 16), (q2 & 0xFFFFu) | (q3 << 16),
-                             (q0 >> 16) | (q1 & 0xFFFF0000u), (q2 >> 16) | (q3 & 0xFFFF0000u)};
-            __builtin_amdgcn_raw_buffer_store_b128(
-                v, x_rsrc,
-                (int)(unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * H +
-                                 (size_t)(unit >> 4) * B * 16 + (size_t)((unit & 15) >> 2) * B * 4 +
-                                 (size_t)brow * 4) * sizeof(float)),
-                0, 16);
+        // publish h as its two fp16 pieces: the lanes of 8 consecutive units gather into two
+        // 16-byte sc1 stores (a granule of first pieces, one of second pieces)
+        u32x4 first, second;
+        gather8_pieces(f16_pieces(hv * PRNN_F16_H_SCALE), first, second);
+        if (it_t >= 0 && (tid & 7) == 0) {
+            const unsigned off =
+                (unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * H +
+                            (size_t)(unit >> 5) * B * 32 + (size_t)((unit & 31) >> 3) * B * 4 +
+                            (size_t)brow * 4) * sizeof(float));
+            __builtin_amdgcn_raw_buffer_store_b128(first, x_rsrc, (int)off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(second, x_rsrc,
+                                                   (int)(off + (unsigned)(B * 16 * sizeof(float))),
+                                                   0, 16);
         }
         if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
         if (s + 1 < p.s_hi) {
@@ -1688,6 +1710,438 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward on the fp16 matrix pipe (round 4; LSTM, H = 1024, `flags` bit CTCASR_RNN_F16).
+//
+// prnn_bwd_kernel delivers its A operand - the dgates of ALL 4H gate columns, 256 KB per 16-row
+// tile and step - at ~50 GB/s per CU: with 128 registers of weights, fp32 fragments and two chains
+// per workgroup only 4 - 16 KB per wave are in flight against ~1 us of latency, and 3.4 us of fp32
+// MFMA issue per tile hide behind nothing else.  Here:
+//   * dgates x R on v_mfma_f32_16x16x32_f16, two fp16 pieces per operand, three products, fp32
+//     accumulation - 96 MFMAs of ~16 cycles per wave, tile and step instead of 256 of 32.
+//     R is bounded (per workgroup: the slice's largest magnitude, found while staging, like
+//     prnn_fwd16_kernel).  dgates are NOT - a step holds 1e-13 .. 1e-3 - but a sum over K only
+//     needs a common scale per ROW AND K BLOCK when the blocks are accumulated apart: every
+//     producer (16 units x 4 gates = 64 columns) scales each of its 16 rows by the power of two
+//     that puts THAT row's largest of its 64 values into [2^13, 2^14), publishes the two fp16
+//     pieces in the 4 bytes per element the fp32 exchange carried, plus 16 inverse scales; the
+//     consumer multiplies a producer's 64 columns into a fresh accumulator (6 MFMAs) and adds
+//     accumulator x inverse scale to its fp32 total.  22 significand bits relative to a
+//     (producer, row) maximum that is never above the row's: finer than one scale per row.
+//   * ONE chain of 4 waves (512 registers each) for one or two 16-row tiles (MT): the weights'
+//     register half is held once, both tiles share every B fragment, and up to 64 KB per wave of
+//     A granules are in flight (a ring of D producers x MT tiles x 4 chunks, refilled as it is
+//     consumed) - the step is wait + the time the CU's load path needs for the bytes.
+// Exchange, in the bytes of prnn_bwd_kernel's: [step][dir][producer P][gate pair m][piece]
+// [k group][b][8 halves] - k group q of (P, m) = units 8 (q & 1) .. + 7 of gate 2 m + (q >> 1) -
+// so a lane's 16-byte load is the A-fragment register quadruple of a K = 32 MFMA; behind the
+// reduce-scatter ring the inverse scales [step][dir][producer][32 rows].  B-fragment slot
+// (P * 2 + m) * 2 + piece, the first QL of a wave in LDS.
+// Also accumulates, besides the bias gradients, the per-column maxima of |dxw| over the launch's
+// steps (`colmax`, bit patterns, atomicMax): what ctcasr_colmax_scale would find in a pass over
+// the finished rows of dxw.
+// ---------------------------------------------------------------------------------------------
+// maximum over the 16 lanes of a DPP row (quad swaps, then the mirrored half and row)
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(dpp_u32<0x141>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(dpp_u32<0x140>(__float_as_uint(v))));
+    return v;
+}
+#define PRNN_B16_SCALE_ROWS 32          // rows per producer in the inverse-scale blocks
+#ifndef PRNN_B16_D1
+#define PRNN_B16_D1 14                  // ring depth, one tile on 4 waves
+#endif
+#ifndef PRNN_B16_NW2
+#define PRNN_B16_NW2 4                  // waves for two tiles behind one barrier (4 or 8)
+#endif
+#ifndef PRNN_B16_D2
+#define PRNN_B16_D2 5                   // ring depth, two tiles
+#endif
+__host__ __device__ inline size_t prnn_b16_scale_bytes(int T) {
+    return (size_t)(T + 1) * 2 * (PRNN_RS_H / 16) * PRNN_B16_SCALE_ROWS * sizeof(float);
+}
+
+// MT batch tiles of 16 rows behind one barrier, NW waves (the K axis - 64 producers - is split
+// over them), a ring of D producers' A granules in flight per wave.
+//   MT = 1, NW = 4: 512 registers per wave, D = 10 (40 KB per wave in flight)
+//   MT = 2, NW = 8: two waves per SIMD hide each other's LDS / VALU latencies, nothing is held
+//                   twice (a wave's 8 producers: 16 B-fragment slots in LDS, 16 in 64 registers),
+//                   one item per thread
+template <int MT, int NW, int D>
+__global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
+    constexpr int H = PRNN_RS_H, GH = 4 * H;
+    constexpr int NTH = 64 * NW;            // threads
+    constexpr int NPW = H / 16 / NW;        // producers per wave (the K split)
+    constexpr int QS = NPW * 4;             // B-fragment slots per wave: (producer, half, piece)
+    constexpr int QL = QS / 2, REGW = QS - QL;
+    constexpr int RED_FLOATS = NW * MT * 16 * 17;
+    constexpr int ITEMS = (MT * 256 + NTH - 1) / NTH;
+    constexpr int DD = D < NPW ? D : NPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 64 * sizeof(u32x4));
+    constexpr int IVL = 4 * NPW;            // float4 slots of a wave's inverse scales per tile
+    float4 *invs = reinterpret_cast<float4 *>(red + RED_FLOATS);      // [NW waves][MT][IVL]
+    float *wave_top = reinterpret_cast<float *>(invs + NW * MT * IVL);
+
+    const int chain = p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
+    const int row0 = chain * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: scalar offsets)
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int B = p.B, T = p.T, BS = p.BS;
+    const int u0 = slice * 16;
+
+    // ---- this workgroup's 16 columns of R^T as scaled fp16 pieces, in fragment order -----------
+    // K chunk (producer P, half m) = units 8 m .. 8 m + 7 of P, all four gates: lane l of a
+    // fragment (k group q = l >> 4) holds element e = 4 (unit & 1) + gate of units 8 m + 2 q,
+    // 8 m + 2 q + 1 - the 8 values two neighbouring producer threads have in registers
+    float w_scale;
+    {
+        // largest magnitude of the slice (any order: whole rows of w_hh_t, 16-byte loads)
+        float m = 0.f;
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 15)) * GH;
+        for (int n = (tid >> 4) * 4; n < GH; n += NTH / 16 * 4) {
+            const float4 v = ldg4(wrow + n);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        if (lane == 0) wave_top[wave] = m;
+        __syncthreads();
+        m = wave_top[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, wave_top[w]);
+        const unsigned bits = __float_as_uint(m);
+        const int e = (int)((bits >> 23) & 0xFF) - 127;
+        const int se = bits == 0u ? 0 : min(max(14 - e, -60), 60);
+        w_scale = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+    const float out_scale = 1.0f / w_scale;
+    u32x4 wreg[REGW];
+    {
+        auto pieces = [&](int pm, u32x4 &first, u32x4 &second) {
+            const float *wcol = p.w + ((size_t)dir * H + u0 + (lane & 15)) * GH +
+                                16 * (wave * NPW + (pm >> 1)) + 8 * (pm & 1) + 2 * (lane >> 4);
+            unsigned q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                q[e] = f16_pieces(wcol[(size_t)(e & 3) * H + (e >> 2)] * w_scale);
+            first = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                            (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+            second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                             (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+        };
+        for (int pm = 0; pm < QL / 2; ++pm) {
+            u32x4 first, second;
+            pieces(pm, first, second);
+            frag[(wave * QL + 2 * pm) * 64 + lane] = first;
+            frag[(wave * QL + 2 * pm + 1) * 64 + lane] = second;
+        }
+#pragma unroll
+        for (int pm = 0; pm < REGW / 2; ++pm) pieces(QL / 2 + pm, wreg[2 * pm], wreg[2 * pm + 1]);
+    }
+    __syncthreads();
+
+    // exchange: [step][dir][producer][half][piece][k group][b][16 B] behind an all-zero block;
+    // inverse scales [step][dir][producer][32 rows] (zero-filled once: rows nobody writes read 0)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * GH;
+    const size_t x_base = x_step;
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.rs, 0, (int)prnn_b16_scale_bytes(T), 0x00020000);
+    constexpr unsigned S_STEP = 2u * (H / 16) * PRNN_B16_SCALE_ROWS * sizeof(float);
+    // the per-item tensors through buffer descriptors: scalar base + one 32-bit offset per lane
+    // (64-bit per-lane pointers cost two registers each and their arithmetic)
+    const int rnum = 0x7FFFFFFF;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.dy), 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cells, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dxw, 0, rnum, 0x00020000);
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    };
+
+    // ---- items: item = tid + it * NTH -> tile item >> 8, row (item >> 4) & 15, unit item & 15 ---
+    const int iu = tid & 15, unit = u0 + iu;
+    int steps[ITEMS], brow[ITEMS];
+    float dc_state[ITEMS], dbs[ITEMS][4], cmx[ITEMS][4];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = tid + it * NTH;
+        brow[it] = row0 + (item >> 4);
+        const bool has = item < MT * 256 && brow[it] < B;
+        steps[it] = has ? row_steps(p.seq_len, brow[it], T) : 0;
+        dc_state[it] = 0.f;
+        if (p.s_hi < T && has) dc_state[it] = p.carry[((size_t)dir * B + brow[it]) * H + unit];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbs[it][g] = cmx[it][g] = 0.f;
+    }
+    int a_steps[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int arow = row0 + t * 16 + (lane & 15);
+        a_steps[t] = arow < B ? row_steps(p.seq_len, arow, T) : 0;
+    }
+
+    unsigned long long pt[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0 && threadIdx.x == 0;
+    for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
+        // everything the cell derivative needs except dh_rec: requested before the barrier
+        float dyv[ITEMS], gi[ITEMS], gf[ITEMS], gg[ITEMS], go[ITEMS], cv[ITEMS], cpv[ITEMS];
+        int it_t[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            it_t[it] = -1;
+            dyv[it] = gi[it] = gf[it] = gg[it] = go[it] = cv[it] = cpv[it] = 0.f;
+            if (s < steps[it]) {
+                const int t = row_time(dir, s, steps[it]);
+                it_t[it] = t;
+                // element index of (t, row, dir, unit) in a [T, BS, 2, H] tensor
+                const unsigned e0 = (unsigned)(((t * BS + brow[it]) * 2 + dir) * H + unit);
+                dyv[it] = ldf(dy_rsrc, e0 * 4u);
+                gi[it] = ldf(g_rsrc, (e0 * 4u - 3u * unit) * 4u);
+                gf[it] = ldf(g_rsrc, (e0 * 4u - 3u * unit + H) * 4u);
+                gg[it] = ldf(g_rsrc, (e0 * 4u - 3u * unit + 2 * H) * 4u);
+                go[it] = ldf(g_rsrc, (e0 * 4u - 3u * unit + 3 * H) * 4u);
+                cv[it] = ldf(c_rsrc, e0 * 4u);
+                if (s > 0)
+                    cpv[it] = ldf(c_rsrc, (unsigned)(((row_time(dir, s - 1, steps[it]) * BS +
+                                                       brow[it]) * 2 + dir) * H + unit) * 4u);
+            }
+        }
+
+        f32x4 total[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) total[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        if (s < T - 1) {
+            if (s < p.s_hi - 1) {
+                dir_wait<1>(p.sync, nullptr, dir, chain, group_size, (unsigned)(p.s_hi - 2 - s),
+                            tid);
+                if (s == p.s_lo && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
+            // inverse scales of the wave's producers (1 KB per tile covers 16 of them), lane-linear
+            float4 iv[MT];
+            unsigned aoff[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                iv[t] = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
+                                               (unsigned)(((dir * (H / 16) + wave * NPW + (lane >> 2)) *
+                                                           PRNN_B16_SCALE_ROWS + row0 + t * 16 +
+                                                           4 * (lane & 3)) * sizeof(float)));
+                const int row = row0 + t * 16 + (lane & 15);
+                const bool ok = s + 1 < a_steps[t];       // otherwise: the all-zero block
+                aoff[t] = (unsigned)(((ok ? x_base + (size_t)(s + 1) * x_step : 0) +
+                                      (size_t)dir * B * GH + (size_t)(lane >> 4) * B * 4 +
+                                      (size_t)(ok ? row : 0) * 4) * sizeof(float));
+            }
+            u32x4 a[DD][MT][4];
+            auto issue = [&](int P, u32x4 (&dst)[MT][4]) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)       // g = half * 2 + piece
+                        dst[t][g] = load16u(x_rsrc, aoff[t],
+                                            (unsigned)(((wave * NPW + P) * 4 + g) * B * 16 *
+                                                       sizeof(float)));
+            };
+#pragma unroll
+            for (int P = 0; P < DD; ++P) issue(P, a[P]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                if (lane < IVL) invs[(wave * MT + t) * IVL + lane] = iv[t];
+            auto bfrag = [&](int sl) -> u32x4 {      // compile-time slot after unrolling
+                return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+            };
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < NPW; ++P) {
+                u32x4 (&ap)[MT][4] = a[P % DD];
+                // the six products of a producer's 64 columns: ONE fresh accumulator per tile when
+                // two tiles alternate on the matrix pipe (a dependent MFMA is two issues away),
+                // two - first-piece products / the two small terms - for a single tile
+                constexpr int NA = MT == 1 ? 2 : 1;
+                f32x4 acc[MT][NA];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    Frag16 w1, w2;
+                    w1.u = bfrag((P * 2 + m) * 2);
+                    w2.u = bfrag((P * 2 + m) * 2 + 1);
+                    Frag16 d1[MT], d2[MT];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        d1[t].u = ap[t][2 * m];
+                        d2[t].u = ap[t][2 * m + 1];
+                    }
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            d1[t].h, w1.h, m == 0 ? zero : acc[t][0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t][NA - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            d1[t].h, w2.h, (m == 0 && NA == 2) ? zero : acc[t][NA - 1], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t][NA - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            d2[t].h, w1.h, acc[t][NA - 1], 0, 0, 0);
+                }
+                if (P + DD < NPW) issue(P + DD, a[P % DD]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float4 ivp = invs[(wave * MT + t) * IVL + 4 * P + (lane >> 4)];
+                    f32x4 sum = acc[t][0];
+                    if constexpr (NA == 2) sum += acc[t][1];
+                    total[t][0] += sum[0] * ivp.x;
+                    total[t][1] += sum[1] * ivp.y;
+                    total[t][2] += sum[2] * ivp.z;
+                    total[t][3] += sum[3] * ivp.w;
+                }
+                // (one producer at a time: left alone the scheduler hoists the LDS reads of many
+                // producers above the MFMAs of the first and runs out of registers)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (prof) {
+            asm volatile("" ::"v"(total[0][0]));
+            unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((wave * MT + t) * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] =
+                    total[t][r] * out_scale;
+        __syncthreads();
+
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = tid + it * NTH;
+            const int tile = item >> 8, ib = (item >> 4) & 15;
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (it_t[it] >= 0) {
+                float dh = dyv[it];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) dh += red[((w * MT + tile) * 16 + ib) * 17 + iu];
+                const float tc = tanhf_(cv[it]);
+                const float dc = dc_state[it] + dh * go[it] * (1.f - tc * tc);
+                dg[0] = dc * gg[it] * gi[it] * (1.f - gi[it]);
+                dg[1] = dc * cpv[it] * gf[it] * (1.f - gf[it]);
+                dg[2] = dc * gi[it] * (1.f - gg[it] * gg[it]);
+                dg[3] = dh * tc * go[it] * (1.f - go[it]);
+                dc_state[it] = dc * gf[it];
+            }
+            if (ITEMS * NTH > MT * 256 && item >= MT * 256) continue;     // (wave-uniform)
+            // the row's scale over this workgroup's 64 values; two fp16 pieces of every value
+            float mx = fmaxf(fmaxf(fabsf(dg[0]), fabsf(dg[1])), fmaxf(fabsf(dg[2]), fabsf(dg[3])));
+            mx = row16_max(mx);
+            const unsigned mbits = __float_as_uint(mx);
+            const int me = (int)((mbits >> 23) & 0xFF) - 127;
+            const int mse = mbits == 0u ? 0 : min(max(13 - me, -100), 100);
+            const float rscale = __uint_as_float((unsigned)(mse + 127) << 23);
+            const float rinv = __uint_as_float((unsigned)(127 - mse) << 23);
+            // this thread's 4 gates and its neighbour unit's: one granule of first pieces (stored
+            // by the even lane), one of second pieces (by the odd lane)
+            unsigned q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) q[g] = f16_pieces(dg[g] * rscale);
+            // mine: the piece this lane stores (even: first, odd: second) of my own 4 gates;
+            // theirs: the piece the NEIGHBOUR stores, handed over by a lane swap
+            const bool odd = (tid & 1) != 0;
+            const unsigned f01 = (q[0] & 0xFFFFu) | (q[1] << 16), f23 = (q[2] & 0xFFFFu) | (q[3] << 16);
+            const unsigned s01 = (q[0] >> 16) | (q[1] & 0xFFFF0000u),
+                           s23 = (q[2] >> 16) | (q[3] & 0xFFFF0000u);
+            const unsigned give01 = odd ? f01 : s01, give23 = odd ? f23 : s23;
+            const unsigned got01 = dpp_u32<0xB1>(give01), got23 = dpp_u32<0xB1>(give23);   // lane ^ 1
+            // element order of a granule: e = 4 (unit & 1) + gate
+            const u32x4 v = odd ? (u32x4){got01, got23, s01, s23} : (u32x4){f01, f23, got01, got23};
+            if (it_t[it] >= 0) {
+                // block (producer, half = unit >> 3, piece), k group (unit >> 1) & 3
+                const unsigned off = (unsigned)(
+                    (x_base + (size_t)s * x_step + (size_t)dir * B * GH +
+                     (size_t)((slice * 2 + (iu >> 3)) * 2 + (odd ? 1 : 0)) * B * 16 +
+                     (size_t)((iu >> 1) & 3) * B * 4 + (size_t)brow[it] * 4) * sizeof(float));
+                __builtin_amdgcn_raw_buffer_store_b128(v, x_rsrc, (int)off, 0, 16);
+            }
+            // the four rows of this wave: one 16-byte store of their inverse scales
+            const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 0));
+            const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 16));
+            const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 32));
+            const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 48));
+            if (lane == 0)
+                store16_sc1(s_rsrc,
+                            (unsigned)s * S_STEP +
+                                (unsigned)(((dir * (H / 16) + slice) * PRNN_B16_SCALE_ROWS + row0 +
+                                            (item >> 4)) * sizeof(float)),
+                            r0, r1, r2, r3);
+            if (it_t[it] >= 0) {      // dxw in its GEMM layout: read after the launch only
+                const unsigned dx0 = (unsigned)(((it_t[it] * BS + brow[it]) * 2 + dir) * GH + unit) * 4u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg[g]), dx_rsrc,
+                                                          (int)(dx0 + (unsigned)g * H * 4u), 0, 0);
+                    dbs[it][g] += dg[g];
+                    cmx[it][g] = fmaxf(cmx[it][g], fabsf(dg[g]));
+                }
+            }
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
+        if (s > p.s_lo) {
+            unsigned unused = 0;
+            dir_arrive<1>(p.sync, nullptr, dir, chain, grp, tid, unused);
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if (p.s_lo > 0) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = tid + it * NTH;
+            if (item < MT * 256 && brow[it] < B)
+                p.carry[((size_t)dir * B + brow[it]) * H + unit] = dc_state[it];
+        }
+    }
+    if (p.dbias || p.colmax) {
+        // sums / maxima over the rows of the tile(s) through LDS, then one atomic per column: the
+        // other batch tile / block of rows / launch of the pass meets it at the same word
+        float *sums = red, *tops = reinterpret_cast<float *>(frag);     // (the weights are done with)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NTH;
+                if (item < MT * 256) {
+                    sums[item] = dbs[it][g];
+                    tops[item] = cmx[it][g];
+                }
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float sum = 0.f, top = 0.f;
+                for (int r = 0; r < 16 * MT; ++r) {
+                    sum += sums[r * 16 + tid];
+                    top = fmaxf(top, tops[r * 16 + tid]);
+                }
+                if (p.dbias) atomicAdd(p.dbias + ((size_t)dir * 4 + g) * H + u0 + tid, sum);
+                if (p.colmax)
+                    atomicMax(p.colmax + ((size_t)dir * 4 + g) * H + u0 + tid, __float_as_uint(top));
+            }
+        }
+    }
+    if (prof)
+        for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+}
+
 int device_cu_count() {
     static int cus = -1;
     if (cus < 0) {
@@ -1796,9 +2250,10 @@ static size_t prnn_step_exchange_bytes(int T, int B, int H, int G) {
     return ctcasr_align_up((size_t)(T + 1) * 2 * B * G * H * sizeof(float), 256);
 }
 // the per-step blocks, then (LSTM, H = 1024) the ring of the reduce-scatter backward kernel
+// ... and the inverse scales of the fp16 backward kernel
 size_t prnn_exchange_bytes(int T, int B, int H, int G) {
     return prnn_step_exchange_bytes(T, B, H, G) +
-           (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() : 0);
+           (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() + prnn_b16_scale_bytes(T) : 0);
 }
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
@@ -1916,8 +2371,8 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
 
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
-             const float *cells, float *dxw, float *drec, float *dbias, void *sync,
-             float *carry, int step_begin, int step_end, int flags, hipStream_t s) {
+             const float *cells, float *dxw, float *drec, float *dbias, unsigned *colmax,
+             void *sync, float *carry, int step_begin, int step_end, int flags, hipStream_t s) {
     PArgs p = {};
     p.dbias = dbias;
     p.s_lo = step_begin; p.s_hi = step_end; p.carry = carry;
@@ -1989,6 +2444,23 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                 if (rc != CTCASR_OK) return rc;
             }
         return CTCASR_OK;
+    }
+    if (cell == CTCASR_CELL_LSTM && H == PRNN_RS_H && (flags & CTCASR_RNN_F16)) {
+        // fp16 matrix pipe: 64 workgroups per direction, ONE chain of 4 waves; B > 16 on half of
+        // the chip: both 16-row tiles in every workgroup (one barrier); on the whole chip: each
+        // tile as its own group of workgroups
+        p.nwg = PRNN_RS_NWG;
+        p.colmax = colmax;
+        p.rs = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xchg) +
+                                         prnn_step_exchange_bytes(T, B, H, 4) +
+                                         prnn_rs_ring_bytes());
+        auto lds = [](int tiles, int waves) {
+            return (size_t)128 * 1024 + (size_t)waves * tiles * 16 * 17 * 4 +
+                   (size_t)tiles * 256 * 16 + 64;      // (inverse scales: 4 float4 per producer)
+        };
+        if (mt == 2 && half_chip)
+            return launch_persistent(prnn_bwd16_kernel<2, PRNN_B16_NW2, PRNN_B16_D2>, p, lds(2, PRNN_B16_NW2), s, PRNN_B16_NW2 / 4);
+        return launch_persistent(prnn_bwd16_kernel<1, 4, PRNN_B16_D1>, p, lds(1, 4), s, 1, mt);
     }
     if (cell == CTCASR_CELL_LSTM && H == PRNN_RS_H && (flags & CTCASR_RNN_REDUCE_SCATTER)) {
         // reduce-scatter form: 64 workgroups per direction, two chains per workgroup for B > 16

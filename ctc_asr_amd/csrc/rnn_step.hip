@@ -290,8 +290,8 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
              int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
-             const float *cells, float *dxw, float *drec, float *dbias, void *sync,
-             float *carry, int step_begin, int step_end, int flags, hipStream_t s);
+             const float *cells, float *dxw, float *drec, float *dbias, unsigned *colmax,
+             void *sync, float *carry, int step_begin, int step_end, int flags, hipStream_t s);
 
 // The persistent kernels cover at most 32 rows (two 16-row tiles) per launch: a bigger batch
 // (33..64) runs as consecutive launches over blocks of rows, each block with its own barrier
@@ -411,6 +411,12 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, c
                                 workspace_bytes, 0, T, CTCASR_RNN_DEFAULT, stream);
 }
 
+// Whether a backward call with these flags runs the fp16-pipe kernel (and so can fill `colmax`).
+extern "C" int ctcasr_rnn_bwd_f16_supported(int cell, int T, int B, int H, int flags) {
+    return (flags & CTCASR_RNN_F16) && cell == CTCASR_CELL_LSTM && H == 1024 &&
+           ctcasr_rnn_persistent_supported(cell, T, B, H) ? 1 : 0;
+}
+
 // Steps [step_begin, step_end) of the backward recurrence, walked downwards.  A whole pass is
 // (0, T); a pass may be cut into launches that cover T..0 in descending order with the same
 // workspace - the state between them (dh through the exchange buffer / state ping-pong, dc in the
@@ -420,9 +426,11 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
                                     const float *w_hh_t, const float *b_hh_n,
                                     const int32_t *seq_len, int T, int B, int H,
                                     const void *reserve, float *dxw, float *dbias,
-                                    void *workspace, size_t workspace_bytes, int step_begin,
-                                    int step_end, int flags, ctcasr_stream_t stream) {
+                                    uint32_t *colmax, void *workspace, size_t workspace_bytes,
+                                    int step_begin, int step_end, int flags,
+                                    ctcasr_stream_t stream) {
     (void)b_hh_n;
+    if (colmax && !ctcasr_rnn_bwd_f16_supported(cell, T, B, H, flags)) return CTCASR_ERR_UNSUPPORTED;
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
@@ -455,7 +463,7 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
             rc = prnn_bwd(cell, dy + b0 * 2 * H, y + b0 * 2 * H, w_hh_t,
                           seq_len ? seq_len + b0 : nullptr, T, prnn_block_rows(B, blk), B, H,
                           p.gates + b0 * 2 * 4 * H, p.cells + b0 * 2 * H, dxw + b0 * 2 * G * H,
-                          p.drec + b0 * 2 * G * H, dbias,
+                          p.drec + b0 * 2 * G * H, dbias, colmax,
                           reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
                               blk * prnn_block_bytes(T, B, H, G),
                           p.cbuf + b0 * 2 * H, step_begin, step_end, flags, s);
@@ -493,8 +501,8 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
                               const void *reserve, float *dxw, float *dbias, void *workspace,
                               size_t workspace_bytes, ctcasr_stream_t stream) {
     return ctcasr_rnn_bwd_steps(cell, dy, y, w_hh_t, b_hh_n, seq_len, T, B, H, reserve, dxw,
-                                dbias, workspace, workspace_bytes, 0, T, CTCASR_RNN_DEFAULT,
-                                stream);
+                                dbias, nullptr, workspace, workspace_bytes, 0, T,
+                                CTCASR_RNN_DEFAULT, stream);
 }
 
 // Synchronises `stream` and reports whether ANY persistent launch that used `workspace` since

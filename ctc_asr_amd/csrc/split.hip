@@ -267,6 +267,16 @@ extern "C" int ctcasr_colmax_scale(const float *x, int64_t rows, int cols, int64
     return ctcasr_launch_status();
 }
 
+// The scales of ctcasr_colmax_scale from column maxima somebody else has found (the fp16 backward
+// recurrence kernel accumulates them while it writes dxw): no pass over the matrix.
+extern "C" int ctcasr_colscale_from_max(const uint32_t *max_bits, int cols, float *scale,
+                                        float *inv_scale, ctcasr_stream_t stream) {
+    if (!max_bits || !scale || !inv_scale || cols <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    colscale_kernel<<<(cols + 255) / 256, 256, 0, (hipStream_t)stream>>>(max_bits, cols, scale,
+                                                                         inv_scale);
+    return ctcasr_launch_status();
+}
+
 extern "C" int ctcasr_split_f16_cols(const float *x, int64_t rows, int cols, int64_t ld_x,
                                      const float *col_scale, float scale, const int *order,
                                      int blocks, void *out, int64_t ld_out, int64_t block_stride,

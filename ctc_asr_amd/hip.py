@@ -51,8 +51,9 @@ SIGNATURES = {
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
     'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 3 +
                              [_c_sz, _c_int, _c_int, _c_int, _c_p]),
-    'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 +
+    'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 5 +
                              [_c_sz, _c_int, _c_int, _c_int, _c_p]),
+    'ctcasr_rnn_bwd_f16_supported': (_c_int, [_c_int] * 5),
     'ctcasr_bias_act_fwd': (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_f, _c_f, _c_u64, _c_p]),
     'ctcasr_bias_act_bwd': (_c_int, [_c_p] * 4 + [_c_i64, _c_int, _c_f, _c_f, _c_p]),
     'ctcasr_dropout': (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_u64, _c_p]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     'ctcasr_split_f16': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_f, _c_p, _c_int, _c_p, _c_i64,
                                   _c_i64, _c_p]),
     'ctcasr_colmax_scale': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+    'ctcasr_colscale_from_max': (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p]),
     'ctcasr_split_f16_cols': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_f, _c_p, _c_int, _c_p,
                                        _c_i64, _c_i64, _c_p]),
     'ctcasr_split_f16_rows': (_c_int, [_c_p, _c_i64, _c_int, _c_i64, _c_p, _c_int, _c_p, _c_i64,
@@ -390,8 +392,11 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
 
 @_on_tensor_device
 def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, dbias=None,
-            workspace=None, steps=None, flags=RNN_DEFAULT, ticket=0):
+            workspace=None, steps=None, flags=RNN_DEFAULT, ticket=0, colmax=None):
     """dy,y f32[T,B,2H], w_hh_t f32[2,H,G*H] -> dxw f32[T,B,2,G*H].
+
+    ``colmax`` (optional; only where `rnn_bwd_f16_supported`): int32[2*G*H] zeroed by the caller,
+    raised to the bit patterns of the largest |dxw| per column over the steps of the call.
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_bwd_steps`): cut
     a pass into calls covering T..0 in descending order, passing the same ``dxw`` and
@@ -415,10 +420,17 @@ def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, d
         CELL_IDS[cell], _dev(dy, name='dy'), _dev(y, name='y'), _dev(w_hh_t, name='w_hh_t'),
         _dev(b_hh_n, name='b_hh_n'), _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch,
         hidden, _dev(reserve, torch.uint8, 'reserve'), _dev(dxw, name='dxw'),
-        _dev(dbias, name='dbias'), _dev(workspace, torch.uint8, 'workspace'),
+        _dev(dbias, name='dbias'), _dev(colmax, torch.int32, 'colmax'),
+        _dev(workspace, torch.uint8, 'workspace'),
         workspace.numel(), int(begin), int(end), int(flags) | (int(ticket) & 0xFFFFFF) << 8,
         _stream()), 'rnn_bwd')
     return dxw
+
+
+def rnn_bwd_f16_supported(cell, num_steps, batch, hidden, flags=RNN_F16):
+    """Whether `rnn_bwd` with these flags runs the fp16-pipe kernel (and can fill ``colmax``)."""
+    return bool(load().ctcasr_rnn_bwd_f16_supported(CELL_IDS[cell], int(num_steps), int(batch),
+                                                    int(hidden), int(flags)))
 
 
 @_on_tensor_device
@@ -525,6 +537,19 @@ def _f16_out(out, rows, blocks, cols, device):
             out.stride(2) != 1 or out.device != device):
         raise CtcAsrError('out must be an fp16 [rows, blocks, cols] view with unit column stride.')
     return out
+
+
+@_on_tensor_device
+def colscale_from_max(max_bits):
+    """(scale, inv_scale) f32[cols] of `colmax_scale` from column maxima already known: int32[cols]
+    bit patterns of max |x[:, c]| (what `rnn_bwd(..., colmax=)` accumulates)."""
+    cols = max_bits.numel()
+    scale = torch.empty(cols, dtype=torch.float32, device=max_bits.device)
+    inv_scale = torch.empty(cols, dtype=torch.float32, device=max_bits.device)
+    _check(load().ctcasr_colscale_from_max(_dev(max_bits, torch.int32, 'max_bits'), cols,
+                                           scale.data_ptr(), inv_scale.data_ptr(), _stream()),
+           'colscale_from_max')
+    return scale, inv_scale
 
 
 @_on_tensor_device

@@ -352,6 +352,10 @@ class CTCModel:
         # three products on the fp16 matrix pipe (LSTM-1024 persistent kernel; |h| <= 1, W_hh
         # scaled per workgroup inside the kernel) instead of fp32 MFMAs
         self.rnn_fwd_f16 = os.environ.get('CTCASR_RNN_FWD_F16', '1') == '1'
+        # ... and the backward recurrence's dgates W_hh (LSTM-1024 persistent kernel): dgates scaled
+        # per (producer workgroup, row) inside the kernel, which also hands the column maxima of
+        # dxw to the fp16 weight-gradient GEMMs (no `colmax` pass over dxw)
+        self.rnn_bwd_f16 = os.environ.get('CTCASR_RNN_BWD_F16', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
         self._side_stream = None
         self.early_hooks = False        # see backward(); set by engine.Trainer
@@ -885,6 +889,7 @@ class CTCModel:
                 reduce_hook(layer, *slices[layer])
 
         self.arena.grad.zero_()
+        arith = acts.setdefault('arithmetic', {})
         training = acts['training']
         t_out, batch = acts['t_out'], acts['batch']
         hidden, gates, cell = cfg.num_units_rnn, GATES[cfg.cell], cfg.cell
@@ -1066,12 +1071,15 @@ class CTCModel:
                                        out=drs.buf[rng, :, cols])
 
             def partial_weight_grads_f16(lo, hi, name=name, dxw2d=dxw2d, drec=drec, x16=x16,
-                                         y16=y16):
+                                         y16=y16, colmax=None):
                 # steps [lo, hi) in the fp16 form: per direction one column-scaled split of the
                 # finished rows of dxw (GRU: and of drec) feeds both W_ih's and W_hh's product
+                # (``colmax``: the column maxima of these rows, left by the recurrence launch)
                 for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
                     cols = slice(d * gh, (d + 1) * gh)
-                    d16, inv = split_gemm.wgrad16_operand(dxw2d[a * batch:b * batch, cols])
+                    d16, inv = split_gemm.wgrad16_operand(
+                        dxw2d[a * batch:b * batch, cols],
+                        None if colmax is None else colmax[d * gh:(d + 1) * gh])
                     split_gemm.wgrad16(g[name + '/w_ih'][d], d16, inv, x16[0], x16[1], a * batch)
                     if d == 0:
                         a2, b2, shift, hcols = max(a, 1), b, -1, slice(0, hidden)
@@ -1089,9 +1097,9 @@ class CTCModel:
             def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec,
                                      ds=ds if self.split_wgrad else None, drs=drs,
                                      input_pieces=input_pieces, output_pieces=output_pieces,
-                                     g16=g16, f16_form=partial_weight_grads_f16):
+                                     g16=g16, f16_form=partial_weight_grads_f16, colmax=None):
                 if g16:
-                    return f16_form(lo, hi)
+                    return f16_form(lo, hi, colmax=colmax)
                 # steps [lo, hi): times [lo, hi) of the forward direction, mirrored for the other
                 x3 = x.view(t_out, batch, -1)
                 xs = input_pieces() if ds is not None else None
@@ -1129,19 +1137,29 @@ class CTCModel:
             dbias = self.arena.grad[b_start:b_start + b_count]
             bounds = [t_out * (chunks - c) // chunks for c in range(chunks + 1)]   # T ... 0
             split_done = []
+            # dgates W_hh on the fp16 matrix pipe where the kernel exists (LSTM-1024); it then also
+            # leaves the column maxima of each launch's rows of dxw for the fp16 weight gradients
+            bwd_flags = self.rnn_bwd_flags | (hip.RNN_F16 if self.rnn_bwd_f16 else 0)
+            f16_rec = hip.rnn_bwd_f16_supported(cell, t_out, batch, hidden, bwd_flags)
+            arith['rnn{}/recurrence_bwd'.format(i)] = 'fp16x3' if f16_rec else 'fp32'
+            colmax = torch.zeros((chunks, 2 * gh), dtype=torch.int32, device=dy.device) \
+                if f16_rec and g16 else None
+            if colmax is not None:
+                side_tensors.append(colmax)
             for c in range(chunks):
                 hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
                             dxw=dxw, dbias=dbias, workspace=acts['rnn_ws'],
-                            steps=(bounds[c + 1], bounds[c]), flags=self.rnn_bwd_flags,
+                            steps=(bounds[c + 1], bounds[c]), flags=bwd_flags,
                             ticket=self._take_ticket() if persistent and not whole_chip_rnn
-                            else 0)
+                            else 0, colmax=None if colmax is None else colmax[c])
                 if c + 1 < chunks:
-                    def finished_steps(lo=bounds[c + 1], hi=bounds[c]):
+                    def finished_steps(lo=bounds[c + 1], hi=bounds[c],
+                                       colmax=None if colmax is None else colmax[c]):
                         if ds is not None:  # these steps' pieces: beside the next launch as well
                             split_steps(lo, hi)
                             split_done.append(torch.cuda.Event())
                             split_done[-1].record(torch.cuda.current_stream(self.device))
-                        partial_weight_grads(lo, hi)
+                        partial_weight_grads(lo, hi, colmax=colmax)
                     on_side(side_tensors, finished_steps, gate=True)
             if ds is not None:
                 split_steps(0, bounds[-2])
@@ -1173,11 +1191,12 @@ class CTCModel:
 
             def weight_grads(name=name, x=x, y=y, dxw=dxw, dxw2d=dxw2d, i=i, chunks=chunks,
                              last=bounds[-2], partial_weight_grads=partial_weight_grads,
-                             drec=drec, use_split=use_split):
+                             drec=drec, use_split=use_split,
+                             colmax=None if colmax is None else colmax[chunks - 1]):
                 if cell != 'gru':       # (the GRU's db_hh came out of the kernel with db_ih)
                     g[name + '/b_hh'].copy_(g[name + '/b_ih'])
                 if chunks > 1 or use_split:   # the earlier launches' shares are already in
-                    partial_weight_grads(0, last)
+                    partial_weight_grads(0, last, colmax=colmax)
                     return
                 torch.mm(dxw2d.t(), x.view(rows, -1),
                          out=g[name + '/w_ih'].view(2 * gates * hidden, -1))

@@ -195,10 +195,12 @@ def mm_nn16_stacked(a, b_stacked, scale_product, out=None):
 
 # ---- gradient GEMMs in the fp16 form: scales per column (weight gradients) / per row (data
 # gradient) of dxw, found on the device; the bounded operand keeps its fixed scale ----------------
-def wgrad16_operand(d2d):
+def wgrad16_operand(d2d, colmax=None):
     """fp16 pieces [rows, 3, cols] (order H_B) of a block of gradient rows, scaled per column, and
-    the inverse scales f32[cols]."""
-    scale, inv = hip.colmax_scale(d2d)
+    the inverse scales f32[cols].  ``colmax``: int32[cols] bit patterns of the column maxima when
+    the kernel that wrote the block has found them already (`hip.rnn_bwd(..., colmax=)`), else a
+    pass over the block finds them."""
+    scale, inv = hip.colmax_scale(d2d) if colmax is None else hip.colscale_from_max(colmax)
     return hip.split_f16_cols(d2d, scale, 1.0, H_B), inv
 
 

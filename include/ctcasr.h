@@ -223,9 +223,20 @@ int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_
  * the next launch continues the recurrence. */
 int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y, const float *w_hh_t,
                          const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
-                         const void *reserve, float *dxw, float *dbias, void *workspace,
-                         size_t workspace_bytes, int step_begin, int step_end, int flags,
-                         ctcasr_stream_t stream);
+                         const void *reserve, float *dxw, float *dbias, uint32_t *colmax,
+                         void *workspace, size_t workspace_bytes, int step_begin, int step_end,
+                         int flags, ctcasr_stream_t stream);
+/* ABI v5.  CTCASR_RNN_F16 in a BACKWARD call's flags (LSTM, H = 1024 on the persistent kernels;
+ * ctcasr_rnn_bwd_f16_supported says whether a call qualifies, every other call ignores the bit):
+ * dgates x W_hh on the fp16 matrix pipe - each producer workgroup scales every row of its 64 gate
+ * columns by its own power of two and publishes two fp16 pieces, the consumer accumulates every
+ * producer's block apart and adds it, unscaled, to an fp32 total; W_hh as in the forward kernel.
+ * fp32-grade (22 significand bits per (row, 64-column block)), not bit-equal to the fp32 kernel.
+ * `colmax` (optional, only with that kernel - else CTCASR_ERR_UNSUPPORTED): u32[2 * 4H], zeroed
+ * by the caller; the kernel raises (atomicMax) word [dir][g H + unit] to the bit pattern of the
+ * largest |dxw| of that column over the steps of the call - what ctcasr_colmax_scale's pass over
+ * the finished rows of dxw would find (same values, no pass). */
+int ctcasr_rnn_bwd_f16_supported(int cell, int T, int B, int H, int flags);
 
 /* ---- fused dense / conv epilogues (tf.layers.dense + ReLU + tf.minimum(., relu_cutoff) +
  * tf.layers.dropout: asr/util/tf_contrib.py:50-61,122-135, asr/model.py:219-225) --------------
@@ -351,6 +362,10 @@ int ctcasr_split_f16(const float *x, int64_t rows, int cols, int64_t ld_x, float
  *                         of a product (cols % 4 == 0, 16-byte aligned) */
 int ctcasr_colmax_scale(const float *x, int64_t rows, int cols, int64_t ld_x, void *workspace,
                         float *scale, float *inv_scale, ctcasr_stream_t stream);
+/* (ABI v5) the same scales from column maxima already known: max_bits u32[cols] = bit patterns of
+ * max_r |x[r][c]| as ctcasr_rnn_bwd_steps(..., colmax, ...) leaves them */
+int ctcasr_colscale_from_max(const uint32_t *max_bits, int cols, float *scale, float *inv_scale,
+                             ctcasr_stream_t stream);
 int ctcasr_split_f16_cols(const float *x, int64_t rows, int cols, int64_t ld_x,
                           const float *col_scale, float scale, const int *order, int blocks,
                           void *out, int64_t ld_out, int64_t block_stride, ctcasr_stream_t stream);

@@ -28,8 +28,9 @@ def main():
         fwd_flags |= hip.RNN_ONE_BARRIER
     if os.environ.get('CTCASR_RS'):            # backward: reduce-scatter form (LSTM-1024)
         bwd_flags |= hip.RNN_REDUCE_SCATTER
-    if os.environ.get('CTCASR_F16'):           # forward: h W_hh^T on the fp16 matrix pipe
+    if os.environ.get('CTCASR_F16'):           # both recurrences on the fp16 matrix pipe
         fwd_flags |= hip.RNN_F16
+        bwd_flags |= hip.RNN_F16
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)

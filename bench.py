@@ -310,7 +310,7 @@ def pmc_traffic(workload, which, launch_steps):
 
 
 def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=True,
-            model_attrs=None):
+            model_attrs=None, stand_in=None):
     """Build the workload ``name`` on this rank's GPU, run warm-up + timed steps under the
     contract's protocol and return the result dict (rank 0) or None.  ``allreduce_early``
     selects the release mode of the gradient buckets (None: the environment / default),
@@ -330,7 +330,8 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                       dense_dropout_rate=args.dropout)
     # fixed input shape: let MIOpen benchmark its convolution kernels once (warm-up steps)
     trainer = Trainer(cfg, device=device, seed=0, world_size=world, rank=rank, conv_autotune=True,
-                      allreduce_early=allreduce_early, reduce=reduce)
+                      allreduce_early=allreduce_early, reduce=reduce,
+                      collective_stand_in=stand_in)
     model = trainer.model
     for key, value in (model_attrs or {}).items():    # (None: the defaults / CTCASR_* switches)
         setattr(model, key, value)
@@ -882,12 +883,19 @@ def merge_release_modes(legs, stub):
             'mode': leg['allreduce']['mode'],     # early falls back to held at H = 2048
             'launches_per_step': leg['allreduce']['launches_per_step'],
             'rank_ms_per_step': leg['allreduce']['rank_ms_per_step'],
-            'exposed_allreduce_ms': round(leg['ms_per_step'] - stub['ms_per_step'], 3)}
+            'exposed_allreduce_ms': round(leg['ms_per_step'] - stub['ms_per_step'], 3),
+            'exposed_allreduce_frac_of_step': round(
+                (leg['ms_per_step'] - stub['ms_per_step']) / leg['ms_per_step'], 4)}
         for m, leg in legs.items()}
     result['allreduce']['chosen'] = best
     result['allreduce']['stubbed_ms_per_step'] = stub['ms_per_step']
     result['allreduce']['exposed_allreduce_ms'] = round(
         result['ms_per_step'] - stub['ms_per_step'], 3)
+    result['allreduce']['exposed_allreduce_frac_of_step'] = round(
+        (result['ms_per_step'] - stub['ms_per_step']) / result['ms_per_step'], 4)
+    # (a mode in which any rank reported an error - e.g. a recurrence time-out under the early
+    # release - is never the chosen one while another mode ran clean)
+    result['allreduce']['choice_rule'] = 'fastest mode without a failed rank'
     return result
 
 
@@ -934,6 +942,12 @@ def main():
                     help='seconds the float64 oracle child may take at full size')
     ap.add_argument('--no-step-checks', action='store_true',
                     help='train_step(check=False): without the deferred per-step error checks')
+    ap.add_argument('--collective-stand-in', action='store_true',
+                    help='N = 1 diagnostic: every gradient bucket launches a collective-shaped '
+                         'kernel (24 resident workgroups holding their CUs for bytes / 150 GB/s on '
+                         'a stream of its own, engine.GradientReducer(stand_in=)) - measures, for '
+                         'both release modes, what ring kernels beside the persistent recurrences '
+                         'cost; reported under `collective_stand_in`')
     ap.add_argument('--c5-batches', type=int, default=24,
                     help='bucketed batches in the C5 sequence of the default N = 1 run')
     args = ap.parse_args()
@@ -1036,6 +1050,22 @@ def main():
                                                  'roofline', 'host_enqueue_ms_per_step')}
         except Exception as err:        # noqa: BLE001
             other['c5'] = {'error': '{}: {}'.format(type(err).__name__, err)}
+    if world == 1 and args.collective_stand_in and args.workload != 'c5':
+        # one GPU cannot run RCCL beside itself; its CU footprint can be stood in for
+        report = {'stand_in': '24 workgroups x 256 threads per bucket, resident for bytes / '
+                              '150 GB/s, own stream, waited for like an async all-reduce',
+                  'plain_ms_per_step': result['ms_per_step']}
+        for mode in ('held', 'early'):
+            try:
+                leg, _ = measure(args.workload, args, rank, local_rank, world,
+                                 allreduce_early=(mode == 'early'), stand_in=(24, 150.0))
+                report[mode] = {'ms_per_step': leg['ms_per_step'],
+                                'inflation_ms': round(leg['ms_per_step'] - result['ms_per_step'], 3),
+                                'inflation_frac': round(leg['ms_per_step'] / result['ms_per_step']
+                                                        - 1.0, 4)}
+            except Exception as err:        # noqa: BLE001 - a time-out is the finding
+                report[mode] = {'error': '{}: {}'.format(type(err).__name__, err)}
+        result['collective_stand_in'] = report
     if rank == 0:
         if world > 1:
             result['allreduce']['ranks_seen_by_allreduce'] = ranks_seen

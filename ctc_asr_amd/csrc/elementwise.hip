@@ -124,7 +124,11 @@ transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows
 __global__ void __launch_bounds__(256)
 adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
             float *__restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
-            float gscale) {
+            float gscale, const int32_t *__restrict__ skip) {
+    // a step whose gradients are known to be garbage (infeasible CTC alignment, non-finite loss,
+    // a persistent recurrence that gave up at a barrier: ctcasr_step_guard) must not touch the
+    // parameters or the moments - decided on the device, the host finds out later
+    if (skip && *skip) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n4 = n >> 2;
     float4 *p4 = reinterpret_cast<float4 *>(p);
@@ -153,6 +157,57 @@ adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restric
         m[i] = mm; v[i] = vv;
         p[i] -= lr_t * mm / (sqrtf(vv) + eps);
     }
+}
+
+// skip[0] = any CTC status word != 0 | any per-utterance loss not finite | any time-out word set;
+// skip[1] = the time-out words or-ed together (what the host polls, see engine.Trainer)
+__global__ void step_guard_kernel(const int32_t *__restrict__ status,
+                                  const float *__restrict__ loss, int batch,
+                                  const unsigned *err0, const unsigned *err1,
+                                  int32_t *__restrict__ skip) {
+    int bad = 0;
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+        if (status && status[b] != 0) bad = 1;
+        if (loss && !isfinite(loss[b])) bad = 1;
+    }
+    bad = __any(bad) ? 1 : 0;
+    __shared__ int any_bad[4];
+    if ((threadIdx.x & 63) == 0) any_bad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned err = (err0 ? *err0 : 0u) | (err1 ? *err1 : 0u);
+        skip[0] = (any_bad[0] | any_bad[1] | any_bad[2] | any_bad[3] | (err != 0u)) ? 1 : 0;
+        skip[1] = (int32_t)err;
+    }
+}
+
+// largest magnitude of a vector, as its bit pattern (the caller zeroes the word)
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float m = 0.f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int64_t i = ((n >> 2) << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += stride)
+        m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    // (NaN compares false everywhere above: a NaN weight shows as a non-finite loss, not here)
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// Diagnostic stand-in for the CU footprint of a collective: `workgroups` workgroups of 256 threads
+// that hold their CUs for `busy_ticks` of the 100 MHz wall clock and touch nothing.  RCCL's ring
+// kernels are exactly that from the point of view of a persistent recurrence launch - resident
+// workgroups that do not yield - and NCCL refuses two ranks on one device, so the one-GPU boxes
+// cannot run the real thing beside the recurrences (tests/test_gpu_dp_rccl.py, bench.py
+// --collective-stand-in).
+__global__ void __launch_bounds__(256) occupy_kernel(unsigned long long busy_ticks) {
+    const unsigned long long start = wall_clock64();
+    while (wall_clock64() - start < busy_ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 int grid_for(int64_t work_items) {
@@ -239,7 +294,7 @@ extern "C" int ctcasr_transpose_batched(const float *in, float *out, int batch, 
 
 extern "C" int ctcasr_adam_step(float *param, const float *grad, float *m, float *v, int64_t n,
                                 float lr, float beta1, float beta2, float epsilon, int64_t step,
-                                float grad_scale, ctcasr_stream_t stream) {
+                                float grad_scale, const int32_t *skip, ctcasr_stream_t stream) {
     if (!param || !grad || !m || !v || n < 0 || step < 1) return CTCASR_ERR_BAD_ARGUMENT;
     if (n == 0) return CTCASR_OK;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
@@ -248,6 +303,32 @@ extern "C" int ctcasr_adam_step(float *param, const float *grad, float *m, float
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) /
                         (1.0 - pow((double)beta1, (double)step));
     adam_kernel<<<grid_for(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(
-        param, grad, m, v, n, (float)lr_t, beta1, beta2, epsilon, grad_scale);
+        param, grad, m, v, n, (float)lr_t, beta1, beta2, epsilon, grad_scale, skip);
+    return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_step_guard(const int32_t *ctc_status, const float *per_utterance_loss,
+                                 int batch, const uint32_t *timeout_word0,
+                                 const uint32_t *timeout_word1, int32_t *skip,
+                                 ctcasr_stream_t stream) {
+    if (!skip || batch < 0) return CTCASR_ERR_BAD_ARGUMENT;
+    step_guard_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ctc_status, per_utterance_loss, batch,
+                                                          timeout_word0, timeout_word1, skip);
+    return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_occupy_cus(int workgroups, int busy_us, ctcasr_stream_t stream) {
+    if (workgroups < 1 || workgroups > 256 || busy_us < 0 || busy_us > 100000)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    occupy_kernel<<<workgroups, 256, 0, (hipStream_t)stream>>>((unsigned long long)busy_us * 100ull);
+    return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_absmax(const float *x, int64_t n, uint32_t *max_bits,
+                             ctcasr_stream_t stream) {
+    if (!x || !max_bits || n < 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (n == 0) return CTCASR_OK;
+    absmax_kernel<<<grid_for(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(x, n, max_bits);
     return ctcasr_launch_status();
 }

@@ -505,6 +505,14 @@ extern "C" int ctcasr_rnn_bwd(int cell, const float *dy, const float *y, const f
                                 CTCASR_RNN_DEFAULT, stream);
 }
 
+extern "C" size_t ctcasr_rnn_timeout_word_offset(int cell, int T, int B, int H, int block) {
+    if (rnn_check(cell, T, B, H) != CTCASR_OK || !ctcasr_rnn_persistent_supported(cell, T, B, H) ||
+        block < 0 || block >= prnn_blocks(B))
+        return (size_t)-1;
+    return rnn_state_bytes(B, H) + (size_t)block * prnn_block_bytes(T, B, H, cell_gates(cell)) +
+           prnn_error_offset();
+}
+
 // Synchronises `stream` and reports whether ANY persistent launch that used `workspace` since
 // the last poll gave up at a grid barrier (CTCASR_ERR_TIMEOUT); the word is sticky across
 // launches and cleared by this call.  Streaming launches never set it.

@@ -69,7 +69,10 @@ split_f16_kernel(const float *__restrict__ x, int64_t ld_x, int64_t vecs, int ve
     unsigned h[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float s = f[i] * scale;
+        // (saturating: an operand outside the range its scale was chosen for becomes the largest
+        // finite fp16, not inf - wrong, but it cannot poison a whole product with NaNs; callers
+        // that cannot bound the operand check it, ctcasr_absmax)
+        const float s = fminf(fmaxf(f[i] * scale, -65504.f), 65504.f);
         const _Float16 h1 = (_Float16)s;
         const _Float16 h2 = (_Float16)(s - (float)h1);
         h[0][i] = __builtin_bit_cast(unsigned short, h1);

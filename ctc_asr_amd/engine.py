@@ -50,12 +50,20 @@ class GradientReducer:
     first launch."""
 
     def __init__(self, grad_arena, world_size, bucket_bytes=64 << 20, group=None,
-                 hold_until=None, force=False, max_bucket_bytes=None):
+                 hold_until=None, force=False, max_bucket_bytes=None, stand_in=None):
         self.grad, self.world, self.group = grad_arena, world_size, group
+        # ``stand_in`` = (workgroups, GB/s): instead of a collective every bucket launches a
+        # kernel of that many resident workgroups that holds its CUs for bytes / rate on a
+        # stream of its own - ordered after the launching stream and waited for by `finish()`
+        # exactly like an asynchronous all-reduce.  The one-GPU stand-in for RCCL's ring kernels
+        # beside the persistent recurrences (NCCL refuses two ranks on one device); implies
+        # `force`.  Gradients are left alone (a one-rank sum).
+        self.stand_in = stand_in
+        self._stand_in_stream = None
         # `force`: run the collectives even with a single rank (a world-size-1 process group is
         # legal): tests use it to put the real backend (RCCL) under the real backward pass on a
         # one-GPU box
-        self.active = world_size > 1 or force
+        self.active = world_size > 1 or force or stand_in is not None
         self.bucket_elems = max(1, bucket_bytes // 4)
         # slices are merged until a bucket holds at least `bucket_bytes`; a pending range larger
         # than `max_bucket_bytes` (a held-back release: everything at once; or one big layer) is
@@ -115,11 +123,37 @@ class GradientReducer:
         hi = stop
         while hi > start:                            # from the end: the order backward made them
             lo = max(start, hi - piece)
-            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM,
-                                              group=self.group, async_op=True))
+            if self.stand_in is not None:
+                self.works.append(self._launch_stand_in((hi - lo) * 4))
+            else:
+                self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM,
+                                                  group=self.group, async_op=True))
             self.launched += 1
             hi = lo
         self.pending_start = self.pending_stop = None
+
+    def _launch_stand_in(self, nbytes):
+        """The stream semantics of `dist.all_reduce(async_op=True)` on the nccl backend: the
+        collective runs on the backend's own stream behind everything enqueued so far on the
+        launching stream; `wait()` makes the then-current stream wait for it."""
+        from ctc_asr_amd import hip
+        workgroups, gb_per_s = self.stand_in
+        device = self.grad.device
+        if self._stand_in_stream is None:
+            self._stand_in_stream = torch.cuda.Stream(device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self._stand_in_stream):
+            self._stand_in_stream.wait_event(ready)
+            hip.occupy_cus(workgroups, max(1, int(nbytes / (gb_per_s * 1e3))))
+            done = torch.cuda.Event()
+            done.record(self._stand_in_stream)
+
+        class _Work:
+            @staticmethod
+            def wait():
+                torch.cuda.current_stream(device).wait_event(done)
+        return _Work
 
     def finish(self):
         if not self.active:
@@ -136,7 +170,7 @@ class Trainer:
 
     def __init__(self, cfg, flags=None, device=None, seed=0, params=None, world_size=1, rank=0,
                  bucket_bytes=64 << 20, conv_autotune=None, allreduce_early=None,
-                 force_reducer=False, reduce=True):
+                 force_reducer=False, reduce=True, collective_stand_in=None):
         self.world, self.rank = world_size, rank
         device = device or 'cuda:{}'.format(torch.cuda.current_device())
         self.model = CTCModel(cfg, device, seed=seed, params=params, conv_autotune=conv_autotune)
@@ -160,13 +194,14 @@ class Trainer:
             allreduce_early = os.environ.get('CTCASR_ALLREDUCE_EARLY', '0') == '1'
         whole_chip = cfg.cell in ('lstm', 'gru') and cfg.num_units_rnn == 2048
         early = bool(allreduce_early) and not whole_chip
-        active = (world_size > 1 or force_reducer) and reduce
+        active = (world_size > 1 or force_reducer or collective_stand_in is not None) and reduce
         self.model.early_hooks = early and active
         # ``reduce=False`` (bench.py's "stubbed" leg): the same step without any collective, to
         # price what the all-reduce adds to it; replicas drift apart - timing only
         self.reducer = GradientReducer(self.model.arena.grad, world_size if reduce else 1,
                                        bucket_bytes, hold_until=None if early else 'rnn0',
-                                       force=force_reducer and reduce)
+                                       force=force_reducer and reduce,
+                                       stand_in=collective_stand_in if reduce else None)
         self.release = 'early' if early else 'held'
         if world_size > 1:   # identical replicas: rank 0's initial parameters win
             dist.broadcast(self.model.arena.param, src=0)
@@ -197,10 +232,19 @@ class Trainer:
                 break
             event.synchronize()
             self._pending_status.popleft()
+            words = host.numpy()
             try:
-                CTCModel.check_status(host)
+                CTCModel.check_status(host[:-2])
             except ValueError as err:
-                raise type(err)('{} [training step {}]'.format(err, step)) from None
+                raise type(err)('{} [training step {}; its update was not applied]'.format(
+                    err, step)) from None
+            if words[-1] != 0:
+                # a persistent recurrence gave up at a grid barrier in that step: the sticky word
+                # is read (and the barrier words reset) by the synchronous poll, which raises
+                self.model.check_rnn_error()
+            if words[-2] != 0:
+                raise FloatingPointError('non-finite CTC loss in training step {}; its update '
+                                         'was not applied'.format(step))
 
     def drain_checks(self):
         """Wait for the steps in flight and raise what they have to report: CTC status of every
@@ -217,9 +261,11 @@ class Trainer:
         1 / world_size inside the Adam kernel.
 
         ``check=True``: errors are raised without stalling the host - an infeasible alignment
-        (where ``tf.nn.ctc_loss`` raises) surfaces at most `max_steps_ahead` steps after the
-        step that hit it, a timed-out persistent kernel at most `rnn_poll_every` steps later or
-        at the next `drain_checks()`; in both cases before a checkpoint is written."""
+        (where ``tf.nn.ctc_loss`` raises), a non-finite loss or a timed-out persistent kernel
+        surfaces at most `max_steps_ahead` steps after the step that hit it (the guard word
+        travels to pinned memory with the CTC status), and always before a checkpoint is
+        written.  Either way that step's update is dropped ON THE DEVICE (`CTCModel.step_guard`
+        -> the Adam kernel's skip flag): parameters and moments never see its gradients."""
         if len(self._step_done) >= self.max_steps_ahead:
             t0 = time.perf_counter()
             while len(self._step_done) >= self.max_steps_ahead:
@@ -235,16 +281,22 @@ class Trainer:
                 self._steps_since_poll = 0
         loss = self.model.forward_backward(features, feature_len, labels,
                                            reduce_hook=self.reducer, check=False)
+        # Invalid gradients never reach the parameters: the guard word is computed on the device
+        # from this step's CTC status, its loss and the recurrence time-out words, and the Adam
+        # kernel drops the update when it is set - whenever the host gets to look.
+        # (N > 1: every rank guards its own shard; the error it raises stops the job.)
+        guard = self.model.step_guard()
         if check:
             status = self.model.last_status
-            host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
-            host.copy_(status, non_blocking=True)
+            host = torch.empty(status.numel() + 2, dtype=status.dtype, pin_memory=True)
+            host[:status.numel()].copy_(status, non_blocking=True)
+            host[status.numel():].copy_(guard, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record(torch.cuda.current_stream(self.model.device))
             self._pending_status.append((copied, host, self.model.step_count + 1))
         self.reducer.finish()
         self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
-                                   grad_scale=1.0 / self.world)
+                                   grad_scale=1.0 / self.world, skip=guard)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.model.device))
         self._step_done.append(done)

@@ -92,7 +92,11 @@ SIGNATURES = {
     'ctcasr_features_workspace_bytes': (_c_sz, [_c_int, _c_int]),
     'ctcasr_features': (_c_int, [_c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_p, _c_int, _c_p, _c_p,
                                  _c_sz, _c_p]),
-    'ctcasr_adam_step': (_c_int, [_c_p] * 4 + [_c_i64] + [_c_f] * 4 + [_c_i64, _c_f, _c_p]),
+    'ctcasr_adam_step': (_c_int, [_c_p] * 4 + [_c_i64] + [_c_f] * 4 + [_c_i64, _c_f, _c_p, _c_p]),
+    'ctcasr_step_guard': (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p]),
+    'ctcasr_rnn_timeout_word_offset': (_c_sz, [_c_int] * 5),
+    'ctcasr_absmax': (_c_int, [_c_p, _c_i64, _c_p, _c_p]),
+    'ctcasr_occupy_cus': (_c_int, [_c_int, _c_int, _c_p]),
 }
 
 _lib = None
@@ -808,11 +812,54 @@ def transpose_batched(src, out=None):
 
 @_on_tensor_device
 def adam_step(param, grad, m, v, step, lr=1e-5, beta1=0.9, beta2=0.999, epsilon=1e-8,
-              grad_scale=1.0):
+              grad_scale=1.0, skip=None):
+    """TensorFlow-form Adam over the flat arenas.  ``skip`` (optional int32 device tensor): the
+    update is dropped on the device when skip[0] != 0 (`step_guard`)."""
     _check(load().ctcasr_adam_step(_dev(param, name='param'), _dev(grad, name='grad'),
                                    _dev(m, name='m'), _dev(v, name='v'), param.numel(), float(lr),
                                    float(beta1), float(beta2), float(epsilon), int(step),
-                                   float(grad_scale), _stream()), 'adam_step')
+                                   float(grad_scale), _dev(skip, torch.int32, 'skip'), _stream()),
+           'adam_step')
+
+
+def rnn_timeout_words(cell, workspace, num_steps, batch, hidden):
+    """Device addresses (ints; 0 = none) of the sticky time-out words of the persistent kernels'
+    row blocks inside ``workspace`` - what `step_guard` reads."""
+    out = []
+    for block in range(2):
+        off = load().ctcasr_rnn_timeout_word_offset(CELL_IDS[cell], int(num_steps), int(batch),
+                                                    int(hidden), block)
+        out.append(0 if off == ctypes.c_size_t(-1).value else workspace.data_ptr() + off)
+    return out
+
+
+@_on_tensor_device
+def step_guard(status, per_utterance_loss, timeout_words=(0, 0), out=None):
+    """out int32[2]: [0] = 1 when this step's gradients must not be applied (a CTC status word
+    != 0, a non-finite per-utterance loss, a persistent recurrence that timed out), [1] = the
+    time-out words or-ed.  Everything stays on the device (`adam_step(skip=out)`)."""
+    if out is None:
+        out = torch.empty(2, dtype=torch.int32, device=status.device)
+    _check(load().ctcasr_step_guard(_dev(status, torch.int32, 'status'),
+                                    _dev(per_utterance_loss, name='per_utterance_loss'),
+                                    status.numel(), timeout_words[0] or None,
+                                    timeout_words[1] or None, _dev(out, torch.int32, 'out'),
+                                    _stream()), 'step_guard')
+    return out
+
+
+def occupy_cus(workgroups, busy_us):
+    """Diagnostic: `workgroups` workgroups hold their CUs for `busy_us` on the current stream (the
+    CU footprint of a collective's ring kernels; `engine.GradientReducer(stand_in=...)`)."""
+    _check(load().ctcasr_occupy_cus(int(workgroups), int(busy_us), _stream()), 'occupy_cus')
+
+
+@_on_tensor_device
+def absmax(x, out):
+    """out (one int32 word, zeroed by the caller) = max(out, bit pattern of max |x|)."""
+    _check(load().ctcasr_absmax(_dev(x.reshape(-1), name='x'), x.numel(),
+                                _dev(out, torch.int32, 'out'), _stream()), 'absmax')
+    return out
 
 
 _FEATURE_TABLES = {}

@@ -253,6 +253,7 @@ class ParamArena:
         self.v = torch.zeros(cursor, dtype=torch.float32, device=device)
         self.p = {n: self._view(self.param, n) for n in self.offsets}
         self.g = {n: self._view(self.grad, n) for n in self.offsets}
+        self.version = 0                # bumped when the parameters are replaced wholesale
 
     def _view(self, arena, name):
         shape = self.shapes[name]
@@ -269,6 +270,7 @@ class ParamArena:
             if name.startswith('conv') and name.endswith('kernel'):
                 value = value.permute(3, 2, 0, 1)
             self.p[name].copy_(value.contiguous().to(self.device))
+        self.version += 1
 
     def export(self, which='param'):
         """name->numpy dict in the shared layout (``which``: 'param' or 'grad')."""
@@ -280,6 +282,46 @@ class ParamArena:
                 value = value.permute(2, 3, 1, 0)
             out[name] = value.contiguous().numpy().copy()
         return out
+
+
+class _WeightPieces:
+    """Pieces of one weight matrix for the split GEMMs of a step.  ``fwd16`` / ``tr16``: fp16
+    pieces (fixed scale `split_gemm.W_SCALE`) of the matrix / of its transpose, or None; the bf16
+    pieces of either are built ahead only where the fp16 form does not apply and otherwise on
+    first use (a layer whose input turns out unbounded, a backward pass after an evaluation-mode
+    forward pass, dense4's gradients)."""
+
+    def __init__(self, model, name, matrix, training):
+        self.model, self.name, self.matrix, self.training = model, name, matrix, training
+        self.fwd16 = self.tr16 = None
+        self._fwd = self._tr = None
+
+    def make_fwd(self, out=None):
+        if self.name == 'dense4':       # K = the kernel's row axis: pieces stacked along the rows
+            stacked = split_gemm.split_rows_stacked(self.matrix, split_gemm.B_ORDER, out=out)
+            self._fwd = stacked.view(-1, self.matrix.shape[1])
+        else:
+            self._fwd = split_gemm.split(self.matrix, split_gemm.B_ORDER, out=out)
+        return self._fwd
+
+    def make_tr(self, out=None, scratch=None):
+        if self.name == 'dense4':       # (its data gradient reads the kernel's own rows)
+            self._tr = split_gemm.split(self.matrix, split_gemm.A_ORDER, out=out)
+        else:
+            rows, cols = self.matrix.shape
+            if scratch is None:
+                scratch = torch.empty((cols, rows), dtype=torch.float32,
+                                      device=self.matrix.device)
+            hip.transpose_batched(self.matrix.view(1, rows, cols), out=scratch.view(1, cols, rows))
+            self._tr = split_gemm.split(scratch, split_gemm.A_ORDER, out=out)
+        return self._tr
+
+    def __getitem__(self, index):
+        if index == 0:
+            return self._fwd if self._fwd is not None else self.make_fwd()
+        if index == 1:
+            return self._tr if self._tr is not None else self.make_tr()
+        return (self.fwd16, self.tr16)[index - 2]
 
 
 class CTCModel:
@@ -357,6 +399,7 @@ class CTCModel:
         # dxw to the fp16 weight-gradient GEMMs (no `colmax` pass over dxw)
         self.rnn_bwd_f16 = os.environ.get('CTCASR_RNN_BWD_F16', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
+        self._w_guard = None            # range check of the weights that go to fp16 (lagged)
         self._side_stream = None
         self.early_hooks = False        # see backward(); set by engine.Trainer
         # variant of the persistent backward recurrence (hip.RNN_*): default = 128 CUs, the
@@ -385,13 +428,74 @@ class CTCModel:
             hip.rnn_resident_gate(cell, workspace, t_out, batch, hidden, self._upcoming_ticket(),
                                   self.side_gate_max_us)
 
-    # ------------------------------------------------------------------ bf16 pieces of the weights
+    # ------------------------------------------------------------------ pieces of the weights
+    def _predicted_bounds(self, training):
+        """Upper bounds of |input| of every recurrent layer and of dense4 as `inference_fn` will
+        find them (None: unbounded) - which decides, ahead of the forward pass, whether a layer's
+        projections take the fp16 form (two pieces under a fixed scale) or the bf16 form."""
+        cfg = self.cfg
+        if cfg.used_model == 'ds2':
+            bound = cfg.relu_cutoff / (1.0 - cfg.conv_dropout_rate)
+        else:
+            bound = cfg.relu_cutoff / (1.0 - (cfg.dense_dropout_rate if training else 0.0))
+        rate = cfg.rnn_dropout_rate if training else 0.0
+        bounds = []
+        for i in range(cfg.num_layers_rnn):
+            if rate > 0.0 and (i > 0 or not cfg.cudnn) and bound is not None:
+                bound = bound / (1.0 - rate)
+            bounds.append(bound)
+            bound = None if cfg.cell == 'rnn_relu' else 1.0
+            if rate > 0.0 and not cfg.cudnn and bound is not None:
+                bound = bound / (1.0 - rate)
+        return bounds + [bound]
+
+    def _weights_in_f16_range(self, names, views, side):
+        """{name: bool}: may this weight matrix be scaled by the fixed `split_gemm.W_SCALE` into
+        fp16 (its largest magnitude, times the scale, stays below half of fp16's range)?  The
+        maxima are found on the device (`hip.absmax`, side stream) and travel to pinned host
+        memory asynchronously: a step looks at the LATEST maxima that have arrived - weights move
+        by O(learning rate) per step, the factor of two of head room covers the lag - and only the
+        first step after the parameters were (re)loaded waits for its own.  An out-of-range
+        matrix takes the bf16 form (fp32's exponent range); it never becomes inf."""
+        fresh = self._w_guard is None or self._w_guard['version'] != self.arena.version or \
+            self._w_guard['names'] != names
+        if fresh:
+            self._w_guard = {
+                'version': self.arena.version, 'names': names, 'event': None,
+                'dev': torch.zeros(len(names), dtype=torch.int32, device=self.device),
+                'host': torch.zeros(len(names), dtype=torch.int32).pin_memory(),
+                'max': None}
+        guard = self._w_guard
+
+        def measure():
+            with torch.cuda.stream(side):
+                guard['dev'].zero_()
+                for k, view in enumerate(views):
+                    hip.absmax(view, guard['dev'][k:k + 1])
+                guard['host'].copy_(guard['dev'], non_blocking=True)
+                guard['event'] = torch.cuda.Event()
+                guard['event'].record(side)
+
+        if fresh:
+            measure()
+            guard['event'].synchronize()
+        if guard['event'] is not None and guard['event'].query():
+            guard['max'] = guard['host'].view(torch.float32).clone().numpy()
+            guard['event'] = None
+        if guard['event'] is None:
+            measure()                       # for a later step
+        limit = 0.5 * split_gemm.F16_MAX / split_gemm.W_SCALE
+        return {name: bool(guard['max'][k] <= limit) for k, name in enumerate(names)}
+
     def _prepare_weight_splits(self, rows, training):
-        """Pieces of the weights the split GEMMs of this step read (split_gemm.py): W_ih as
-        [2GH, 6, in] for the forward projection, its transpose as [in, 6, 2GH] for the data
-        gradient; the dense4 kernel stacked along its rows (forward) and as [in, 6, out] (data
-        gradient).  They are built on the side stream while the front end runs (the weights are
-        final since the last Adam step); `_weight_split` makes the main stream wait for them."""
+        """Pieces of the weights the split GEMMs of this step read (split_gemm.py).  Per recurrent
+        layer whose input is bounded (every layer of the BASELINE configurations) and whose W_ih
+        is in range: the fp16 pieces of W_ih [2GH, 3, in] for the forward projection and of its
+        transpose for the data gradient; the bf16 pieces ([.., 6, ..]) only where the fp16 form
+        does not apply - they are made on demand otherwise (`_WeightPieces`).  The dense4 kernel:
+        stacked along its rows (forward), [in, 6, out] bf16 for its data gradient.  Built on the
+        side stream while the front end runs (the weights are final since the last Adam step);
+        `_weight_split` makes the main stream wait for them."""
         cfg, p = self.cfg, self.arena.p
         self._w_split, self._w_split_ready = {}, None
         if not self.split_gemm:
@@ -401,7 +505,7 @@ class CTCModel:
         for i in range(cfg.num_layers_rnn):
             w_ih = p['rnn{}/w_ih'.format(i)].view(gh2, -1)
             if split_gemm.worthwhile(rows, w_ih.shape[1], gh2):
-                jobs.append(('rnn{}'.format(i), w_ih))
+                jobs.append((i, 'rnn{}'.format(i), w_ih))
         k4 = p['dense4/kernel']
         dense4 = self.split_dense4 and split_gemm.worthwhile(rows, k4.shape[0], k4.shape[1])
         if not jobs and not dense4:
@@ -413,70 +517,84 @@ class CTCModel:
         bufs = self._w_split_bufs
         start = torch.cuda.Event()
         start.record(main)
+        side.wait_event(start)              # the previous step is done with the buffers
+        bounds = self._predicted_bounds(training)
+        in_range = {}
+        if self.fwd_f16:
+            names = tuple(name for _, name, _ in jobs) + (('dense4',) if dense4 else ())
+            views = [w for _, _, w in jobs] + ([k4] if dense4 else [])
+            in_range = self._weights_in_f16_range(names, views, side)
+
+        def f16_form(layer, name):
+            return (self.fwd_f16 and in_range.get(name, False) and
+                    split_gemm.f16_scale(bounds[layer]) is not None)
+
+        def buf(key, make):
+            if key not in bufs:
+                bufs[key] = make()
+            return bufs[key]
+
+        dense4_f16 = dense4 and f16_form(cfg.num_layers_rnn, 'dense4')
         with torch.cuda.stream(side):
-            side.wait_event(start)          # the previous step is done with the buffers
-            for name, w_ih in jobs:
-                if name not in bufs:
-                    bufs[name] = (
-                        split_gemm.empty(gh2, w_ih.shape[1], split_gemm.B_ORDER, self.device),
-                        split_gemm.empty(w_ih.shape[1], gh2, split_gemm.A_ORDER, self.device),
-                        torch.empty((w_ih.shape[1], gh2), dtype=torch.float32, device=self.device),
-                        split_gemm.empty16(gh2, w_ih.shape[1], split_gemm.H_B, self.device))
-                fwd, tr, scratch, fwd16 = bufs[name]
-                split_gemm.split(w_ih, split_gemm.B_ORDER, out=fwd)
-                if self.fwd_f16:
-                    split_gemm.split16(w_ih, split_gemm.W_SCALE, split_gemm.H_B, out=fwd16)
-                tr16 = None
-                if training:
-                    hip.transpose_batched(w_ih.view(1, gh2, -1), out=scratch.view(1, -1, gh2))
-                    split_gemm.split(scratch, split_gemm.A_ORDER, out=tr)
-                    if self.fwd_f16 and self.bwd_f16:
-                        if name + '/t16' not in bufs:
-                            bufs[name + '/t16'] = split_gemm.empty16(w_ih.shape[1], gh2,
-                                                                     split_gemm.H_B, self.device)
-                        tr16 = split_gemm.split16(scratch, split_gemm.W_SCALE, split_gemm.H_B,
-                                                  out=bufs[name + '/t16'])
-                self._w_split[name] = (fwd, tr if training else None,
-                                       fwd16 if self.fwd_f16 else None, tr16)
+            for i, name, w_ih in jobs:
+                cols = w_ih.shape[1]
+                pieces = _WeightPieces(self, name, w_ih, training)
+                if f16_form(i, name):
+                    pieces.fwd16 = split_gemm.split16(
+                        w_ih, split_gemm.W_SCALE, split_gemm.H_B,
+                        out=buf(name + '/f16', lambda: split_gemm.empty16(
+                            gh2, cols, split_gemm.H_B, self.device)))
+                    # the layer's gradient GEMMs take the fp16 form as well when its OUTPUT has
+                    # fp16 pieces (the next layer's input / dense4's): else the bf16 pieces of
+                    # the transpose are needed - made on demand
+                    above_f16 = f16_form(i + 1, 'rnn{}'.format(i + 1)) \
+                        if i + 1 < cfg.num_layers_rnn else dense4_f16
+                    if training and self.bwd_f16 and above_f16:
+                        scratch = buf(name + '/t', lambda: torch.empty(
+                            (cols, gh2), dtype=torch.float32, device=self.device))
+                        hip.transpose_batched(w_ih.view(1, gh2, -1), out=scratch.view(1, -1, gh2))
+                        pieces.tr16 = split_gemm.split16(
+                            scratch, split_gemm.W_SCALE, split_gemm.H_B,
+                            out=buf(name + '/t16', lambda: split_gemm.empty16(
+                                cols, gh2, split_gemm.H_B, self.device)))
+                else:
+                    pieces.make_fwd(buf(name + '/bf16', lambda: split_gemm.empty(
+                        gh2, cols, split_gemm.B_ORDER, self.device)))
+                    if training:
+                        pieces.make_tr(
+                            buf(name + '/tbf16', lambda: split_gemm.empty(
+                                cols, gh2, split_gemm.A_ORDER, self.device)),
+                            buf(name + '/t', lambda: torch.empty(
+                                (cols, gh2), dtype=torch.float32, device=self.device)))
+                self._w_split[name] = pieces
             if dense4:
-                if 'dense4' not in bufs:
-                    bufs['dense4'] = (
-                        torch.empty((6,) + tuple(k4.shape), dtype=torch.bfloat16,
-                                    device=self.device),
-                        split_gemm.empty(k4.shape[0], k4.shape[1], split_gemm.A_ORDER,
-                                         self.device),
-                        torch.empty((3,) + tuple(k4.shape), dtype=torch.float16,
-                                    device=self.device))
-                stacked, by_row, stacked16 = bufs['dense4']
-                split_gemm.split_rows_stacked(k4, split_gemm.B_ORDER, out=stacked)
-                if self.fwd_f16:
+                pieces = _WeightPieces(self, 'dense4', k4, training)
+                if dense4_f16:
+                    stacked16 = buf('dense4/f16', lambda: torch.empty(
+                        (3,) + tuple(k4.shape), dtype=torch.float16, device=self.device))
                     split_gemm.split16_rows_stacked(k4, split_gemm.W_SCALE, split_gemm.H_B,
                                                     out=stacked16)
-                if training:
-                    split_gemm.split(k4, split_gemm.A_ORDER, out=by_row)
-                self._w_split['dense4'] = (stacked.view(-1, k4.shape[1]),
-                                           by_row if training else None,
-                                           stacked16.view(-1, k4.shape[1]) if self.fwd_f16
-                                           else None, None)
+                    pieces.fwd16 = stacked16.view(-1, k4.shape[1])
+                else:
+                    pieces.make_fwd(buf('dense4/bf16', lambda: torch.empty(
+                        (6,) + tuple(k4.shape), dtype=torch.bfloat16, device=self.device)))
+                if training:        # (dense4's gradients keep the bf16 form: dz has no bound)
+                    pieces.make_tr(buf('dense4/tbf16', lambda: split_gemm.empty(
+                        k4.shape[0], k4.shape[1], split_gemm.A_ORDER, self.device)), None)
+                self._w_split['dense4'] = pieces
             self._w_split_ready = torch.cuda.Event()
             self._w_split_ready.record(side)
 
     def _weight_split(self, name, backward=False):
-        """(forward pieces, backward pieces) of a weight, or None: fp32 GEMMs for this layer."""
+        """The `_WeightPieces` of a weight, or None: fp32 GEMMs for this layer.  Indexable like the
+        tuple it replaces: [0] bf16 pieces for the forward product, [1] for the data gradient,
+        [2] / [3] the fp16 ones (None where the fp16 form does not apply); [0] and [1] are made
+        on first use when they were not built ahead."""
         got = self._w_split.get(name)
         if got is None:
             return None
         if self._w_split_ready is not None:
             torch.cuda.current_stream(self.device).wait_event(self._w_split_ready)
-        if backward and got[1] is None:     # a backward pass after an evaluation-mode forward
-            p = self.arena.p
-            if name == 'dense4':
-                back = split_gemm.split(p['dense4/kernel'], split_gemm.A_ORDER)
-            else:
-                w_ih = p[name + '/w_ih']
-                w_ih = w_ih.view(w_ih.shape[0] * w_ih.shape[1], -1)
-                back = split_gemm.split(w_ih.t().contiguous(), split_gemm.A_ORDER)
-            got = self._w_split[name] = (got[0], back, got[2], got[3])
         return got
 
     # ------------------------------------------------------------------ forward
@@ -1321,13 +1439,30 @@ class CTCModel:
         self.backward(reduce_hook)
         return loss
 
+    def step_guard(self):
+        """int32[2] device tensor for `apply_gradients(skip=...)`: [0] != 0 when the gradients
+        of the last `forward_backward` must not be applied - a CTC status word set (infeasible
+        alignment / bad labels: where ``tf.nn.ctc_loss`` raises), a non-finite loss, or a
+        persistent recurrence kernel that gave up at a barrier - decided on the device, so the
+        host may find out later (deferred checks) without the parameters having been touched;
+        [1] = the recurrence time-out words (`engine.Trainer` copies this to pinned memory)."""
+        acts, cfg = self._acts, self.cfg
+        words = (0, 0)
+        if acts is not None and hip.rnn_persistent_supported(cfg.cell, acts['t_out'],
+                                                             acts['batch'], cfg.num_units_rnn):
+            words = hip.rnn_timeout_words(cfg.cell, acts['rnn_ws'], acts['t_out'], acts['batch'],
+                                          cfg.num_units_rnn)
+        return hip.step_guard(self.last_status, self.last_per_utterance_loss, words)
+
     def apply_gradients(self, learning_rate=1e-5, beta1=0.9, beta2=0.999, epsilon=1e-8,
-                        grad_scale=1.0):
-        """TensorFlow-form Adam over the whole arena in one launch (``asr/model.py:80-83``)."""
+                        grad_scale=1.0, skip=None):
+        """TensorFlow-form Adam over the whole arena in one launch (``asr/model.py:80-83``).
+        ``skip``: the device flag of `step_guard` - parameters and moments stay untouched when
+        it is set (the step counter still advances)."""
         self.step_count += 1
         a = self.arena
         hip.adam_step(a.param, a.grad, a.m, a.v, self.step_count, learning_rate, beta1, beta2,
-                      epsilon, grad_scale)
+                      epsilon, grad_scale, skip=skip)
 
     # ------------------------------------------------------------------ estimator-style entry
     def model_fn(self, features, labels, mode, learning_rate=1e-5, adam=(0.9, 0.999, 1e-8)):

@@ -396,7 +396,32 @@ int ctcasr_gemm_split_tn(const float *a, int64_t lda, const float *b, int64_t ld
  * all-reduce). */
 int ctcasr_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr,
                      float beta1, float beta2, float epsilon, int64_t step, float grad_scale,
-                     ctcasr_stream_t stream);
+                     const int32_t *skip, ctcasr_stream_t stream);
+/* ABI v5: `skip` (optional device word): the launch leaves param, m and v untouched when it is
+ * non-zero - a step whose gradients are known to be invalid never reaches the parameters, without
+ * the host having to look first.  ctcasr_step_guard fills it:
+ *   skip[0] = any ctc_status[b] != 0 (tf.nn.ctc_loss would have raised, asr/model.py:259)
+ *             | any per_utterance_loss[b] not finite | any persistent-recurrence time-out word
+ *             (device pointers to the sticky words of up to two row blocks of the workspace,
+ *             ctcasr_rnn_timeout_word_offset; either may be NULL);
+ *   skip[1] = the time-out words or-ed together (the host can poll this copy asynchronously -
+ *             ctcasr_rnn_poll_error synchronises). */
+int ctcasr_step_guard(const int32_t *ctc_status, const float *per_utterance_loss, int batch,
+                      const uint32_t *timeout_word0, const uint32_t *timeout_word1, int32_t *skip,
+                      ctcasr_stream_t stream);
+/* byte offset inside the recurrence workspace of the sticky time-out word of row block `block`
+ * (0 .. (B - 1) / 32), or (size_t)-1 when (cell, T, B, H) runs the streaming kernels / there is
+ * no such block */
+size_t ctcasr_rnn_timeout_word_offset(int cell, int T, int B, int H, int block);
+/* DIAGNOSTIC (ABI v5): `workgroups` (1..256) workgroups of 256 threads that hold their CUs for
+ * `busy_us` (<= 100 ms) and touch no memory - the CU footprint of a collective's ring kernels, for
+ * measuring on ONE GPU what such kernels cost beside the persistent recurrences (NCCL / RCCL
+ * refuse two ranks on one device).  Not used by the training path. */
+int ctcasr_occupy_cus(int workgroups, int busy_us, ctcasr_stream_t stream);
+/* max_bits[0] = max(max_bits[0], bit pattern of max |x[i]|) (atomicMax; the caller zeroes it):
+ * range guard of operands that go to the fp16 matrix pipe under a FIXED scale (the input
+ * projections' weights, split_gemm.py) */
+int ctcasr_absmax(const float *x, int64_t n, uint32_t *max_bits, ctcasr_stream_t stream);
 
 /* ---- K1: feature extraction ----------------------------------------------------------------
  * Replaces python_speech_features.logfbank / mfcc / delta + the post-processing of load_sample

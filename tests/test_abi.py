@@ -69,7 +69,14 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.ctcasr_set_option(b'rnn_fwd_half_chip', 1) == -1
     assert lib.ctcasr_set_option(b'rnn_kernel_events', 0) == 0
     assert lib.ctcasr_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0,
-                                None) == -1
+                                None, None) == -1
+    # flag 64 is not a variant bit (16 = CTCASR_RNN_F16 is)
+    assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
+                                    0, 0, 8, 16, None) == -1             # (null pointers)
+    assert lib.ctcasr_step_guard(None, None, 4, None, None, None, None) == -1
+    assert lib.ctcasr_absmax(None, 4, None, None) == -1
+    assert lib.ctcasr_colscale_from_max(None, 4, None, None, None) == -1
+    assert lib.ctcasr_rnn_bwd_f16_supported(2, 8, 2, 64, 16) == 0
     # workspace sizing is pure host arithmetic
     need = lib.ctcasr_ctc_loss_workspace_bytes(500, 16, 29, 150)
     assert need >= 500 * 16 * 301 * 8 + 500 * 16 * 29 * 4

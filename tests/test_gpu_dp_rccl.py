@@ -225,3 +225,52 @@ def test_bench_two_ranks_on_one_gpu_report_both_release_modes():
         assert 'exposed_allreduce_ms' in info
     assert line['allreduce']['chosen'] in modes
     assert line['allreduce']['stubbed_ms_per_step'] > 0
+
+
+@pytest.mark.parametrize('early', [False, True])
+def test_collective_shaped_kernels_beside_the_persistent_recurrences(early):
+    """The first N > 1 run must not be the first time resident, non-yielding workgroups share
+    the chip with the persistent recurrences.  NCCL refuses two ranks on one
+    device, so the stand-in: every gradient bucket launches a kernel of 24 workgroups that holds
+    its CUs for bytes / 150 GB/s on a stream of its own, ordered and waited for exactly like an
+    asynchronous all-reduce (`GradientReducer(stand_in=)`), in both release modes - beside the
+    128-CU backward recurrences (early) / behind the last of them and in front of the next step's
+    whole-chip forward recurrence (held).  DS2 2 x BiLSTM-1024 at batch 32 (the two-tile kernels):
+    no recurrence time-out, the losses of the plain run bit for bit (nothing touches the
+    gradients), several launches per step; the step-time inflation is printed (DESIGN.md 6 quotes
+    bench.py --collective-stand-in for the C3 figure)."""
+    from ctc_asr_amd.engine import Trainer
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=2, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0)
+    rng = np.random.default_rng(8)
+    feats = torch.tensor(rng.normal(size=(32, 399, 80)).astype(np.float32), device='cuda')
+    flen = torch.full((32,), 399, dtype=torch.int32)
+    labels = CTCModel.pack_labels([list(rng.integers(1, 28, size=40)) for _ in range(32)], 'cuda')
+
+    def run(stand_in):
+        trainer = Trainer(cfg, device='cuda', seed=2, allreduce_early=early,
+                          collective_stand_in=stand_in)
+        assert trainer.release == ('early' if early else 'held')
+        losses = []
+        for _ in range(2):
+            trainer.train_step(feats, flen, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            losses.append(trainer.train_step(feats, flen, labels))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 6 * 1e3
+        trainer.drain_checks()                      # raises on a recurrence time-out
+        return torch.stack(losses).cpu().numpy(), ms, trainer.reducer.launched
+
+    plain, plain_ms, launched0 = run(None)
+    busy, busy_ms, launched = run((24, 150.0))
+    assert launched0 == 0 and launched >= 8 * 2
+    assert np.isfinite(busy).all()
+    # (the step itself is deterministic to fp32 summation order only: atomics in the CTC gradient)
+    assert np.abs(busy - plain).max() < 1e-4 * np.abs(plain).max()
+    print('collective stand-in, {} release: {:.2f} -> {:.2f} ms per step ({} launches)'.format(
+        'early' if early else 'held', plain_ms, busy_ms, launched))
+    assert busy_ms < plain_ms * 1.5

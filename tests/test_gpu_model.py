@@ -335,6 +335,70 @@ def test_assembled_c3_model_batch_32():
                     'rnn4/w_ih', 'rnn4/b_ih', 'dense4/kernel', 'logits/bias'))
 
 
+@pytest.mark.timeout(1200)
+def test_assembled_c3_model_at_the_benchmark_shape():
+    """The shape `bench.py` times (BASELINE configs[2]: DS2 2-conv + 5 x BiLSTM-1024, batch 32,
+    999 frames -> T' = 500, 150 labels per utterance) through the default path - fp16-split
+    projection GEMMs, both recurrences on the fp16 matrix pipe - against the float64 torch
+    restatement: logits and loss to 1e-3, greedy strings identical, and the gradients of the
+    bottom layer's input weights, the top layer's recurrent weights and the first convolution
+    (each has crossed the whole depth x length of the stack in one direction or the other) to
+    1e-3 of their largest element."""
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=5, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0)
+    model = _assembled_against_torch_ref(
+        cfg, batch=32, frames=999, label_len=150, seed=23,
+        grad_names=('conv0/kernel', 'conv1/kernel', 'rnn0/w_ih', 'rnn0/w_hh', 'rnn2/w_hh',
+                    'rnn4/w_hh', 'rnn4/w_ih', 'rnn4/b_ih', 'dense4/kernel', 'logits/kernel'))
+    what = model.arithmetic()
+    assert what['rnn0/input_projection'] == what['rnn4/input_projection'] == 'fp16x3'
+    assert what['rnn2/recurrence_fwd'] == what['rnn2/recurrence_bwd'] == 'fp16x3'
+
+
+@pytest.mark.timeout(900)
+def test_fifty_training_steps_track_the_all_fp32_path(monkeypatch):
+    """Drift: 50 Adam steps of the C3 model at the benchmark's shape on the same batch, once
+    through the default arithmetic (fp16 / bf16 pieces on the 16-bit matrix pipe for the
+    projection GEMMs and both recurrences) and once with every product on the fp32 pipe
+    (CTCASR_SPLIT_GEMM=0, CTCASR_RNN_FWD_F16=0, CTCASR_RNN_BWD_F16=0): the loss trajectories
+    agree to 1e-3 relative at every step (they start bit-close and part only as fast as fp32
+    round-off of either path is amplified by training itself)."""
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=5, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0)
+    rng = np.random.default_rng(29)
+    feats = torch.tensor(rng.normal(size=(32, 999, 80)).astype(np.float32), device='cuda')
+    flen = torch.full((32,), 999, dtype=torch.int32)
+    labels = CTCModel.pack_labels([list(rng.integers(1, 28, size=150)) for _ in range(32)], 'cuda')
+
+    def trajectory(fp32_everything):
+        for name in ('CTCASR_SPLIT_GEMM', 'CTCASR_RNN_FWD_F16', 'CTCASR_RNN_BWD_F16'):
+            if fp32_everything:
+                monkeypatch.setenv(name, '0')
+            else:
+                monkeypatch.delenv(name, raising=False)
+        model = CTCModel(cfg, 'cuda', seed=3)
+        assert model.split_gemm != fp32_everything and model.rnn_bwd_f16 != fp32_everything
+        losses = []
+        for _ in range(50):
+            losses.append(model.forward_backward(feats, flen, labels, check=False))
+            model.apply_gradients(learning_rate=1e-4)
+        model.check_rnn_error()
+        form = model.arithmetic()['rnn2/recurrence_bwd']
+        assert form == ('fp32' if fp32_everything else 'fp16x3')
+        out = torch.stack(losses).double().cpu().numpy()
+        del model
+        torch.cuda.empty_cache()
+        return out
+
+    split, plain = trajectory(False), trajectory(True)
+    assert np.isfinite(split).all() and np.isfinite(plain).all()
+    assert plain[-1] < 0.9 * plain[0]                      # it does train
+    rel = np.abs(split - plain) / np.abs(plain)
+    assert rel.max() < 1e-3, (int(rel.argmax()), float(rel.max()))
+
+
 def test_assembled_reference_default_model():
     """The reference's own flag defaults (asr/params.py): 3 convolutions (32, 32, 96) + 4 x
     bidirectional ReLU-RNN-2048 + dense 2048, batch 16, at T' = 40."""

@@ -197,13 +197,95 @@ def test_deferred_checks_still_raise_where_tensorflow_raises():
     bad = [[1, 2, 3], list(range(1, 14))]                                      # 13 labels > 11
     trainer.train_step(feats, flen, good)
     trainer.drain_checks()
+    before = trainer.model.arena.param.clone()
+    moments = trainer.model.arena.m.clone(), trainer.model.arena.v.clone()
     trainer.train_step(feats, flen, bad)            # does not raise here: the check is deferred
+    # ... but its update never reached the parameters or the moments: the Adam launch dropped it
+    # on the device (nothing is applied from a step that is known to be invalid)
+    torch.cuda.synchronize()
+    assert torch.equal(trainer.model.arena.param, before)
+    assert torch.equal(trainer.model.arena.m, moments[0])
+    assert torch.equal(trainer.model.arena.v, moments[1])
     with pytest.raises(InfeasibleAlignmentError, match=r'batch rows \[1\].*training step 2'):
         trainer.drain_checks()
     trainer.drain_checks()                          # reported once
+    trainer.train_step(feats, flen, good)           # a valid step moves them again
+    torch.cuda.synchronize()
+    assert not torch.equal(trainer.model.arena.param, before)
+    trainer.drain_checks()
     # without a drain the error surfaces from a later train_step, within max_steps_ahead + 1
     trainer.train_step(feats, flen, bad)
     with pytest.raises(InfeasibleAlignmentError):
         for _ in range(trainer.max_steps_ahead + 1):
             trainer.train_step(feats, flen, good)
             torch.cuda.synchronize()
+
+
+def test_step_guard_words():
+    """`ctcasr_step_guard`: the skip word is set by a CTC status word, by a non-finite loss and by
+    a recurrence time-out word, and only then; `adam_step(skip=)` honours it."""
+    from ctc_asr_amd import hip
+    hip.load()
+    status = torch.zeros(5, dtype=torch.int32, device='cuda')
+    loss = torch.ones(5, device='cuda')
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert hip.step_guard(status, loss).tolist() == [0, 0]
+    assert hip.step_guard(status, loss, (word.data_ptr(), 0)).tolist() == [0, 0]
+    word.fill_(1)
+    assert hip.step_guard(status, loss, (0, word.data_ptr())).tolist() == [1, 1]
+    status[3] = 1
+    assert hip.step_guard(status, loss).tolist() == [1, 0]
+    status.zero_()
+    loss[4] = float('inf')
+    assert hip.step_guard(status, loss).tolist() == [1, 0]
+    loss[4] = float('nan')
+    assert hip.step_guard(status, loss).tolist() == [1, 0]
+    p, g = torch.ones(1000, device='cuda'), torch.ones(1000, device='cuda')
+    m, v = torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
+    hip.adam_step(p, g, m, v, 1, lr=0.1, skip=torch.tensor([1, 0], dtype=torch.int32, device='cuda'))
+    assert float(p.min()) == 1.0 and float(m.abs().max()) == 0.0
+    hip.adam_step(p, g, m, v, 1, lr=0.1, skip=torch.tensor([0, 7], dtype=torch.int32, device='cuda'))
+    assert float(p.max()) < 1.0 and float(m.min()) > 0.0
+
+
+def test_out_of_range_weights_take_the_bf16_form(monkeypatch):
+    """The fp16 form of the projection GEMMs scales W_ih by a FIXED 2^11 (|w| < 29).  Nothing
+    bounds a weight: the model finds every matrix's largest magnitude on the device and a matrix
+    outside half of that range takes the bf16 form (fp32's exponent range) - it never becomes
+    inf.  One weight of 40 in the second layer: that layer's projections report 'bf16x6', the
+    loss is finite and equals the all-fp32-GEMM step's; the fp16 split kernel itself saturates."""
+    from ctc_asr_amd import hip, split_gemm
+    from ctc_asr_amd.model import CTCModel, ModelConfig, init_params
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=2, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0)
+    flat = init_params(cfg, 4)
+    flat['rnn1/w_ih'][1, 17, 5] = 40.0
+    rng = np.random.default_rng(4)
+    feats = torch.tensor(rng.normal(size=(8, 199, 80)).astype(np.float32))
+    flen = torch.full((8,), 199, dtype=torch.int32)
+    labels = [list(rng.integers(1, 28, size=20)) for _ in range(8)]
+    model = CTCModel(cfg, 'cuda', params=flat)
+    loss = float(model.forward_backward(feats, flen, labels))
+    what = model.arithmetic()
+    assert what['rnn0/input_projection'] == 'fp16x3' and what['rnn1/input_projection'] == 'bf16x6'
+    assert np.isfinite(loss) and torch.isfinite(model.arena.grad).all()
+    monkeypatch.setenv('CTCASR_SPLIT_GEMM', '0')
+    plain = CTCModel(cfg, 'cuda', params=flat)
+    assert not plain.split_gemm
+    loss_plain = float(plain.forward_backward(feats, flen, labels))
+    assert abs(loss - loss_plain) <= 2e-6 * abs(loss_plain)
+    rel = float((model.arena.g['rnn1/w_ih'] - plain.arena.g['rnn1/w_ih']).norm() /
+                plain.arena.g['rnn1/w_ih'].norm())
+    assert rel < 5e-4, rel
+    # a weight that GROWS out of range is noticed from the maxima of an earlier step
+    model.arena.p['rnn0/w_ih'][0, 3, 3] = 100.0
+    for _ in range(4):
+        model.forward_backward(feats, flen, labels)
+        torch.cuda.synchronize()
+    assert model.arithmetic()['rnn0/input_projection'] == 'bf16x6'
+    # the split kernel saturates instead of producing inf
+    x = torch.tensor([[1e3, -1e3, 40.0, 1.0, 0.0, 0.0, 0.0, 0.0]], device='cuda')
+    pieces = hip.split_f16(x, split_gemm.W_SCALE, split_gemm.H_B)
+    assert torch.isfinite(pieces.float()).all()
+    assert float(pieces[0, 0, 0]) == 65504.0 and float(pieces[0, 0, 1]) == -65504.0

@@ -56,7 +56,7 @@ def main(src, workload, out_md):
                                             'batched_transpose', 'vectorized_elementwise',
                                             'reduce_kernel', 'transpose_kernel'))]
     entries, traffic_text = [], []
-    for which, pattern in (('rnn_bwd', 'prnn_bwd_kernel'), ('rnn_fwd', 'prnn_fwd_kernel')):
+    for which, pattern in (('rnn_bwd', 'prnn_bwd'), ('rnn_fwd', 'prnn_fwd')):
         f_kb, w_kb = value(fetch, pattern, 'FETCH_SIZE'), value(write, pattern, 'WRITE_SIZE')
         if f_kb is None or w_kb is None:
             continue

@@ -757,6 +757,89 @@ def measure_c5(args, rank, local_rank, world):
     return result
 
 
+def measure_c5_from_disk(args, local_rank, utterances=416, repeat=8, log_frequency=200):
+    """`train.py`'s own loop over a corpus ON DISK: C5-shaped utterances
+    (0.7 - 17 s, LibriSpeech-like) written as WAV + CSV in the reference's layout to a temporary
+    directory - ``utterances`` files, each listed ``repeat`` times in the manifest so that an
+    epoch has about as many steps as the reference's logging period - driven through
+    ``input_fn_generator('train_bucket')`` - CSV, WAV headers, shuffle buffer, buckets, reader
+    pool, pinned uploads, features on the GPU - and `train.train_epoch` with the reference's
+    logging cadence (``log_frequency`` = 200, asr/params.py:114: the first step and every 200th:
+    loss read-back, beam-64 decode of the batch, edit distance / WER, summary records).  One
+    untimed epoch (allocator, page cache), then the SAME batches once from HBM (raw PCM kept on the
+    device, the step `measure_c5` times) and once more through the whole pipeline (same shuffle
+    seed).  ``value`` = audio seconds of the epoch / its wall time; ``ratio_to_in_hbm`` is the
+    number the item asks for (>= 0.9)."""
+    import tempfile
+    from ctc_asr_amd import hip, summaries, synth, train
+    from ctc_asr_amd.engine import Trainer
+    from ctc_asr_amd.input_functions import input_fn_generator
+    from ctc_asr_amd.model import ModelConfig
+    from ctc_asr_amd.params import CSV_DELIMITER, CSV_FIELDNAMES, FLAGS
+    device = 'cuda:{}'.format(local_rank)
+    filters, layers, hidden, dense, batch, _, rnn_cell = WORKLOADS['c5']
+    with tempfile.TemporaryDirectory() as tmp:
+        corpus, csv = os.path.join(tmp, 'corpus'), os.path.join(tmp, 'train.csv')
+        rng = np.random.default_rng(77)
+        rows = synth.write_corpus(corpus, csv,
+                                  synth.librispeech_like_durations(rng, utterances, drop=True),
+                                  seed=78, subdir='train', sacrificial_row=False)
+        with open(csv, 'w', encoding='utf-8') as handle:      # every file `repeat` times, by length
+            handle.write(CSV_DELIMITER.join(CSV_FIELDNAMES) + '\n')
+            for row in [r for r in rows for _ in range(repeat)] + [rows[-1]]:
+                handle.write(CSV_DELIMITER.join(row) + '\n')
+        FLAGS.reset()
+        FLAGS.update(corpus_dir=corpus, train_csv=csv, train_dir=os.path.join(tmp, 'ckpt'),
+                     batch_size=batch, num_buckets=8, feature_type='mel',
+                     feature_normalization='local', beam_width=C5_BEAM_WIDTH,
+                     log_frequency=log_frequency, random_seed=5)
+        cfg = ModelConfig(used_model='ds2', conv_filters=filters, num_units_dense=dense,
+                          num_layers_rnn=layers, num_units_rnn=hidden, rnn_cell=rnn_cell,
+                          cudnn=True, dense_dropout_rate=args.dropout, beam_width=C5_BEAM_WIDTH)
+        trainer = Trainer(cfg, device=device, seed=0)
+        kept = []
+        for item in input_fn_generator('train_bucket', device=device, seed=11)():      # epoch A
+            trainer.train_step(item.features['spectrogram'], item.features['spectrogram_length'],
+                               item.packed_labels)
+            kept.append((item.pcm, item.num_samples, item.packed_labels, item.audio_seconds))
+        torch.cuda.synchronize()
+        trainer.drain_checks()
+
+        def replay():
+            for pcm, nsamp, labels, _ in kept:
+                feats, lengths = hip.features(pcm, nsamp, 'mel', 'local', False, 16000)
+                trainer.train_step(feats, lengths, labels)
+        replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        replay()
+        torch.cuda.synchronize()
+        in_hbm_s = time.perf_counter() - t0
+        trainer.drain_checks()
+        writer = summaries.SummaryWriter(FLAGS.train_dir, 'train')
+        t0 = time.perf_counter()
+        steps, _ = train.train_epoch(trainer, 'train_bucket', 2, 0, 1, writer, seed=11)
+        torch.cuda.synchronize()
+        disk_s = time.perf_counter() - t0
+        FLAGS.reset()
+    audio_s = sum(k[3] for k in kept)
+    assert steps == len(kept)
+    del trainer
+    torch.cuda.empty_cache()
+    return {'value': round(audio_s / disk_s, 2), 'unit': 'audio-s/s', 'steps': steps,
+            'ms_per_step': round(disk_s / steps * 1e3, 3),
+            'in_hbm_value': round(audio_s / in_hbm_s, 2),
+            'ratio_to_in_hbm': round(in_hbm_s / disk_s, 4),
+            'config': {'wav_files_on_disk': utterances, 'manifest_rows': utterances * repeat,
+                       'batch': batch, 'num_buckets': 8,
+                       'log_frequency': log_frequency, 'beam_width_of_logged_decodes': C5_BEAM_WIDTH,
+                       'workload': 'BASELINE.json configs[4] on one GPU, corpus on disk: '
+                                   'train.train_epoch over input_fn_generator(\'train_bucket\')'},
+            'note': 'wall time of one epoch of train.py\'s loop incl. its logged steps (loss '
+                    'read-back, beam-64 decode, metrics, summary records) against the same batches '
+                    'stepped from raw PCM resident in HBM'}
+
+
 # ------------------------------------------------------------------------------ parity probe
 # small shape: 4 x 100 rows - enough for the model to take its split-GEMM path; the fall-back when
 # the host cannot finish the full-size oracle in time
@@ -1001,6 +1084,11 @@ def main():
     if args.workload == 'c5':
         result = measure_c5(args, rank, local_rank, world)
         cfg = frames = batch = seconds = None
+        if world == 1:
+            try:
+                other['c5_from_disk'] = measure_c5_from_disk(args, local_rank)
+            except Exception as err:        # noqa: BLE001
+                other['c5_from_disk'] = {'error': '{}: {}'.format(type(err).__name__, err)}
     elif world == 1:
         result, (cfg, frames, batch, seconds) = measure(args.workload, args, rank, local_rank,
                                                         world)
@@ -1050,6 +1138,10 @@ def main():
                                                  'roofline', 'host_enqueue_ms_per_step')}
         except Exception as err:        # noqa: BLE001
             other['c5'] = {'error': '{}: {}'.format(type(err).__name__, err)}
+        try:
+            other['c5_from_disk'] = measure_c5_from_disk(args, local_rank)
+        except Exception as err:        # noqa: BLE001
+            other['c5_from_disk'] = {'error': '{}: {}'.format(type(err).__name__, err)}
     if world == 1 and args.collective_stand_in and args.workload != 'c5':
         # one GPU cannot run RCCL beside itself; its CU footprint can be stood in for
         report = {'stand_in': '24 workgroups x 256 threads per bucket, resident for bytes / '

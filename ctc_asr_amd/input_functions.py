@@ -33,7 +33,7 @@ from ctc_asr_amd.csv_helper import get_bucket_boundaries, read_csv_rows
 from ctc_asr_amd.labels import ctoi
 from ctc_asr_amd.params import CSV_HEADER_LABEL, CSV_HEADER_PATH, FLAGS
 
-READER_THREADS = 4           # WAV files of one batch are read concurrently
+READER_THREADS = 8           # WAV files of one batch are read concurrently
 SUPPORTED_FEATURE_TYPES = ('mel', 'mfcc')
 SUPPORTED_NORMALIZATIONS = ('none', 'local', 'local_scalar')
 
@@ -110,6 +110,85 @@ def features_from_pcm(pcm_list, device='cuda', feature_type=None, feature_normal
                         FLAGS.features_drop_every_second_frame, FLAGS.sampling_rate)
 
 
+_RINGS = {}      # the live staging ring per (device, depth, batch size)
+
+
+class _StagingRing:
+    """Pinned host buffers of the reader thread, allocated ONCE per epoch iterator and reused
+    round-robin: allocating (or freeing) pinned memory synchronises with the device - a
+    `pin_memory()` per batch stalls the training steps in flight (measured: 16 ms per batch of the
+    input pipeline alone, 35 instead of 17 ms per C5 step).  A slot is reused only after the
+    upload that read it has finished (its event)."""
+
+    def __init__(self, slots, batch_rows):
+        self.slots = [{'pcm': None, 'small': torch.empty(1 << 16, dtype=torch.int32).pin_memory(),
+                       'event': None} for _ in range(slots)]
+        self.rows, self.next = batch_rows, 0
+
+    def take(self, samples):
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot['event'] is not None:
+            slot['event'].synchronize()
+        if slot['pcm'] is None or slot['pcm'].numel() < self.rows * samples:
+            # (grows to the longest batch seen: a handful of allocations per epoch, not one per
+            # batch; utterances are capped by the corpus filter - 17 s = 272 000 samples)
+            slot['pcm'] = torch.empty(self.rows * max(samples, 1 << 16), dtype=torch.int16) \
+                .pin_memory()
+        return slot
+
+
+class _Staged:
+    """One batch on its way to HBM: zero-padded int16 PCM, sample counts and the CTC labels in
+    their packed form, copied from PINNED host buffers with asynchronous copies on a stream of
+    their own.  A pageable `.to(device)` is a synchronous copy in stream order: it would stall the
+    host until the GPU has worked off everything enqueued before it - the previous training
+    steps - and with that the run-ahead that keeps the GPU fed (train.py from disk ran 35 % under
+    the same steps from HBM).  Built by the reader thread; the consumer makes
+    its stream wait for ``ready`` and never blocks."""
+
+    def __init__(self, items, device, stream, ring=None):
+        pcm = [it[0] for it in items]
+        lengths = np.array([len(p) for p in pcm], dtype=np.int32)
+        width = int(lengths.max())
+        rows = [list(it[1]) for it in items]
+        offsets = np.zeros(len(rows) + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum([len(r) for r in rows])
+        flat = np.array([v for r in rows for v in r] or [0], dtype=np.int32)
+        if ring is None:
+            ring = _StagingRing(1, len(pcm))
+        slot = ring.take(width) if len(pcm) <= ring.rows else _StagingRing(1, len(pcm)).take(width)
+        host_pcm = slot['pcm'][:len(pcm) * width].view(len(pcm), width)
+        view = host_pcm.numpy()
+        for row, samples in enumerate(pcm):
+            view[row, :len(samples)] = samples
+            view[row, len(samples):] = 0
+        small = slot['small']
+        need = len(lengths) + len(flat) + len(offsets)
+        if small.numel() < need:
+            small = slot['small'] = torch.empty(2 * need, dtype=torch.int32).pin_memory()
+        cuts = np.cumsum([0, len(lengths), len(flat), len(offsets)])
+        packed = small.numpy()
+        for lo, hi, part in zip(cuts[:-1], cuts[1:], (lengths, flat, offsets)):
+            packed[lo:hi] = part
+        with torch.cuda.stream(stream):
+            self.pcm = host_pcm.to(device, non_blocking=True)
+            small_d = small[:need].to(device, non_blocking=True)
+            self.ready = torch.cuda.Event()
+            self.ready.record(stream)
+        slot['event'] = self.ready
+        self.num_samples = small_d[cuts[0]:cuts[1]]
+        self.packed_labels = (small_d[cuts[1]:cuts[2]], small_d[cuts[2]:cuts[3]],
+                              max([len(r) for r in rows] + [1]), rows)
+        self._keep = small_d
+        label_width = max(len(r) for r in rows)
+        self.labels = np.zeros((len(rows), max(label_width, 1)), dtype=np.int32)
+        for row, ids in enumerate(rows):
+            self.labels[row, :len(ids)] = ids
+        self.texts = [it[2] for it in items]
+        self.seconds = float(lengths.sum()) / FLAGS.sampling_rate
+
+
 def load_sample(file_path, feature_type=None, feature_normalization=None, device='cuda'):
     """Load a WAV file and convert it into feature vectors: (f32[T, 80] ndarray, int32 scalar).
 
@@ -130,27 +209,39 @@ def read_manifest(csv_path):
 
 class Batch:
     """One minibatch: ``features`` dict + dense zero-padded ``labels`` like the reference's
-    ``input_fn`` output (``asr/input_functions.py:112-120``), tensors already in HBM."""
+    ``input_fn`` output (``asr/input_functions.py:112-120``), tensors already in HBM.
+    ``packed_labels``: the same labels as `CTCModel.pack_labels` would upload them (what
+    `Trainer.train_step` / `loss_fn` take without another host-to-device copy); ``pcm`` /
+    ``num_samples``: the raw audio the features were computed from (device tensors)."""
 
-    def __init__(self, spectrogram, spectrogram_length, label_plaintext, labels, seconds):
+    def __init__(self, spectrogram, spectrogram_length, label_plaintext, labels, seconds,
+                 packed_labels=None, pcm=None, num_samples=None):
         self.features = {'spectrogram': spectrogram, 'spectrogram_length': spectrogram_length,
                          'label_plaintext': label_plaintext}
         self.labels = labels
         self.audio_seconds = seconds
+        self.packed_labels = packed_labels if packed_labels is not None else labels
+        self.pcm, self.num_samples = pcm, num_samples
 
     def __iter__(self):      # (features, labels) = batch
         return iter((self.features, self.labels))
 
 
-def _make_batch(items, device):
-    pcm = [it[0] for it in items]
-    feats, lengths = features_from_pcm(pcm, device)
-    width = max(len(it[1]) for it in items)
-    labels = np.zeros((len(items), max(width, 1)), dtype=np.int32)
-    for row, it in enumerate(items):
-        labels[row, :len(it[1])] = it[1]
-    seconds = float(sum(len(p) for p in pcm)) / FLAGS.sampling_rate
-    return Batch(feats, lengths, [it[2] for it in items], labels, seconds)
+def _make_batch(items, device, staged=None):
+    """Features of one batch on the current stream.  ``staged``: the batch's `_Staged` uploads
+    (made by the reader thread); without it they are made here."""
+    if staged is None:
+        staged = _Staged(items, device, torch.cuda.current_stream(device))
+    main = torch.cuda.current_stream(device)
+    main.wait_event(staged.ready)
+    for tensor in (staged.pcm, staged._keep):
+        tensor.record_stream(main)          # allocated on the upload stream, used on this one
+    feature_type, feature_normalization = _check_feature_args(None, None)
+    feats, lengths = hip.features(staged.pcm, staged.num_samples, feature_type,
+                                  feature_normalization, FLAGS.features_drop_every_second_frame,
+                                  FLAGS.sampling_rate)
+    return Batch(feats, lengths, staged.texts, staged.labels, staged.seconds,
+                 staged.packed_labels, staged.pcm, staged.num_samples)
 
 
 def _example_stream(csv_path, shuffle, rng):
@@ -255,27 +346,40 @@ def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, p
 
         if prefetch <= 0:
             for items in host_side():
-                yield _make_batch(items, device)
+                yield _make_batch(items, torch.device(device) if torch.device(device).index
+                                  is not None else torch.device('cuda', torch.cuda.current_device()))
             return
-        # WAV reading / label encoding run ahead on a host thread (the reference's prefetch(64))
+        # WAV reading, label packing and the uploads run ahead on a host thread (the reference's
+        # prefetch(64)): pinned staging buffers, asynchronous copies on an upload stream
         pending = queue.Queue(maxsize=prefetch)
         done = object()
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        upload = torch.cuda.Stream(dev)
+        # (queue + producer + consumer; kept across epochs: pinned allocations cost up to 80 ms)
+        key = (str(dev), prefetch + 3, FLAGS.batch_size)
+        ring = _RINGS.get(key)
+        if ring is None:
+            _RINGS.clear()
+            ring = _RINGS[key] = _StagingRing(prefetch + 3, FLAGS.batch_size)
 
         def producer():
             try:
+                torch.cuda.set_device(dev)
                 for items in host_side():
-                    pending.put(items)
+                    pending.put((items, _Staged(items, dev, upload, ring)))
                 pending.put(done)
             except BaseException as exc:      # surface reader errors in the consumer
                 pending.put(exc)
 
         threading.Thread(target=producer, daemon=True).start()
         while True:
-            items = pending.get()
-            if items is done:
+            got = pending.get()
+            if got is done:
                 return
-            if isinstance(items, BaseException):
-                raise items
-            yield _make_batch(items, device)
+            if isinstance(got, BaseException):
+                raise got
+            yield _make_batch(got[0], dev, got[1])
 
     return input_fn

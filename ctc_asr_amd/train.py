@@ -29,21 +29,23 @@ class NanLossDuringTrainingError(RuntimeError):
     """Raised when the training loss is NaN or infinite."""
 
 
-def train_epoch(trainer, target, epoch, rank, world, writer=None):
+def train_epoch(trainer, target, epoch, rank, world, writer=None, seed=None):
     """One pass over ``target``.  Every ``FLAGS.log_frequency`` steps (and at the first step)
     rank 0 prints the reference's LoggerHook line and records the summaries the reference
     records: loss, learning rate, and - from a beam-search decode of the batch just trained on -
     mean edit distance, word error rate and ``num_samples_to_report`` decoded / original texts."""
     model = trainer.model
+    if seed is None and world > 1:      # (every rank must walk the same shuffled order)
+        seed = (FLAGS.random_seed or 1) * 1000 + epoch
     input_fn = input_fn_generator(target, device=model.device, rank=rank, world_size=world,
-                                  seed=(FLAGS.random_seed or 1) * 1000 + epoch if world > 1
-                                  else None)
+                                  seed=seed)
     logger = summaries.ThroughputLogger(FLAGS.log_frequency, FLAGS.batch_size * world)
     window_loss, steps = 0.0, 0
     for batch in input_fn():
         features, labels = batch
+        # (the labels as the reader thread has uploaded them: no host-to-device copy here)
         loss = trainer.train_step(features['spectrogram'], features['spectrogram_length'],
-                                  labels)
+                                  batch.packed_labels)
         steps += 1
         logger.add_audio(batch.audio_seconds * world)
         if model.step_count % FLAGS.log_frequency == 0 or steps == 1:

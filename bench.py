@@ -896,8 +896,11 @@ def _probe_gpu_side(cfg_kwargs, device, batch, frames, label_len, variants):
             setattr(model, key, value)
         logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(lengths),
                                              training=True)
-        loss = float(model.loss_fn(logits, seq_len, labels))
+        model.loss_fn(logits, seq_len, labels)
         model.check_rnn_error()
+        # (the mean of the fp32 per-utterance losses in float64: an fp32 mean of values near 1e3
+        # resolves 1.2e-4 and would hide what the variants differ by)
+        loss = float(model.last_per_utterance_loss.double().mean())
         out[name] = (loss, logits.cpu().numpy(), model.arithmetic())
         del model
         torch.cuda.empty_cache()

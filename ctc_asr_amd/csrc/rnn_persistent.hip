@@ -335,7 +335,9 @@ __global__ void resident_gate_kernel(SyncWords *sy, unsigned ticket, unsigned lo
     for (;;) {
         const unsigned seen = __hip_atomic_load(&sy->resident_ticket[0], __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
-        if (((seen - ticket) & 0xFFFFFFu) < 0x800000u) break;      // seen >= ticket (mod 2^24)
+        // seen >= ticket (mod 2^24); 0 = nothing posted yet (tickets are 1 .. 2^24 - 1: a freshly
+        // zeroed workspace must not pass a ticket above 2^23 at once)
+        if (seen != 0u && ((seen - ticket) & 0xFFFFFFu) < 0x800000u) break;
         if (wall_clock64() - start >= ticks) break;
         __builtin_amdgcn_s_sleep(8);
     }

@@ -549,6 +549,9 @@ extern "C" int ctcasr_rnn_resident_gate(void *workspace, size_t workspace_bytes,
     if (!workspace || workspace_bytes < ctcasr_rnn_workspace_bytes(cell, T, B, H))
         return CTCASR_ERR_WORKSPACE;
     if (!ctcasr_rnn_persistent_supported(cell, T, B, H) || max_wait_us == 0) return CTCASR_OK;
+    // (B = 33 .. 64: a pass runs as one launch per block of <= 32 rows, all carrying the ticket;
+    // the gate watches the FIRST block's words - work behind it overlaps every block, and may take
+    // CUs the later blocks need at their start: a late start, never a wrong result)
     return prnn_resident_gate(reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H), ticket,
                               max_wait_us, (hipStream_t)stream);
 }

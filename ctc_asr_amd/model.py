@@ -369,8 +369,11 @@ class CTCModel:
         self._ticket = 0
         # launches per persistent backward recurrence: the weight-gradient GEMMs of the steps one
         # launch has finished run beside the next launch instead of queueing up behind the layer.
-        # 0 = by batch: 2 launches up to 16 rows (C2: 22.8 ms per step against 23.1 with 3), 3
-        # above (C3: 97.7 against 102.8 with 2, 99.1 with 4)
+        # 0 = the default, 2 launches.  (Rounds 1 - 3 ran 3 above 16 rows: C3 97.7 ms per step
+        # against 102.8 with 2 and 99.1 with 4 when the GEMMs were fp32.  With the fp16 GEMMs and
+        # the fp16-pipe recurrence the side stream is as long as the recurrence itself and fewer,
+        # bigger GEMMs win: C3 55.6 - 55.9 ms with 2 against 56.8 - 56.9 with 3, and 60 launches
+        # fewer per step, profiles/r04_ab.md)
         self.bwd_chunks = max(0, int(os.environ.get('CTCASR_BWD_CHUNKS', '0')))
         # launches per persistent FORWARD recurrence when the next layer's input projection is
         # pipelined with it on the other half of the chip (1 = off: whole-chip single launch)
@@ -585,16 +588,18 @@ class CTCModel:
             self._w_split_ready = torch.cuda.Event()
             self._w_split_ready.record(side)
 
-    def _weight_split(self, name, backward=False):
+    def _weight_split(self, name, backward=False, acts=None):
         """The `_WeightPieces` of a weight, or None: fp32 GEMMs for this layer.  Indexable like the
         tuple it replaces: [0] bf16 pieces for the forward product, [1] for the data gradient,
         [2] / [3] the fp16 ones (None where the fp16 form does not apply); [0] and [1] are made
         on first use when they were not built ahead."""
-        got = self._w_split.get(name)
+        pieces, ready = (self._w_split, self._w_split_ready) if acts is None else \
+            (acts['w_split'], acts['w_split_ready'])
+        got = pieces.get(name)
         if got is None:
             return None
-        if self._w_split_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._w_split_ready)
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
         return got
 
     # ------------------------------------------------------------------ forward
@@ -807,7 +812,10 @@ class CTCModel:
         acts.update(flat_split=flat_split, flat_of=x, flat_uses_split=k4_pieces is not None)
         logits = torch.mm(dense4, p['logits/kernel'])
         hip.bias_act_fwd(logits, p['logits/bias'], 0.0)
-        acts.update(rnn_flat=rnn_flat, dense4=dense4)
+        # (backward reads the pieces and the per-layer GEMM forms of THIS forward pass back from
+        # the activations, not from whatever a later forward pass of another shape / mode left)
+        acts.update(rnn_flat=rnn_flat, dense4=dense4, w_split=self._w_split,
+                    w_split_ready=self._w_split_ready)
         self._acts = acts
         logits = logits.view(t_out, batch, cfg.num_classes)
         self.last_logits, self.last_seq_length = logits, seq_length     # for logging / summaries
@@ -1006,6 +1014,8 @@ class CTCModel:
             if reduce_hook is not None:
                 reduce_hook(layer, *slices[layer])
 
+        # (every weight gradient below ACCUMULATES into the arena - step ranges, directions and the
+        # kernels' bias sums add their shares - so the arena starts from zero here)
         self.arena.grad.zero_()
         arith = acts.setdefault('arithmetic', {})
         training = acts['training']
@@ -1072,7 +1082,7 @@ class CTCModel:
         # dense4: dz and the data gradient are on the critical path, the kernel gradient is not
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
-        k4_split = self._weight_split('dense4', True) if acts['flat_uses_split'] else None
+        k4_split = self._weight_split('dense4', True, acts) if acts['flat_uses_split'] else None
         if k4_split is not None:
             dz_split = split_gemm.split(dz, split_gemm.B_ORDER)
             dy = split_gemm.mm_nt(dz_split, k4_split[1]).view(t_out, batch, 2 * hidden)
@@ -1122,7 +1132,7 @@ class CTCModel:
             chunks = 1
             if (side is not main and acts['rnn_len'] is None and not whole_chip_rnn and
                     persistent):
-                chunks = self.bwd_chunks or (2 if batch <= 16 else 3)
+                chunks = self.bwd_chunks or 2
                 if t_out < 8 * chunks:
                     chunks = 1
             dy = dy.contiguous()
@@ -1135,7 +1145,7 @@ class CTCModel:
 
             # bf16-split operands (split_gemm.py): the pieces of this layer's input and W_ih come
             # from the forward pass where it used them; y's are the next layer's input pieces
-            w_pieces = self._weight_split(name, True)
+            w_pieces = self._weight_split(name, True, acts)
             use_split = w_pieces is not None
             # fp16 form of this layer's gradient GEMMs: when the forward pass left fp16 pieces of
             # the layer's input AND of its output (the next layer's input / dense4's), dxw is

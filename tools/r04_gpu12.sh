@@ -1,0 +1,3 @@
+python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+python bench.py > gpurun_out/r04_default_line.json 2> gpurun_out/r04_default_line.err; echo rc=$?
+python tools/show_bench.py gpurun_out/r04_default_line.json; tail -3 gpurun_out/r04_default_line.err

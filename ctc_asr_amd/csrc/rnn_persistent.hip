@@ -79,6 +79,7 @@ struct PArgs {
     const float *w;        // fwd: w_hh [2, G*H, H]; bwd: w_hh_t [2, H, G*H]
     const int *seq_len;
     float *y;              // [T, B, 2H]
+    unsigned short *y16;   // forward, fp16 kernel (optional): the pieces of y, [T, B, 3, 2H] halves
     const float *dy;
     float *dxw;
     float *gates;          // LSTM reserve [T, B, 2, 4H]
@@ -1028,6 +1029,16 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
             dir_arrive<1>(p.sync, nullptr, dir, chain, grp, tid, unused);
         }
         // y and the reserve for the backward pass: nobody inside this launch reads them
+        if (p.y16 && it_t >= 0 && (tid & 7) == 0) {
+            // ... and the pieces of y in the layout of ctcasr_split_f16 (blocks: first, first,
+            // second; scale 2^15): the NEXT layer's input projection / dense4 / this layer's
+            // recurrent weight gradient read them - no split pass over y
+            u32x4 *dst = reinterpret_cast<u32x4 *>(
+                p.y16 + (((size_t)it_t * BS + brow) * 3) * 2 * H + dir * H + unit);
+            dst[0] = first;
+            dst[(size_t)2 * H / 8] = first;
+            dst[(size_t)4 * H / 8] = second;
+        }
         if (it_t >= 0) {
             p.y[((size_t)it_t * BS + brow) * 2 * H + dir * H + unit] = hv;
             float *gr = p.gates + (((size_t)it_t * BS + brow) * 2 + dir) * 4 * H + unit;
@@ -2260,14 +2271,15 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
              const float *b_hh_n, const int32_t *seq_len, int T, int B, int BS, int H, float *y,
-             float *gates, float *cells, void *sync, float *carry, int step_begin, int step_end,
-             int flags, hipStream_t s) {
+             void *y16, float *gates, float *cells, void *sync, float *carry, int step_begin,
+             int step_end, int flags, hipStream_t s) {
     // forward default: the whole chip (nothing of the same layer can overlap it)
     const bool fwd_half_chip = (flags & CTCASR_RNN_HALF_CHIP) != 0;
     PArgs p = {};
     p.carry = carry;
     p.xchg = reinterpret_cast<float *>(reinterpret_cast<char *>(sync) + sizeof(SyncWords));
     p.xw = xw; p.w = w_hh; p.seq_len = seq_len; p.y = y; p.gates = gates; p.cells = cells;
+    p.y16 = reinterpret_cast<unsigned short *>(y16);
     p.bias = xw_bias; p.b_hh = b_hh_n;
     p.ndir = 2; p.dir0 = 0; p.chain0 = 0;
     p.sync = reinterpret_cast<SyncWords *>(sync);

@@ -286,8 +286,8 @@ int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
              const float *b_hh_n, const int32_t *seq_len, int T, int B, int BS, int H, float *y,
-             float *gates, float *cells, void *sync, float *carry, int step_begin, int step_end,
-             int flags, hipStream_t s);
+             void *y16, float *gates, float *cells, void *sync, float *carry, int step_begin,
+             int step_end, int flags, hipStream_t s);
 int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
              const int32_t *seq_len, int T, int B, int BS, int H, const float *gates,
              const float *cells, float *dxw, float *drec, float *dbias, unsigned *colmax,
@@ -343,14 +343,26 @@ static int rnn_check(int cell, int T, int B, int H) {
 // state between them (h through the exchange buffer / state ping-pong, c in the carry) stays in
 // the workspace.  After a launch, y of the steps it covered is final: their share of the NEXT
 // layer's input projection can run on another stream beside the following launch.
+// Whether a forward call with these flags runs the fp16-pipe kernel (and so can write `y_pieces`).
+extern "C" int ctcasr_rnn_fwd_f16_supported(int cell, int T, int B, int H, int flags) {
+    const int rows = B < PRNN_BLOCK_ROWS ? B : PRNN_BLOCK_ROWS;
+    return (flags & CTCASR_RNN_F16) && (cell == CTCASR_CELL_LSTM || cell == CTCASR_CELL_GRU) &&
+           !(rows > 16 && (flags & CTCASR_RNN_ONE_BARRIER)) &&
+           ctcasr_rnn_persistent_supported(cell, T, B, H) ? 1 : 0;
+}
+
 extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_bias,
                                     const float *w_hh, const float *b_hh_n,
                                     const int32_t *seq_len, int T, int B,
-                                    int H, float *y, void *reserve, void *workspace,
-                                    size_t workspace_bytes, int step_begin, int step_end,
-                                    int flags, ctcasr_stream_t stream) {
+                                    int H, float *y, void *y_pieces, void *reserve,
+                                    void *workspace, size_t workspace_bytes, int step_begin,
+                                    int step_end, int flags, ctcasr_stream_t stream) {
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
+    // the pieces of y come out of the fp16-pipe kernel only, and only where every row runs all
+    // T steps (rows past their length would have to be zero-filled)
+    if (y_pieces && (seq_len || !ctcasr_rnn_fwd_f16_supported(cell, T, B, H, flags)))
+        return CTCASR_ERR_UNSUPPORTED;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
                          CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16))
         return CTCASR_ERR_BAD_ARGUMENT;
@@ -377,8 +389,10 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_b
             const size_t b0 = (size_t)blk * PRNN_BLOCK_ROWS;
             rc = prnn_fwd(cell, xw + b0 * 2 * G * H, xw_bias, w_hh, b_hh_n,
                           seq_len ? seq_len + b0 : nullptr, T, prnn_block_rows(B, blk), B, H,
-                          y + b0 * 2 * H, p.gates + b0 * 2 * 4 * H,
-                          p.cells + b0 * 2 * H,
+                          y + b0 * 2 * H,
+                          y_pieces ? reinterpret_cast<char *>(y_pieces) + b0 * 3 * 2 * H * 2
+                                   : nullptr,
+                          p.gates + b0 * 2 * 4 * H, p.cells + b0 * 2 * H,
                           reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H) +
                               blk * prnn_block_bytes(T, B, H, G),
                           p.cbuf + b0 * 2 * H, step_begin, step_end, flags, s);
@@ -406,8 +420,8 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, c
                               const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
                               float *y, void *reserve, void *workspace, size_t workspace_bytes,
                               ctcasr_stream_t stream) {
-    return ctcasr_rnn_fwd_steps(cell, xw, xw_bias, w_hh, b_hh_n, seq_len, T, B, H, y, reserve,
-                                workspace,
+    return ctcasr_rnn_fwd_steps(cell, xw, xw_bias, w_hh, b_hh_n, seq_len, T, B, H, y, nullptr,
+                                reserve, workspace,
                                 workspace_bytes, 0, T, CTCASR_RNN_DEFAULT, stream);
 }
 

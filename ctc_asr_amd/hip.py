@@ -49,8 +49,9 @@ SIGNATURES = {
     'ctcasr_rnn_gru_drec_offset': (_c_sz, [_c_int] * 3),
     'ctcasr_rnn_fwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 3 + [_c_sz, _c_p]),
     'ctcasr_rnn_bwd': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 + [_c_sz, _c_p]),
-    'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 3 +
+    'ctcasr_rnn_fwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 4 +
                              [_c_sz, _c_int, _c_int, _c_int, _c_p]),
+    'ctcasr_rnn_fwd_f16_supported': (_c_int, [_c_int] * 5),
     'ctcasr_rnn_bwd_steps': (_c_int, [_c_int] + [_c_p] * 5 + [_c_int] * 3 + [_c_p] * 5 +
                              [_c_sz, _c_int, _c_int, _c_int, _c_p]),
     'ctcasr_rnn_bwd_f16_supported': (_c_int, [_c_int] * 5),
@@ -361,7 +362,7 @@ def rnn_workspace(cell, num_steps, batch, hidden, device):
 
 @_on_tensor_device
 def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, workspace=None,
-            steps=None, flags=RNN_DEFAULT, xw_bias=None, ticket=0):
+            steps=None, flags=RNN_DEFAULT, xw_bias=None, ticket=0, y16=None):
     """xw f32[T,B,2,G*H], w_hh f32[2,G*H,H] -> (y f32[T,B,2H], reserve, workspace).
 
     ``steps=(begin, end)`` runs that range of recurrence steps only (`ctcasr_rnn_fwd_steps`): cut
@@ -388,6 +389,7 @@ def rnn_fwd(cell, xw, w_hh, seq_len=None, b_hh_n=None, y=None, reserve=None, wor
         CELL_IDS[cell], _dev(xw, name='xw'), _dev(xw_bias, name='xw_bias'),
         _dev(w_hh, name='w_hh'), _dev(b_hh_n, name='b_hh_n'),
         _dev(seq_len, torch.int32, 'seq_len'), num_steps, batch, hidden, _dev(y, name='y'),
+        _dev(y16, torch.float16, 'y16'),
         _dev(reserve, torch.uint8, 'reserve'), _dev(workspace, torch.uint8, 'workspace'),
         workspace.numel(), int(begin), int(end), int(flags) | (int(ticket) & 0xFFFFFF) << 8,
         _stream()), 'rnn_fwd')
@@ -429,6 +431,13 @@ def rnn_bwd(cell, dy, y, w_hh_t, reserve, seq_len=None, b_hh_n=None, dxw=None, d
         workspace.numel(), int(begin), int(end), int(flags) | (int(ticket) & 0xFFFFFF) << 8,
         _stream()), 'rnn_bwd')
     return dxw
+
+
+def rnn_fwd_f16_supported(cell, num_steps, batch, hidden, flags=RNN_F16):
+    """Whether `rnn_fwd` with these flags runs the fp16-pipe kernel (and can write ``y16``: fp16
+    [T*B, 3, 2H], the pieces of y * 2^15 in the layout of `split_f16(order (0, 0, 1))`)."""
+    return bool(load().ctcasr_rnn_fwd_f16_supported(CELL_IDS[cell], int(num_steps), int(batch),
+                                                    int(hidden), int(flags)))
 
 
 def rnn_bwd_f16_supported(cell, num_steps, batch, hidden, flags=RNN_F16):

@@ -401,6 +401,8 @@ class CTCModel:
         # per (producer workgroup, row) inside the kernel, which also hands the column maxima of
         # dxw to the fp16 weight-gradient GEMMs (no `colmax` pass over dxw)
         self.rnn_bwd_f16 = os.environ.get('CTCASR_RNN_BWD_F16', '1') == '1'
+        # the fp16-pipe forward kernel writes the fp16 pieces of its output itself (no split pass)
+        self.rnn_fwd_pieces = os.environ.get('CTCASR_RNN_FWD_PIECES', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
         self._w_guard = None            # range check of the weights that go to fp16 (lagged)
         self._side_stream = None
@@ -723,6 +725,7 @@ class CTCModel:
         in_split = []                   # bf16 pieces of the layer inputs (None: fp32 GEMM)
         in_split16 = []                 # (fp16 pieces, scale) where the forward used them
         pipelined_xw = None
+        y16_of = None               # (tensor, its fp16 pieces, their scale) from a forward kernel
         x = rnn_in.contiguous()
         workspace = self._rnn_workspace(cell, t_out, batch, hidden)
         rnn_rate = cfg.rnn_dropout_rate if training else 0.0
@@ -749,8 +752,13 @@ class CTCModel:
                 scale = split_gemm.f16_scale(in_bound) if w_pieces[2] is not None else None
                 if scale is not None:
                     # bounded input: two fp16 pieces, three products (the bf16 pieces the weight
-                    # gradients want are made in the backward pass, on the side stream)
-                    x16 = split_gemm.split16(x.view(t_out * batch, -1), scale, split_gemm.H_A)
+                    # gradients want are made in the backward pass, on the side stream); the
+                    # pieces of a recurrent layer's output come out of its fp16-pipe forward
+                    # kernel (`y16_of`), everything else is split here
+                    if y16_of is not None and y16_of[0] is x and y16_of[2] == scale:
+                        x16 = y16_of[1]
+                    else:
+                        x16 = split_gemm.split16(x.view(t_out * batch, -1), scale, split_gemm.H_A)
                     xw = split_gemm.mm_nt16(x16, w_pieces[2], scale * split_gemm.W_SCALE)
                     pieces16 = (x16, scale)
                     form = 'fp16x3'
@@ -764,13 +772,29 @@ class CTCModel:
             in_split16.append(pieces16)
             arithmetic['rnn{}/input_projection'.format(i)] = form
             if self._pipeline_forward(i, cell, t_out, batch, hidden, rnn_len, rnn_rate):
+                y16_of = None
                 y, reserve, workspace, pipelined_xw = self._rnn_fwd_pipelined(
                     i, xw, t_out, batch, hidden, gates, workspace)
             else:
+                # the fp16-pipe kernel can hand the fp16 pieces of its output to whoever multiplies
+                # them next (the next layer's projection / dense4; this layer's dW_hh): worth it
+                # when that consumer takes the fp16 form at the kernel's own scale (|h| <= 1, no
+                # dropout in between) and every row runs all steps
+                y16 = None
+                consumer = 'rnn{}'.format(i + 1) if i + 1 < cfg.num_layers_rnn else 'dense4'
+                if (f16_rec and self.rnn_fwd_pieces and rnn_len is None and
+                        not (rnn_rate > 0.0 and (not cfg.cudnn or i + 1 < cfg.num_layers_rnn)) and
+                        hip.rnn_fwd_f16_supported(cell, t_out, batch, hidden, rnn_flags)):
+                    pieces = self._weight_split(consumer)
+                    if pieces is not None and pieces[2] is not None:
+                        y16 = split_gemm.empty16(t_out * batch, 2 * hidden, split_gemm.H_A,
+                                                 self.device)
                 y, reserve, workspace = hip.rnn_fwd(
                     cell, xw.view(t_out, batch, 2, gates * hidden), p['rnn{}/w_hh'.format(i)],
                     rnn_len, b_hh_n=p['rnn{}/b_hh'.format(i)] if cell == 'gru' else None,
-                    workspace=workspace, xw_bias=self._rnn_bias(i), flags=rnn_flags)
+                    workspace=workspace, xw_bias=self._rnn_bias(i), flags=rnn_flags,
+                    y16=None if y16 is None else y16.buf)
+                y16_of = None if y16 is None else (y, y16, split_gemm.RNN_F16_H_SCALE)
             arithmetic['rnn{}/recurrence_fwd'.format(i)] = rnn_form
             layer_in.append(x)
             layer_out.append(y)
@@ -795,7 +819,10 @@ class CTCModel:
             if k4_pieces is not None and k4_pieces[2] is not None else None
         if flat_scale is not None:
             # bounded input (the recurrent stack's output): fp16 pieces, three products
-            flat16 = split_gemm.split16(rnn_flat, flat_scale, split_gemm.H_A)
+            if y16_of is not None and y16_of[0] is x and y16_of[2] == flat_scale:
+                flat16 = y16_of[1]
+            else:
+                flat16 = split_gemm.split16(rnn_flat, flat_scale, split_gemm.H_A)
             acts['flat16'] = (flat16, flat_scale)
             dense4 = split_gemm.mm_nn16_stacked(flat16, k4_pieces[2],
                                                 flat_scale * split_gemm.W_SCALE)

@@ -144,6 +144,8 @@ def mm_tn_rows(out, a, b, lo, hi, a_cols=slice(None), b_cols=slice(None), b_shif
 H_A, H_B = (0, 0, 1), (0, 1, 0)            # h1 k1 + h1 k2 + h2 k1
 F16_MAX = 60000.0                          # (fp16's largest finite value is 65504)
 W_SCALE = 2.0 ** 11                        # weights: |w| < 29
+RNN_F16_H_SCALE = 2.0 ** 15                # scale of the pieces of h the fp16-pipe recurrence
+                                           # kernels publish / write (PRNN_F16_H_SCALE)
 
 
 def f16_scale(bound):

@@ -194,8 +194,16 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
 #define CTCASR_RNN_TICKET(ticket) ((int)(((unsigned)(ticket) & 0xFFFFFFu) << 8))
 int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_bias, const float *w_hh,
                          const float *b_hh_n, const int32_t *seq_len, int T, int B, int H,
-                         float *y, void *reserve, void *workspace, size_t workspace_bytes,
-                         int step_begin, int step_end, int flags, ctcasr_stream_t stream);
+                         float *y, void *y_pieces, void *reserve, void *workspace,
+                         size_t workspace_bytes, int step_begin, int step_end, int flags,
+                         ctcasr_stream_t stream);
+/* ABI v5.  `y_pieces` (optional; only where ctcasr_rnn_fwd_f16_supported and seq_len == NULL, else
+ * CTCASR_ERR_UNSUPPORTED): fp16 [T, B, 3, 2H] - the two fp16 pieces of y * 2^15 in the block
+ * layout of ctcasr_split_f16(order 0, 0, 1), written by the fp16-pipe forward kernel itself (it
+ * has them in registers: they are what it publishes to the other workgroups): the operand of the
+ * next layer's forward projection / dense4 and of this layer's recurrent weight gradient, without
+ * a split pass over y. */
+int ctcasr_rnn_fwd_f16_supported(int cell, int T, int B, int H, int flags);
 /* 1 when the LDS-resident single-launch kernels cover (cell, T, B, H) on this device, else the
  * per-step streaming kernels run.  CTCASR_RNN_MODE=stream in the environment forces the latter. */
 int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);

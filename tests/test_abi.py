@@ -59,10 +59,10 @@ def test_argument_errors_are_reported_not_thrown(lib):
                               None) == -1
     # unknown flag bits of the step-range entry points are an argument error
     assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
-                                    0, 0, 8, 64, None) == -1
+                                    None, 0, 0, 8, 64, None) == -1
     # ... the upper 24 bits are the residency ticket, not variant flags
     assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
-                                    0, 0, 8, 5 << 8, None) == -1      # (null pointers, not flags)
+                                    None, 0, 0, 8, 5 << 8, None) == -1   # (null pointers, not flags)
     assert lib.ctcasr_rnn_resident_gate(None, 0, 2, 8, 2, 1024, 1, 200, None) == -3
     assert lib.ctcasr_rnn_resident_gate(None, 0, 2, 8, 2, 1024, 0, 200, None) == -1
     # the only process-wide option is the profiling switch
@@ -72,7 +72,8 @@ def test_argument_errors_are_reported_not_thrown(lib):
                                 None, None) == -1
     # flag 64 is not a variant bit (16 = CTCASR_RNN_F16 is)
     assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
-                                    0, 0, 8, 16, None) == -1             # (null pointers)
+                                    None, 0, 0, 8, 16, None) == -1       # (null pointers)
+    assert lib.ctcasr_rnn_fwd_f16_supported(2, 8, 2, 64, 16) == 0
     assert lib.ctcasr_step_guard(None, None, 4, None, None, None, None) == -1
     assert lib.ctcasr_absmax(None, 4, None, None) == -1
     assert lib.ctcasr_colscale_from_max(None, 4, None, None, None) == -1

@@ -285,6 +285,7 @@ def test_rnn_fwd_on_the_fp16_matrix_pipe(hip, cell, use_len, dims):
     y32, _, ws32 = hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias)
     y16, reserve, ws = hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias,
                                    flags=hip.RNN_F16)
+    y_f16 = y16
     hip.rnn_poll_error(cell, ws, num_steps, batch, hidden)
     hip.rnn_poll_error(cell, ws32, num_steps, batch, hidden)
     err16 = float((y16.double() - ref).abs().max())
@@ -304,6 +305,23 @@ def test_rnn_fwd_on_the_fp16_matrix_pipe(hip, cell, use_len, dims):
         assert torch.equal(y_cut, y16)
         if cell == 'lstm' and not use_len:  # (parts of the reserve a forward pass does not write:
             assert torch.equal(reserve_cut, reserve)    # the GRU's drec, rows past their length)
+    # the kernel's own fp16 pieces of y (what it publishes, written in the layout of split_f16):
+    # bit for bit the split of the y it wrote; not offered where rows end early
+    from ctc_asr_amd import split_gemm
+    pieces16 = torch.zeros(num_steps * batch, 3, 2 * hidden, dtype=torch.float16, device=DEV)
+    if use_len:
+        with pytest.raises(hip.CtcAsrError):
+            hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias, flags=hip.RNN_F16, y16=pieces16)
+    else:
+        y_again, _, ws_p = hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias,
+                                       flags=hip.RNN_F16, y16=pieces16)
+        hip.rnn_poll_error(cell, ws_p, num_steps, batch, hidden)
+        assert torch.equal(y_again, y_f16)
+        want = hip.split_f16(y_again.view(num_steps * batch, 2 * hidden),
+                             split_gemm.RNN_F16_H_SCALE, split_gemm.H_A)
+        assert torch.equal(pieces16.view(torch.int16), want.view(torch.int16))
+        with pytest.raises(hip.CtcAsrError):        # the fp32 kernel has no pieces to give
+            hip.rnn_fwd(cell, xw, w_hh, sl, b_hh_n=b_hh, xw_bias=bias, y16=pieces16)
     if cell == 'lstm' and hidden == 1024 and batch <= 16:
         # half of the chip: another split of the same sums (16 units per workgroup: other scales)
         y_half, _, ws_half = hip.rnn_fwd(cell, xw, w_hh, sl, xw_bias=bias,

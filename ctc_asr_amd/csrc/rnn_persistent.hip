@@ -103,6 +103,7 @@ struct PArgs {
     unsigned *colmax;      // backward, fp16 form (optional): [2][G * H] maxima of |dxw| (bit patterns)
     int prof;              // record phase timings of workgroup 0
     unsigned ticket;       // != 0: post it once every workgroup of this launch is running
+    int xcd_split;         // fp16 kernels: direction 0 on XCDs 0 - 3, direction 1 on XCDs 4 - 7
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) {
@@ -799,7 +800,12 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
     const int row0 = chain * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x % (p.ndir * p.nwg);
-    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    // Workgroup b runs on XCD b % 8.  `xcd_split` (two directions in the launch): direction 0 on
+    // XCDs 0 - 3, direction 1 on XCDs 4 - 7 - an exchange block is then pulled across the fabric
+    // by four L2s instead of eight, and an XCD's L2 holds one direction's blocks instead of two.
+    const bool split = p.xcd_split && p.ndir == 2;
+    const int dir = p.dir0 + (split ? (wg & 7) >> 2 : wg / p.nwg);
+    const int slice = split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int H = p.H, B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * UPB;
@@ -1805,7 +1811,9 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: scalar offsets)
     const int wg = blockIdx.x % (p.ndir * p.nwg);
-    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    const bool split = p.xcd_split && p.ndir == 2;      // (see prnn_fwd16_kernel)
+    const int dir = p.dir0 + (split ? (wg & 7) >> 2 : wg / p.nwg);
+    const int slice = split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * 16;
@@ -2287,6 +2295,7 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
     p.s_lo = step_begin; p.s_hi = step_end;
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
+    p.xcd_split = (flags & CTCASR_RNN_XCD_SPLIT) != 0;
     const int mt = (B + 15) / 16;
     const bool one_barrier = (flags & CTCASR_RNN_ONE_BARRIER) != 0;
     // fp16 matrix pipe (CTCASR_RNN_F16): the same geometries as the fp32 kernels below - H = 2048
@@ -2403,6 +2412,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
     p.nwg = cell == CTCASR_CELL_LSTM ? (half_chip ? H / 16 : H / 8) : (half_chip ? H / 32 : H / 16);
     p.prof = getenv("CTCASR_RNN_PROF") != nullptr;
     p.ticket = ((unsigned)flags >> 8) & 0xFFFFFFu;
+    p.xcd_split = (flags & CTCASR_RNN_XCD_SPLIT) != 0;
     const int mt = (B + 15) / 16;
     // batches of 17..32 rows = two independent 16-row tiles (see ChainSync):
     //   half of the chip: two chains inside every workgroup (8 waves): LSTM 11.0 us per step

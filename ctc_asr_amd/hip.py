@@ -18,7 +18,8 @@ ABI_VERSION = 5
 BUILD_PROBE_WRONG_RESULTS, BUILD_NONDEFAULT_TUNING = 1, 2      # ctcasr_build_flags() bits
 RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP, RNN_ONE_BARRIER = 0, 1, 2, 4   # rnn_fwd/bwd `flags`
 RNN_REDUCE_SCATTER = 8
-RNN_F16 = 16          # forward, LSTM / GRU persistent kernels: h W_hh^T as fp16x3 (ABI v5)
+RNN_F16 = 16          # persistent LSTM / GRU kernels: the recurrent products as fp16x3 (ABI v5)
+RNN_XCD_SPLIT = 32    # fp16-pipe kernels: one direction per half of the XCDs
 CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
 CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}
 

@@ -401,6 +401,12 @@ class CTCModel:
         # per (producer workgroup, row) inside the kernel, which also hands the column maxima of
         # dxw to the fp16 weight-gradient GEMMs (no `colmax` pass over dxw)
         self.rnn_bwd_f16 = os.environ.get('CTCASR_RNN_BWD_F16', '1') == '1'
+        # fp16-pipe kernels: direction 0 on XCDs 0 - 3, direction 1 on XCDs 4 - 7 - every exchange
+        # block crosses the fabric into four L2s instead of eight (bit-identical results; backward
+        # recurrence 8.56 -> 8.30 us per step alone, 9.9 -> 9.7 in the C3 step, the step 0.5 ms
+        # shorter in two alternating A/Bs: profiles/r04_ab.md)
+        self.rnn_xcd_flag = hip.RNN_XCD_SPLIT \
+            if os.environ.get('CTCASR_RNN_XCD_SPLIT', '1') == '1' else 0
         # the fp16-pipe forward kernel writes the fp16 pieces of its output itself (no split pass)
         self.rnn_fwd_pieces = os.environ.get('CTCASR_RNN_FWD_PIECES', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
@@ -720,7 +726,7 @@ class CTCModel:
         # h W_hh^T of the forward recurrence on the fp16 matrix pipe (persistent LSTM / GRU kernels)
         f16_rec = (self.rnn_fwd_f16 and cell in ('lstm', 'gru') and
                    hip.rnn_persistent_supported(cell, t_out, batch, hidden))
-        rnn_flags = hip.RNN_F16 if f16_rec else hip.RNN_DEFAULT
+        rnn_flags = (hip.RNN_F16 | self.rnn_xcd_flag) if f16_rec else hip.RNN_DEFAULT
         rnn_form = 'fp16x3' if f16_rec else 'fp32'
         in_split = []                   # bf16 pieces of the layer inputs (None: fp32 GEMM)
         in_split16 = []                 # (fp16 pieces, scale) where the forward used them
@@ -929,7 +935,8 @@ class CTCModel:
             lo, hi = bounds[c], bounds[c + 1]
             hip.rnn_fwd(cell, xw.view(t_out, batch, 2, gh), p[name + '/w_hh'], None, y=y,
                         reserve=reserve, workspace=workspace, steps=(lo, hi),
-                        flags=hip.RNN_HALF_CHIP | (hip.RNN_F16 if self.rnn_fwd_f16 else 0),
+                        flags=hip.RNN_HALF_CHIP | ((hip.RNN_F16 | self.rnn_xcd_flag)
+                                                   if self.rnn_fwd_f16 else 0),
                         xw_bias=bias_here, ticket=self._take_ticket())
             if c + 1 < chunks:
                 ready = torch.cuda.Event()
@@ -1294,7 +1301,8 @@ class CTCModel:
             split_done = []
             # dgates W_hh on the fp16 matrix pipe where the kernel exists (LSTM-1024); it then also
             # leaves the column maxima of each launch's rows of dxw for the fp16 weight gradients
-            bwd_flags = self.rnn_bwd_flags | (hip.RNN_F16 if self.rnn_bwd_f16 else 0)
+            bwd_flags = self.rnn_bwd_flags | ((hip.RNN_F16 | self.rnn_xcd_flag)
+                                              if self.rnn_bwd_f16 else 0)
             f16_rec = hip.rnn_bwd_f16_supported(cell, t_out, batch, hidden, bwd_flags)
             arith['rnn{}/recurrence_bwd'.format(i)] = 'fp16x3' if f16_rec else 'fp32'
             colmax = torch.zeros((chunks, 2 * gh), dtype=torch.int32, device=dy.device) \

@@ -185,6 +185,10 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
  * its two pieces.  The backward kernels and everything else are unaffected (y, the reserve and
  * the carry stay fp32).  Other cells / shapes / CTCASR_RNN_ONE_BARRIER ignore the bit. */
 #define CTCASR_RNN_F16 16
+/* fp16-pipe kernels, both directions in one launch: direction 0's workgroups on XCDs 0 - 3,
+ * direction 1's on XCDs 4 - 7 (workgroup b runs on XCD b % 8) - every exchange block crosses the
+ * fabric into four L2s instead of eight.  Same results bit for bit (ABI v5). */
+#define CTCASR_RNN_XCD_SPLIT 32
 /* Residency ticket (bits 8..31 of `flags`, 0 = none): a persistent launch that carries one posts
  * it in the workspace once ALL of its workgroups are running; ctcasr_rnn_resident_gate() makes
  * another stream wait for exactly that (bounded).  Use: work for the CUs a half-chip launch

@@ -31,6 +31,9 @@ def main():
     if os.environ.get('CTCASR_F16'):           # both recurrences on the fp16 matrix pipe
         fwd_flags |= hip.RNN_F16
         bwd_flags |= hip.RNN_F16
+    if os.environ.get('CTCASR_XCD'):           # fp16 kernels: one direction per half of the XCDs
+        fwd_flags |= hip.RNN_XCD_SPLIT
+        bwd_flags |= hip.RNN_XCD_SPLIT
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)

@@ -79,18 +79,18 @@ def dtype_label(model):
     """The arithmetic the step computes in, spelled out: tensors, accumulation and the own kernels
     are fp32; the big GEMMs multiply fp16 / bf16 PIECES of the fp32 operands on the 16-bit matrix
     pipe unless CTCASR_SPLIT_GEMM=0."""
+    which = [name for name, on in (('forward', model.rnn_fwd_f16), ('backward', model.rnn_bwd_f16))
+             if on]
+    rec = '; {} recurrence (h x W_hh / dgates x W_hh) as fp16x3 split, fp32 accumulate'.format(
+        ' and '.join(which)) if which else ''
     if not model.split_gemm:
-        return 'f32'
+        return 'f32' if not rec else 'f32 tensors / accumulate / GEMMs' + rec
     gemms = 'bf16x6 split (24 significand bits)'
     if model.fwd_f16:
         gemms = 'fp16x3 split (22 significand bits) where the layer input is bounded - {} - ' \
                 'bf16x6 split (24 bits) elsewhere'.format(
                     'forward projections and their gradient GEMMs' if model.bwd_f16
                     else 'forward projections')
-    which = [name for name, on in (('forward', model.rnn_fwd_f16), ('backward', model.rnn_bwd_f16))
-             if on]
-    rec = '; {} recurrence (h x W_hh / dgates x W_hh) as fp16x3 split, fp32 accumulate'.format(
-        ' and '.join(which)) if which else ''
     return 'f32 tensors / accumulate / own kernels; projection GEMMs: ' + gemms + rec
 
 

@@ -123,7 +123,7 @@ class _StagingRing:
     def __init__(self, slots, batch_rows):
         self.slots = [{'pcm': None, 'small': torch.empty(1 << 16, dtype=torch.int32).pin_memory(),
                        'event': None} for _ in range(slots)]
-        self.rows, self.next = batch_rows, 0
+        self.rows, self.next, self.busy = batch_rows, 0, False
 
     def take(self, samples):
         slot = self.slots[self.next]
@@ -358,11 +358,16 @@ def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, p
             dev = torch.device('cuda', torch.cuda.current_device())
         upload = torch.cuda.Stream(dev)
         # (queue + producer + consumer; kept across epochs: pinned allocations cost up to 80 ms)
+        # (one iterator at a time per ring: an iterator that starts while another one's reader
+        # thread is still alive gets buffers of its own)
         key = (str(dev), prefetch + 3, FLAGS.batch_size)
         ring = _RINGS.get(key)
         if ring is None:
             _RINGS.clear()
             ring = _RINGS[key] = _StagingRing(prefetch + 3, FLAGS.batch_size)
+        elif ring.busy:
+            ring = _StagingRing(prefetch + 3, FLAGS.batch_size)
+        ring.busy = True
 
         def producer():
             try:
@@ -372,6 +377,8 @@ def input_fn_generator(target, device='cuda', rank=0, world_size=1, seed=None, p
                 pending.put(done)
             except BaseException as exc:      # surface reader errors in the consumer
                 pending.put(exc)
+            finally:
+                ring.busy = False
 
         threading.Thread(target=producer, daemon=True).start()
         while True:

@@ -284,6 +284,28 @@ class ParamArena:
         return out
 
 
+def predicted_input_bounds(cfg, training):
+    """Upper bounds of |input| of every recurrent layer and (last entry) of dense4 as
+    `CTCModel.inference_fn` will find them (None: unbounded) - which decides, ahead of the forward
+    pass, whether a layer's projections take the fp16 form (two pieces under a fixed scale) or the
+    bf16 form: the front end's clipped ReLU (<= relu_cutoff, times 1 / keep_prob where a dropout
+    follows), |h| <= 1 behind the gated / tanh cells, nothing behind the ReLU cell."""
+    if cfg.used_model == 'ds2':
+        bound = cfg.relu_cutoff / (1.0 - cfg.conv_dropout_rate)
+    else:
+        bound = cfg.relu_cutoff / (1.0 - (cfg.dense_dropout_rate if training else 0.0))
+    rate = cfg.rnn_dropout_rate if training else 0.0
+    bounds = []
+    for i in range(cfg.num_layers_rnn):
+        if rate > 0.0 and (i > 0 or not cfg.cudnn) and bound is not None:
+            bound = bound / (1.0 - rate)
+        bounds.append(bound)
+        bound = None if cfg.cell == 'rnn_relu' else 1.0
+        if rate > 0.0 and not cfg.cudnn and bound is not None:
+            bound = bound / (1.0 - rate)
+    return bounds + [bound]
+
+
 class _WeightPieces:
     """Pieces of one weight matrix for the split GEMMs of a step.  ``fwd16`` / ``tr16``: fp16
     pieces (fixed scale `split_gemm.W_SCALE`) of the matrix / of its transpose, or None; the bf16
@@ -441,24 +463,7 @@ class CTCModel:
 
     # ------------------------------------------------------------------ pieces of the weights
     def _predicted_bounds(self, training):
-        """Upper bounds of |input| of every recurrent layer and of dense4 as `inference_fn` will
-        find them (None: unbounded) - which decides, ahead of the forward pass, whether a layer's
-        projections take the fp16 form (two pieces under a fixed scale) or the bf16 form."""
-        cfg = self.cfg
-        if cfg.used_model == 'ds2':
-            bound = cfg.relu_cutoff / (1.0 - cfg.conv_dropout_rate)
-        else:
-            bound = cfg.relu_cutoff / (1.0 - (cfg.dense_dropout_rate if training else 0.0))
-        rate = cfg.rnn_dropout_rate if training else 0.0
-        bounds = []
-        for i in range(cfg.num_layers_rnn):
-            if rate > 0.0 and (i > 0 or not cfg.cudnn) and bound is not None:
-                bound = bound / (1.0 - rate)
-            bounds.append(bound)
-            bound = None if cfg.cell == 'rnn_relu' else 1.0
-            if rate > 0.0 and not cfg.cudnn and bound is not None:
-                bound = bound / (1.0 - rate)
-        return bounds + [bound]
+        return predicted_input_bounds(self.cfg, training)
 
     def _weights_in_f16_range(self, names, views, side):
         """{name: bool}: may this weight matrix be scaled by the fixed `split_gemm.W_SCALE` into

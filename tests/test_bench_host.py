@@ -111,3 +111,39 @@ def test_flops_by_pipe_add_up_and_price_the_mixed_roof():
     assert with_split['ms_per_step_at_peak'] < without['ms_per_step_at_peak']
     assert abs(without['ms_per_step_at_peak'] - 32 * (split + fp32) / 157.3e12 * 1e3) < 0.01
     assert 0.0 < with_split['frac'] < 1.0 and 0.0 < without['frac'] < 1.0
+
+
+def test_predicted_input_bounds_and_dtype_label():
+    """Host logic of round 4: which layers may take the fp16 form (bounded input), and the
+    `dtype` text of the bench line for each arithmetic."""
+    import types
+    import bench
+    from ctc_asr_amd import split_gemm
+    from ctc_asr_amd.model import ModelConfig, predicted_input_bounds
+    ds2 = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_layers_rnn=3, rnn_cell='lstm')
+    assert predicted_input_bounds(ds2, True) == [20.0, 1.0, 1.0, 1.0]
+    assert all(split_gemm.f16_scale(b) is not None for b in predicted_input_bounds(ds2, True))
+    assert split_gemm.f16_scale(1.0) == split_gemm.RNN_F16_H_SCALE
+    relu = ModelConfig(used_model='ds2', num_layers_rnn=2, rnn_cell='rnn_relu')
+    assert predicted_input_bounds(relu, True) == [20.0, None, None]
+    drop = ModelConfig(used_model='ds2', num_layers_rnn=2, rnn_cell='gru', rnn_dropout_rate=0.5,
+                       conv_dropout_rate=0.2)
+    assert predicted_input_bounds(drop, True) == [25.0, 2.0, 1.0]      # cuDNN: input of layers 2..L
+    assert predicted_input_bounds(drop, False) == [25.0, 1.0, 1.0]
+    ds1 = ModelConfig(used_model='ds1', num_layers_rnn=1, rnn_cell='lstm', cudnn=False,
+                      dense_dropout_rate=0.1, rnn_dropout_rate=0.5, relu_cutoff=100.0)
+    train_bounds = predicted_input_bounds(ds1, True)
+    assert abs(train_bounds[0] - 100.0 / 0.9 / 0.5) < 1e-9 and train_bounds[1] == 2.0
+    assert split_gemm.f16_scale(train_bounds[0]) is None               # cutoff above 64: bf16 form
+
+    def model(**attrs):
+        base = dict(split_gemm=True, fwd_f16=True, bwd_f16=True, rnn_fwd_f16=True, rnn_bwd_f16=True)
+        base.update(attrs)
+        return types.SimpleNamespace(**base)
+    assert bench.dtype_label(model(split_gemm=False, rnn_fwd_f16=False, rnn_bwd_f16=False)) == 'f32'
+    assert 'recurrence' in bench.dtype_label(model(split_gemm=False))
+    text = bench.dtype_label(model())
+    assert 'fp16x3' in text and 'forward and backward recurrence' in text and text.startswith('f32 ')
+    assert 'recurrence' not in bench.dtype_label(model(rnn_fwd_f16=False, rnn_bwd_f16=False))
+    assert 'fp16x3' not in bench.dtype_label(model(fwd_f16=False, rnn_fwd_f16=False,
+                                                   rnn_bwd_f16=False))

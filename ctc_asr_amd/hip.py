@@ -63,6 +63,10 @@ SIGNATURES = {
     'ctcasr_conv_s12_supported': (_c_int, [_c_int, _c_int]),
     'ctcasr_conv_s12_pack_weights': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
     'ctcasr_conv_s12_fwd': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_f, _c_int, _c_p]),
+    'ctcasr_conv_s12_pack16_bytes': (_c_sz, [_c_int]),
+    'ctcasr_conv_s12_pack_weights16': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
+    'ctcasr_conv_s12_fwd16': (_c_int, [_c_p, _c_f, _c_p, _c_p, _c_p] + [_c_int] * 4 +
+                              [_c_f, _c_int, _c_p]),
     'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
     'ctcasr_conv_s12_wrw_workspace_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_conv_s12_wrw': (_c_int, [_c_p] * 3 + [_c_int] * 5 + [_c_p, _c_f, _c_p] +
@@ -718,6 +722,44 @@ def conv_s12_fwd(x, packed, cout, bias=None, out=None, relu_cutoff=0.0, time_maj
                                           _dev(bias, name='bias'), _dev(out, name='y'), batch,
                                           frames, freq, cout, float(relu_cutoff),
                                           1 if time_major else 0, _stream()), 'conv_s12_fwd')
+    return out
+
+
+@_on_tensor_device
+def conv_s12_pack_weights16(weight, packed=None):
+    """weight f32[cout, 32, 11, 21] -> uint8 buffer for `conv_s12_fwd16`: the bit pattern of
+    max |w| (found on the device) and the two fp16 pieces of w * s_w in fragment order."""
+    cout = weight.shape[0]
+    nbytes = load().ctcasr_conv_s12_pack16_bytes(int(cout))
+    if nbytes == 0 or tuple(weight.shape[1:]) != (32, 11, 21):
+        raise CtcAsrError('conv_s12_pack_weights16: unsupported kernel shape {}'.format(
+            tuple(weight.shape)))
+    if packed is None or packed.numel() != nbytes:
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _check(load().ctcasr_conv_s12_pack_weights16(_dev(weight, name='weight'),
+                                                 _dev(packed, torch.uint8, 'packed'), int(cout),
+                                                 _stream()), 'conv_s12_pack_weights16')
+    return packed
+
+
+@_on_tensor_device
+def conv_s12_fwd16(x, x_scale, packed16, cout, bias=None, out=None, relu_cutoff=0.0,
+                   time_major=False):
+    """`conv_s12_fwd` with its products on the fp16 matrix pipe (two fp16 pieces per operand,
+    three products, fp32 accumulation): for x with a known bound, bound * x_scale < 65504
+    (``x_scale`` a power of two).  ``packed16`` from `conv_s12_pack_weights16`."""
+    batch, frames, freq = x.shape[0], x.shape[1], x.shape[2]
+    if x.shape[3] != 32 or not conv_s12_supported(freq, cout):
+        raise CtcAsrError('conv_s12_fwd16: unsupported layer shape {} -> {} channels'.format(
+            tuple(x.shape), cout))
+    shape = (frames, batch, freq // 2, cout) if time_major else (batch, frames, freq // 2, cout)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+    with _Timed('conv_s12_fwd'):
+        _check(load().ctcasr_conv_s12_fwd16(_dev(x, name='x'), float(x_scale),
+                                            _dev(packed16, torch.uint8, 'packed16'),
+                                            _dev(bias, name='bias'), _dev(out, name='y'), batch,
+                                            frames, freq, cout, float(relu_cutoff),
+                                            1 if time_major else 0, _stream()), 'conv_s12_fwd16')
     return out
 
 

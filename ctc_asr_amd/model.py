@@ -381,6 +381,9 @@ class CTCModel:
         # (forward, data gradient, kernel gradient; any T, no padded intermediates)
         self.own_conv = os.environ.get('CTCASR_OWN_CONV', '1') == '1'
         self._conv_packed = {}          # layer -> fragment-ordered weight copies
+        self._conv_packed16 = {}        # ... and the fp16 pieces for the fp16-pipe forward kernel
+        # forward pass of the 11 x 21 convolutions on the fp16 matrix pipe (bounded input)
+        self.conv_f16 = os.environ.get('CTCASR_CONV_F16', '1') == '1'
         # backward of the conv epilogue (mask + bias gradient) inside the gradient kernels
         self.conv_fused_bwd = os.environ.get('CTCASR_CONV_FUSED_BWD', '1') == '1'
         # Side-stream work that should run BESIDE a half-chip persistent recurrence launch waits
@@ -676,9 +679,24 @@ class CTCModel:
                     self._conv_packed[i] = hip.conv_s12_pack_weights(kernel,
                                                                      self._conv_packed.get(i))
                     last_time_major = fused and i == layers - 1
-                    y = hip.conv_s12_fwd(x.permute(0, 2, 3, 1), self._conv_packed[i],
-                                         kernel.shape[0], p['conv{}/bias'.format(i)],
-                                         relu_cutoff=cutoff, time_major=last_time_major)
+                    # the layer's input is the clipped ReLU of the layer before (fused epilogue
+                    # or `bias_act_fwd`): bounded by relu_cutoff -> the forward product on the
+                    # fp16 matrix pipe, two pieces per operand (csrc/conv16.hip)
+                    x_scale = split_gemm.f16_scale(cfg.relu_cutoff) \
+                        if (self.conv_f16 and fused and i > 0) else None
+                    if x_scale is not None:
+                        self._conv_packed16[i] = hip.conv_s12_pack_weights16(
+                            kernel, self._conv_packed16.get(i))
+                        y = hip.conv_s12_fwd16(x.permute(0, 2, 3, 1), x_scale,
+                                               self._conv_packed16[i], kernel.shape[0],
+                                               p['conv{}/bias'.format(i)], relu_cutoff=cutoff,
+                                               time_major=last_time_major)
+                    else:
+                        y = hip.conv_s12_fwd(x.permute(0, 2, 3, 1), self._conv_packed[i],
+                                             kernel.shape[0], p['conv{}/bias'.format(i)],
+                                             relu_cutoff=cutoff, time_major=last_time_major)
+                    acts.setdefault('arithmetic_front', {})['conv{}/forward'.format(i)] = \
+                        'fp16x3' if x_scale is not None else 'fp32'
                     if not last_time_major:
                         y = y.permute(0, 3, 1, 2)
                     conv_in.append(x)      # the own kernel gradient reads the plain input
@@ -727,7 +745,7 @@ class CTCModel:
         cell, hidden, gates = cfg.cell, cfg.num_units_rnn, GATES[cfg.cell]
         rnn_len = None if cfg.cudnn else seq_length
         layer_in, layer_out, reserves, drop_seeds = [], [], [], []
-        arithmetic = acts['arithmetic'] = {}
+        arithmetic = acts['arithmetic'] = dict(acts.get('arithmetic_front', {}))
         # h W_hh^T of the forward recurrence on the fp16 matrix pipe (persistent LSTM / GRU kernels)
         f16_rec = (self.rnn_fwd_f16 and cell in ('lstm', 'gru') and
                    hip.rnn_persistent_supported(cell, t_out, batch, hidden))

@@ -288,6 +288,18 @@ int ctcasr_conv_s12_pack_weights(const float *w, float *packed, int cout, ctcasr
  * conv_layers; 0 = convolution + bias only).  y_time_major / dz_time_major != 0: that tensor is
  * laid out [T, B, F, C] instead of [B, T, F, C] - the last layer of the stack hands its output
  * to the recurrent stack (and takes its gradient back) without a transpose. */
+/* ABI v5: the forward pass with its products on the fp16 matrix pipe (csrc/conv16.hip): input and
+ * weights as two fp16 pieces each, three piece products per tap, fp32 accumulation - for inputs
+ * with a known bound (behind the clipped ReLU of the previous layer): bound * x_scale < 65504,
+ * x_scale a power of two.  The weights are packed per step by ctcasr_conv_s12_pack_weights16 into
+ * `packed16` (ctcasr_conv_s12_pack16_bytes(cout) bytes: the bit pattern of max |w|, found on the
+ * device, then the pieces in fragment order under the scale derived from it). */
+size_t ctcasr_conv_s12_pack16_bytes(int cout);
+int ctcasr_conv_s12_pack_weights16(const float *w, void *packed16, int cout,
+                                   ctcasr_stream_t stream);
+int ctcasr_conv_s12_fwd16(const float *x, float x_scale, const void *packed16, const float *bias,
+                          float *y, int B, int T, int freq_in, int cout, float relu_cutoff,
+                          int y_time_major, ctcasr_stream_t stream);
 int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
                         int T, int freq_in, int cout, float relu_cutoff, int y_time_major,
                         ctcasr_stream_t stream);

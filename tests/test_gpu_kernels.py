@@ -638,6 +638,54 @@ def test_dropout_kernel(hip):
 
 
 @pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
+@pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 37), (1, 500)])
+@pytest.mark.parametrize('weight_size', [0.05, 30.0, 1e-5])
+def test_conv_s12_forward_on_the_fp16_matrix_pipe(hip, shape, layer, weight_size):
+    """`ctcasr_conv_s12_fwd16` (csrc/conv16.hip): the forward convolution with input and weights as
+    two fp16 pieces each.  Input in [0, 20] like the clipped ReLU in front of it (scale 2^11), any
+    weight magnitude (the scale comes from the kernel's own maximum, found on the device).
+    Against fp64 `conv2d` next to the fp32-MFMA kernel on the same operands: not further away
+    than 3 x its error (measured: closer); fused epilogue and time-major output as the fp32
+    kernel's; an input beyond the bound saturates to a finite result."""
+    from ctc_asr_amd import split_gemm
+    batch, frames = shape
+    freq, cout = layer
+    rng = np.random.default_rng(frames + cout)
+    x_np = np.clip(rng.normal(size=(batch, frames, freq, 32)) * 6.0, 0.0, 20.0).astype(np.float32)
+    x_np[rng.random(x_np.shape) < 0.3] *= 1e-4            # small values beside the clipped ones
+    weight = (rng.normal(size=(cout, 32, 11, 21)) * weight_size).astype(np.float32)
+    bias = (rng.normal(size=cout) * weight_size).astype(np.float32)
+    scale = split_gemm.f16_scale(20.0)
+    packed16 = hip.conv_s12_pack_weights16(_t(weight))
+    packed = hip.conv_s12_pack_weights(_t(weight))
+    y16 = hip.conv_s12_fwd16(_t(x_np), scale, packed16, cout, _t(bias))
+    y32 = hip.conv_s12_fwd(_t(x_np), packed, cout, _t(bias))
+    x = torch.zeros(batch, 32, frames + 10, freq + 19, dtype=torch.float64)
+    x[:, :, 5:5 + frames, 9:9 + freq] = torch.tensor(x_np, dtype=torch.float64).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64),
+                                     torch.tensor(bias, dtype=torch.float64), stride=(1, 2)) \
+        .permute(0, 2, 3, 1).numpy()
+    top = max(np.abs(ref).max(), 1e-30)
+    e16 = np.abs(y16.cpu().numpy() - ref).max() / top
+    e32 = np.abs(y32.cpu().numpy() - ref).max() / top
+    assert e16 < 3 * e32 + 1e-7, (e16, e32)
+    assert e16 < 2e-5, e16
+    assert not torch.equal(y16, y32)
+    cut = float(0.3 * np.abs(ref).max())
+    y_act = hip.conv_s12_fwd16(_t(x_np), scale, packed16, cout, _t(bias), relu_cutoff=cut)
+    assert torch.equal(y_act, torch.clamp(y16, 0.0, cut))
+    y_tm = hip.conv_s12_fwd16(_t(x_np), scale, packed16, cout, _t(bias), time_major=True)
+    assert torch.equal(y_tm.permute(1, 0, 2, 3), y16)
+    # re-packing into the same buffer after the weights changed (what a training step does)
+    again = hip.conv_s12_pack_weights16(_t(weight * 2), packed16)
+    assert again.data_ptr() == packed16.data_ptr()
+    y_twice = hip.conv_s12_fwd16(_t(x_np), scale, again, cout)
+    assert float((y_twice - 2 * (y16 - _t(bias))).abs().max()) <= 4e-6 * top
+    big = hip.conv_s12_fwd16(_t(x_np * 100.0), scale, again, cout)
+    assert torch.isfinite(big).all()
+
+
+@pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
 @pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (3, 65), (1, 500)])
 def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
     """Implicit-GEMM forward, data gradient and kernel gradient of the 11x21 / stride (1,2) layers (32 -> 32 channels

@@ -1,5 +1,5 @@
 // The 11 x 21, stride (1, 2) convolutions over 32 input channels (conv.hip) with their products on
-// the fp16 matrix pipe: FORWARD pass (round 4).
+// the fp16 matrix pipe: forward pass and data gradient (round 4).
 //
 // conv.hip's kernels run at 110 - 140 TFLOP/s of fp32 MFMA (157 peak): MFMA-issue bound, the last
 // fp32-MFMA kernels of the training step.  The forward product's operands are both bounded - the
@@ -90,6 +90,210 @@ conv16_pack_fwd_kernel(const float *__restrict__ w, const unsigned *__restrict__
                      (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
     dst[64] = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
                       (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+}
+
+// backward order: packed[(((tap * PASSES + pass) * 2 + nt) * 2 + piece) * 64 + kg * 16 + n] =
+// 8 halves: piece of w[co = 32 pass + 8 kg .. + 7][ci = 16 nt + n][kt][kf] * s_w
+__global__ void __launch_bounds__(256)
+conv16_pack_bwd_kernel(const float *__restrict__ w, const unsigned *__restrict__ max_bits,
+                       u32x4 *__restrict__ packed, int cout) {
+    const int passes = cout / 32;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (tap, pass, nt, lane)
+    if (i >= C16_KT * C16_KF * passes * 2 * 64) return;
+    const int lane = i & 63, nt = (i >> 6) & 1, pass = (i >> 7) % passes, tap = (i >> 7) / passes;
+    const int n = lane & 15, kg = lane >> 4, kt = tap / C16_KF, kf = tap % C16_KF;
+    const float s_w = scale_below_f16_max(*max_bits);
+    unsigned q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        q[e] = f16_pieces(w[(((size_t)(32 * pass + 8 * kg + e) * C16_CIN + 16 * nt + n) * C16_KT + kt) *
+                                C16_KF + kf] * s_w);
+    u32x4 *dst = packed + ((size_t)((tap * passes + pass) * 2 + nt) * 2) * 64 + lane;
+    dst[0] = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                     (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+    dst[64] = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                      (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL,
+                                                                 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float4 mask_dz16(float4 g, const float *act, size_t index4, float upper) {
+    if (act) {
+        const float4 v = reinterpret_cast<const float4 *>(act)[index4];
+        g.x = (v.x > 0.f && v.x < upper) ? g.x : 0.f;
+        g.y = (v.y > 0.f && v.y < upper) ? g.y : 0.f;
+        g.z = (v.z > 0.f && v.z < upper) ? g.z : 0.f;
+        g.w = (v.w > 0.f && v.w < upper) ? g.w : 0.f;
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// data gradient.  dz has no bound (gradients span decades) - but a product only needs a common
+// scale along its K axis, and all taps of one kt pair an output row with dz cells of ONE frame:
+// every dz FRAME of the patch (all positions x the 32 channels of the pass) carries its own power
+// of two.  Staging is two-phase: the slice is loaded into registers while an LDS atomicMax per
+// frame finds the largest magnitude, then scaled into [2^13, 2^14), split into two fp16 pieces
+// and written to the patch.  The 10 / 11 taps of a (kt, parity) accumulate in fp32 by MFMA from
+// a zero accumulator; the result enters the total times the frame's inverse scale (4 FMAs per
+// ~32 MFMAs): 22 significand bits relative to the largest gradient of a frame of the patch - the
+// granularity of the data gradient GEMM's per-row scales.
+// ---------------------------------------------------------------------------------------------
+template <int COUT, int FI>
+__global__ void __launch_bounds__(256)
+conv16_bwd_data_kernel(const float *__restrict__ dz, const u32x4 *__restrict__ wp,
+                       const unsigned *__restrict__ w_max_bits, float *__restrict__ dx, int T,
+                       int dz_time_major, const float *__restrict__ act, float upper) {
+    using G = Geometry16<COUT, FI>;
+    constexpr int PASSES = COUT / 32;
+    constexpr int CH = G::PT > 32 ? 2 : 1;                  // staging chunks (whole frames)
+    constexpr int FPC = (G::PT + CH - 1) / CH;              // frames per chunk
+    constexpr int NV = (FPC * G::PF * 8 + 255) / 256;       // float4 per thread and chunk
+    extern __shared__ __attribute__((aligned(16))) char patch[];    // [PT][PF][C16_CELL], then
+    unsigned *fmax = reinterpret_cast<unsigned *>(patch + G::LDS);  // per frame: max bits,
+    float *finv = reinterpret_cast<float *>(fmax + G::PT);          // inverse scale
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * G::TT, b = blockIdx.y;
+    const int kg = lane >> 4, n = lane & 15;
+    const float out_scale = 1.0f / scale_below_f16_max(*w_max_bits);
+
+    int base_a[5], frame_c[5][4];       // byte offset of the A-fragment rows / patch frame of the
+#pragma unroll                          // accumulator rows (before the kt shift)
+    for (int ti = 0; ti < 5; ++ti) {
+        const int row = ti * 16 + n, tt = row / G::FO, j = row % G::FO;
+        base_a[ti] = (((G::TT / 4) * wave + tt) * G::PF + j) * C16_CELL + 16 * kg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) frame_c[ti][r] = (G::TT / 4) * wave + (ti * 16 + 4 * kg + r) / G::FO;
+    }
+    f32x4 acc[2][5][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[p][ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        // ---- stage dz[b, t0-5 .. , :, 32 pass .. 32 pass + 31] with 5 zero positions each side ----
+        __syncthreads();                        // (everyone is done with the previous patch)
+        if (tid < G::PT) fmax[tid] = 0u;
+        __syncthreads();
+        // (in CH chunks of whole frames, so that a thread holds at most NV float4 at a time)
+#pragma unroll 1
+        for (int ch = 0; ch < CH; ++ch) {
+            float4 v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = ch * FPC * G::PF * 8 + tid + k * 256;
+                const int c4 = i & 7, pos = (i >> 3) % G::PF, pr = i / (8 * G::PF);
+                const int ts = t0 - 5 + pr, fo = pos - 5;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tid + k * 256 < FPC * G::PF * 8 && pr < G::PT && ts >= 0 && ts < T && fo >= 0 &&
+                    fo < G::FO) {
+                    const size_t cell = dz_time_major ? (size_t)ts * gridDim.y + b
+                                                      : (size_t)b * T + ts;
+                    const size_t at = (cell * G::FO + fo) * (COUT / 4) + pass * 8 + c4;
+                    v[k] = mask_dz16(reinterpret_cast<const float4 *>(dz)[at], act, at, upper);
+                    const float m = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)),
+                                          fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+                    if (m > 0.f) atomicMax(fmax + pr, __float_as_uint(m));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = ch * FPC * G::PF * 8 + tid + k * 256;
+                const int c4 = i & 7, pos = (i >> 3) % G::PF, pr = i / (8 * G::PF);
+                if (tid + k * 256 >= FPC * G::PF * 8 || pr >= G::PT) continue;
+                const unsigned mbits = fmax[pr];
+                const int me = (int)((mbits >> 23) & 0xFF) - 127;
+                const int mse = (mbits == 0u || me > 127) ? 0 : min(max(13 - me, -100), 100);
+                const float sc = __uint_as_float((unsigned)(mse + 127) << 23);
+                const unsigned q0 = f16_pieces(v[k].x * sc), q1 = f16_pieces(v[k].y * sc),
+                               q2 = f16_pieces(v[k].z * sc), q3 = f16_pieces(v[k].w * sc);
+                char *cellp = patch + (pr * G::PF + pos) * C16_CELL;
+                *reinterpret_cast<u32x2 *>(cellp + 8 * c4) =
+                    (u32x2){(q0 & 0xFFFFu) | (q1 << 16), (q2 & 0xFFFFu) | (q3 << 16)};
+                *reinterpret_cast<u32x2 *>(cellp + 64 + 8 * c4) =
+                    (u32x2){(q0 >> 16) | (q1 & 0xFFFF0000u), (q2 >> 16) | (q3 & 0xFFFF0000u)};
+                if (c4 == 0 && pos == 0) finv[pr] = __uint_as_float((unsigned)(127 - mse) << 23);
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int kt = 0; kt < C16_KT; ++kt) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                // even output frequencies (f = 2j) meet the odd kf, odd ones (f = 2j+1) the even
+                // kf; dz position = j + 4 + p - m (+5 for the zero border) with m = kf / 2
+                const int taps = p == 0 ? 10 : 11;
+                f32x4 part[5][2];
+#pragma unroll
+                for (int m = 0; m < taps; ++m) {
+                    const int kf = p == 0 ? 2 * m + 1 : 2 * m;
+                    const u32x4 *wt = wp + (size_t)(((kt * C16_KF + kf) * PASSES + pass) * 2) * 2 * 64 +
+                                      lane;
+                    const int tap_off = ((10 - kt) * G::PF + 9 + p - m) * C16_CELL;
+                    Frag16 a1[5], a2[5];
+#pragma unroll
+                    for (int ti = 0; ti < 5; ++ti) {
+                        a1[ti].u = *reinterpret_cast<const u32x4 *>(patch + base_a[ti] + tap_off);
+                        a2[ti].u = *reinterpret_cast<const u32x4 *>(patch + base_a[ti] + tap_off + 64);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        Frag16 w1, w2;
+                        w1.u = wt[nt * 128];
+                        w2.u = wt[nt * 128 + 64];
+#pragma unroll
+                        for (int ti = 0; ti < 5; ++ti)
+                            part[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                a1[ti].h, w1.h, m == 0 ? zero : part[ti][nt], 0, 0, 0);
+#pragma unroll
+                        for (int ti = 0; ti < 5; ++ti)
+                            part[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                a1[ti].h, w2.h, part[ti][nt], 0, 0, 0);
+#pragma unroll
+                        for (int ti = 0; ti < 5; ++ti)
+                            part[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                a2[ti].h, w1.h, part[ti][nt], 0, 0, 0);
+                    }
+                }
+                // the taps of this kt read dz frame (row frame + 10 - kt): its inverse scale
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float inv = finv[frame_c[ti][r] + 10 - kt];
+                        acc[p][ti][0][r] += part[ti][0][r] * inv;
+                        acc[p][ti][1][r] += part[ti][1][r] * inv;
+                    }
+            }
+        }
+    }
+
+    // ---- write dx[b, t, 2j + p, ci] ---------------------------------------------------------------
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + 4 * kg + r, tt = row / G::FO, j = row % G::FO;
+                const int t = t0 + (G::TT / 4) * wave + tt;
+                if (t < T) {
+                    float *out = dx + ((size_t)(b * T + t) * FI + 2 * j + p) * C16_CIN + n;
+                    out[0] = acc[p][ti][0][r] * out_scale;
+                    out[16] = acc[p][ti][1][r] * out_scale;
+                }
+            }
 }
 
 template <int COUT, int FI>
@@ -231,6 +435,20 @@ int launch_fwd16(const float *x, float x_scale, const void *packed, const unsign
     return ctcasr_launch_status();
 }
 
+template <int COUT, int FI>
+int launch_bwd16(const float *dz, const void *packed, const unsigned *w_max_bits, float *dx, int B,
+                 int T, int dz_time_major, const float *act, float upper, hipStream_t s) {
+    using G = Geometry16<COUT, FI>;
+    const size_t lds = G::LDS + (size_t)G::PT * 8;          // + per-frame maxima / inverse scales
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv16_bwd_data_kernel<COUT, FI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    dim3 grid((T + G::TT - 1) / G::TT, B);
+    conv16_bwd_data_kernel<COUT, FI><<<grid, 256, lds, s>>>(
+        dz, reinterpret_cast<const u32x4 *>(packed), w_max_bits, dx, T, dz_time_major, act, upper);
+    return ctcasr_launch_status();
+}
+
 bool covered16(int freq_in, int cout) {
     return (freq_in == 40 && cout == 32) || (freq_in == 20 && cout == 96);
 }
@@ -238,9 +456,12 @@ bool covered16(int freq_in, int cout) {
 }  // namespace
 
 // bytes of the fragment-ordered fp16 pieces of a layer's kernel (+ 16 for the magnitude word)
+static size_t pack16_order_bytes(int cout) {     // one order: 2 pieces x 2 bytes per weight
+    return (size_t)C16_KT * C16_KF * C16_CIN * cout * 4;
+}
 extern "C" size_t ctcasr_conv_s12_pack16_bytes(int cout) {
     if (cout != 32 && cout != 96) return 0;
-    return (size_t)C16_KT * C16_KF * (cout / 16) * 2 * 64 * 16 + 16;
+    return 16 + 2 * pack16_order_bytes(cout);   // magnitude word, forward order, backward order
 }
 
 // w [cout, 32, 11, 21] -> `packed`: one word with the bit pattern of max |w| (16 bytes reserved),
@@ -257,7 +478,30 @@ extern "C" int ctcasr_conv_s12_pack_weights16(const float *w, void *packed, int 
     const int threads = C16_KT * C16_KF * (cout / 16) * 64;
     conv16_pack_fwd_kernel<<<(threads + 255) / 256, 256, 0, s>>>(
         w, max_bits, reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(packed) + 16), cout);
+    const int threads_b = C16_KT * C16_KF * (cout / 32) * 2 * 64;
+    conv16_pack_bwd_kernel<<<(threads_b + 255) / 256, 256, 0, s>>>(
+        w, max_bits,
+        reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(packed) + 16 + pack16_order_bytes(cout)),
+        cout);
     return ctcasr_launch_status();
+}
+
+// dx = data gradient like ctcasr_conv_s12_bwd_data, the products as fp16 x 3 with a power-of-two
+// scale per dz frame of a workgroup's patch found while it is staged: no bound on dz is assumed.
+extern "C" int ctcasr_conv_s12_bwd_data16(const float *dz, const void *packed, float *dx, int B,
+                                          int T, int freq_in, int cout, int dz_time_major,
+                                          const float *act, float relu_cutoff,
+                                          ctcasr_stream_t stream) {
+    if (!dz || !packed || !dx || B <= 0 || T <= 0 || (act && relu_cutoff <= 0.f))
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (!covered16(freq_in, cout) || B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned *max_bits = reinterpret_cast<const unsigned *>(packed);
+    const void *pieces = reinterpret_cast<const char *>(packed) + 16 + pack16_order_bytes(cout);
+    if (cout == 32)
+        return launch_bwd16<32, 40>(dz, pieces, max_bits, dx, B, T, dz_time_major, act,
+                                    relu_cutoff, s);
+    return launch_bwd16<96, 20>(dz, pieces, max_bits, dx, B, T, dz_time_major, act, relu_cutoff, s);
 }
 
 // y = conv(x) + bias like ctcasr_conv_s12_fwd, the products as fp16 x 3 on the 16-bit matrix pipe.

@@ -67,6 +67,7 @@ SIGNATURES = {
     'ctcasr_conv_s12_pack_weights16': (_c_int, [_c_p, _c_p, _c_int, _c_p]),
     'ctcasr_conv_s12_fwd16': (_c_int, [_c_p, _c_f, _c_p, _c_p, _c_p] + [_c_int] * 4 +
                               [_c_f, _c_int, _c_p]),
+    'ctcasr_conv_s12_bwd_data16': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
     'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
     'ctcasr_conv_s12_wrw_workspace_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_conv_s12_wrw': (_c_int, [_c_p] * 3 + [_c_int] * 5 + [_c_p, _c_f, _c_p] +
@@ -782,6 +783,29 @@ def conv_s12_bwd_data(dz, packed, out=None, time_major=False, act=None, relu_cut
                                                2 * freq_out, cout, 1 if time_major else 0,
                                                _dev(act, name='act'), float(relu_cutoff),
                                                _stream()), 'conv_s12_bwd_data')
+    return out
+
+
+@_on_tensor_device
+def conv_s12_bwd_data16(dz, packed16, out=None, time_major=False, act=None, relu_cutoff=0.0):
+    """`conv_s12_bwd_data` with its products on the fp16 matrix pipe: every dz cell (frame,
+    position) is scaled by its own power of two while it is staged - no bound on dz is assumed.
+    ``packed16`` from `conv_s12_pack_weights16`."""
+    if time_major:
+        frames, batch, freq_out, cout = dz.shape
+    else:
+        batch, frames, freq_out, cout = dz.shape
+    if not conv_s12_supported(2 * freq_out, cout):
+        raise CtcAsrError('conv_s12_bwd_data16: unsupported layer shape {}'.format(tuple(dz.shape)))
+    out = torch.empty((batch, frames, 2 * freq_out, 32), dtype=torch.float32, device=dz.device) \
+        if out is None else out
+    with _Timed('conv_s12_bwd_data'):
+        _check(load().ctcasr_conv_s12_bwd_data16(_dev(dz, name='dz'),
+                                                 _dev(packed16, torch.uint8, 'packed16'),
+                                                 _dev(out, name='dx'), batch, frames,
+                                                 2 * freq_out, cout, 1 if time_major else 0,
+                                                 _dev(act, name='act'), float(relu_cutoff),
+                                                 _stream()), 'conv_s12_bwd_data16')
     return out
 
 

@@ -643,7 +643,7 @@ class CTCModel:
         cfg, p = self.cfg, self.arena.p
         sequences = sequences.to(self.device, torch.float32).contiguous()
         batch, frames, _ = sequences.shape
-        acts = {'training': training, 'batch': batch}
+        acts = {'training': training, 'batch': batch, 'conv_f16': {}}
         self._prepare_weight_splits(cfg.output_time(frames) * batch, training)
         if cfg.used_model == 'ds2':
             # conv dropout: the reference never forwards `training` to conv_layers, so a
@@ -697,6 +697,7 @@ class CTCModel:
                                              relu_cutoff=cutoff, time_major=last_time_major)
                     acts.setdefault('arithmetic_front', {})['conv{}/forward'.format(i)] = \
                         'fp16x3' if x_scale is not None else 'fp32'
+                    acts.setdefault('conv_f16', {})[i] = x_scale is not None
                     if not last_time_major:
                         y = y.permute(0, 3, 1, 2)
                     conv_in.append(x)      # the own kernel gradient reads the plain input
@@ -1469,7 +1470,11 @@ class CTCModel:
                     hip.conv_s12_wrw(dz_phys, conv_in.permute(0, 2, 3, 1), out=g[name + '/kernel'],
                                      time_major=tm,
                                      dbias=g[name + '/bias'] if fused_bwd else None, **mask)
-                    if i > 0:
+                    if i > 0 and acts['conv_f16'].get(i):
+                        # (the fp16 pieces of this step's weights, packed by the forward pass)
+                        dact = hip.conv_s12_bwd_data16(dz_phys, self._conv_packed16[i],
+                                                       time_major=tm, **mask)
+                    elif i > 0:
                         dact = hip.conv_s12_bwd_data(dz_phys, self._conv_packed[i],
                                                      time_major=tm, **mask)
                     done(name)

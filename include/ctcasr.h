@@ -300,6 +300,12 @@ int ctcasr_conv_s12_pack_weights16(const float *w, void *packed16, int cout,
 int ctcasr_conv_s12_fwd16(const float *x, float x_scale, const void *packed16, const float *bias,
                           float *y, int B, int T, int freq_in, int cout, float relu_cutoff,
                           int y_time_major, ctcasr_stream_t stream);
+/* ... and the data gradient (arguments of ctcasr_conv_s12_bwd_data): dz has no bound, so every dz
+ * frame of a workgroup's patch (all taps of one kt read one frame) gets its own power-of-two
+ * scale while it is staged; the weights' pieces are the backward-order half of `packed16`. */
+int ctcasr_conv_s12_bwd_data16(const float *dz, const void *packed16, float *dx, int B, int T,
+                               int freq_in, int cout, int dz_time_major, const float *act,
+                               float relu_cutoff, ctcasr_stream_t stream);
 int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
                         int T, int freq_in, int cout, float relu_cutoff, int y_time_major,
                         ctcasr_stream_t stream);

@@ -686,6 +686,46 @@ def test_conv_s12_forward_on_the_fp16_matrix_pipe(hip, shape, layer, weight_size
 
 
 @pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
+@pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 37), (1, 500)])
+def test_conv_s12_data_gradient_on_the_fp16_matrix_pipe(hip, shape, layer):
+    """`ctcasr_conv_s12_bwd_data16`: dz over eight decades across frames and utterances (a
+    power-of-two scale per dz frame of a workgroup's patch, found while it is staged), zero cells,
+    the fused epilogue mask and the time-major layout; against fp64 autograd next to the fp32-MFMA
+    kernel: per (utterance, frame) the error relative to that frame's largest gradient is not
+    above 3 x the fp32 kernel's."""
+    batch, frames = shape
+    freq, cout = layer
+    rng = np.random.default_rng(3 * frames + cout)
+    x_np = rng.normal(size=(batch, frames, freq, 32)).astype(np.float32)
+    dz = rng.normal(size=(batch, frames, freq // 2, cout))
+    dz *= 10.0 ** rng.uniform(-8, 0, size=(batch, frames, 1, 1))
+    dz[rng.random(dz.shape[:3]) < 0.1] = 0.0
+    dz = dz.astype(np.float32)
+    weight = (rng.normal(size=(cout, 32, 11, 21)) * 0.05).astype(np.float32)
+    packed = hip.conv_s12_pack_weights(_t(weight))
+    packed16 = hip.conv_s12_pack_weights16(_t(weight))
+    dx32 = hip.conv_s12_bwd_data(_t(dz), packed)
+    dx16 = hip.conv_s12_bwd_data16(_t(dz), packed16)
+    x = torch.zeros(batch, 32, frames + 10, freq + 19, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64), stride=(1, 2))
+    y.backward(torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
+    ref = x.grad[:, :, 5:5 + frames, 9:9 + freq].permute(0, 2, 3, 1)
+    top = ref.abs().amax(dim=(2, 3)).clamp_min(1e-300)
+
+    def frame_err(got):
+        return float(((got.double().cpu() - ref).abs().amax(dim=(2, 3)) / top).max())
+    e16, e32 = frame_err(dx16), frame_err(dx32)
+    assert e16 < 3 * e32 + 1e-6, (e16, e32)
+    assert not torch.equal(dx16, dx32)
+    dz_tm = _t(dz).permute(1, 0, 2, 3).contiguous()
+    assert torch.equal(hip.conv_s12_bwd_data16(dz_tm, packed16, time_major=True), dx16)
+    act = _t(rng.uniform(-1.0, 2.5, size=dz.shape).astype(np.float32))
+    masked = _t(dz) * ((act > 0) & (act < 1.5)).float()
+    assert torch.equal(hip.conv_s12_bwd_data16(_t(dz), packed16, act=act, relu_cutoff=1.5),
+                       hip.conv_s12_bwd_data16(masked, packed16))
+
+
+@pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
 @pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (3, 65), (1, 500)])
 def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
     """Implicit-GEMM forward, data gradient and kernel gradient of the 11x21 / stride (1,2) layers (32 -> 32 channels

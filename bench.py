@@ -83,6 +83,9 @@ def dtype_label(model):
              if on]
     rec = '; {} recurrence (h x W_hh / dgates x W_hh) as fp16x3 split, fp32 accumulate'.format(
         ' and '.join(which)) if which else ''
+    if getattr(model, 'conv_f16', False) and len(model.cfg.conv_filters) > 1 and \
+            model.cfg.used_model == 'ds2':
+        rec += '; the 32-input-channel convolutions (forward, data gradient) as fp16x3 split'
     if not model.split_gemm:
         return 'f32' if not rec else 'f32 tensors / accumulate / GEMMs' + rec
     gemms = 'bf16x6 split (24 significand bits)'
@@ -705,12 +708,16 @@ def measure_c5(args, rank, local_rank, world):
         rnn_flops = sum(2.0 * 2 * batch * hidden * gates * hidden * item['t_out'] * layers
                         for item in batches)
         t_outs = [item['t_out'] for item in batches]
+        arith = model.arithmetic()
+        bwd_f16 = bool(model.rnn_bwd_f16 and arith.get('rnn0/recurrence_fwd') == 'fp16x3')
+        bwd_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if bwd_f16 else FP32_MFMA_PEAK_TFLOPS
         result = {
             'metric': 'audio-seconds/s training throughput (DS2, mixed-length bucketed batches '
                       '0.7-17 s)',
             'value': round(audio_s / elapsed, 2), 'unit': 'audio-s/s', 'n_gpus': world,
             'steps': steps, 'warmup': steps, 'ms_per_step': round(elapsed / steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': dtype_label(model),
             'data': 'synthetic (16 kHz int16 Gaussian-noise PCM resident in HBM, durations from a '
                     'log-normal (median 10.5 s) filtered to [0.7, 17] s, 96 buckets, seeded order; random labels '
                     'at 15 chars/s)',
@@ -739,16 +746,24 @@ def measure_c5(args, rank, local_rank, world):
                 'note': 'evaluation path: eval-mode forward per batch, logits kept, beam search '
                         'in grouped launches (CTCModel.decode_many), host conversion included'},
             'roofline': {
-                'kernel': 'prnn_bwd_kernel<LSTM> over the whole bucket sequence (launches of '
-                          'T\'/2 steps x 2 directions, batch {})'.format(batch),
-                'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': FP32_MFMA_PEAK_TFLOPS,
+                'kernel': 'prnn_bwd{}_kernel<LSTM> over the whole bucket sequence (launches of '
+                          'T\'/2 steps x 2 directions, batch {})'.format(
+                              '16' if bwd_f16 else '', batch),
+                'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': round(bwd_peak, 1),
+                'pipe': 'fp16 MFMA, 3 piece products per fp32 product (peak = 2500 / 3 '
+                        'fp32-equivalent TFLOP/s)' if bwd_f16 else 'fp32 MFMA',
                 'achieved': round(rnn_flops / (bwd_ms * 1e-3) / 1e12, 2) if bwd_ms else None,
-                'frac': round(rnn_flops / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                'frac': round(rnn_flops / (bwd_ms * 1e-3) / 1e12 / bwd_peak, 4)
                 if bwd_ms else None,
+                'frac_of_fp32_mfma_peak':
+                    round(rnn_flops / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                    if bwd_ms else None,
                 'traffic': None, 'launches': bwd_calls,
                 'avg_launch_us': round(bwd_ms * 1e3 / max(bwd_calls, 1), 1),
                 'cus_occupied': 128,
-                'other_pass': {'kernel': 'prnn_fwd_kernel', 'launches': fwd_calls,
+                'other_pass': {'kernel': 'prnn_fwd{}_kernel'.format(
+                                   '16' if arith.get('rnn0/recurrence_fwd') == 'fp16x3' else ''),
+                               'launches': fwd_calls,
                                'achieved': round(rnn_flops / (fwd_ms * 1e-3) / 1e12, 2)
                                if fwd_ms else None}},
         }

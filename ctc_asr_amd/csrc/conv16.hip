@@ -449,6 +449,296 @@ int launch_bwd16(const float *dz, const void *packed, const unsigned *w_max_bits
     return ctcasr_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel gradient on the fp16 pipe:
+//   dw[co, ci, kt, kf] = sum_{b,t,fo} dz[b, t, fo, co] * x[b, t + kt - 5, 2 fo + kf - 9, ci]
+// The summation axis (b, t, fo) is the MFMA's K axis, and a lane's 8 consecutive k must sit in 16
+// contiguous, aligned bytes for BOTH operands whatever the tap: kt shifts t, kf shifts 2 fo - the
+// utterance index b is the one axis no tap shifts.  So a pack pass (HBM-bound, ~50 us at C3)
+// first writes both operands as fp16 pieces with 8 utterances innermost:
+//   x16  [b / 8][t][f ][piece][ci  ][b % 8]      (x * x_scale; x is bounded, see the forward pass)
+//   dz16 [b / 8][t][fo][piece][cout][b % 8]      (masked dz * s[co])
+// with a power-of-two scale per output channel (the non-contracted index of dz) from the channel's
+// largest |dz| (found by wrw16_colmax_kernel, which also leaves the bias gradient) - the
+// convention of the weight-gradient GEMMs (split_gemm.wgrad16): 22 significand bits relative to
+// the channel's largest gradient.  The conversion happens ONCE per element, not once per kt
+// workgroup (11 x), and the main kernel's staging is a flat 16-byte copy: a tile = one frame t x
+// 8 utterances = FO K slots of 8; its x slice [FI][2][32][8] halves lands at position 9 of an LDS
+// line [FI + 20 positions] whose borders stay zero; a K step = 4 slots (fo = 4 q + g for k group
+// g): A fragment dzs[fo][piece][co], B fragment xs[2 fo + kf][piece][ci] - one ds_read_b128 each,
+// contiguous per 16 lanes, conflict-free.  Grid (splits, 11 kt, cout / 32) as in conv.hip; a wave
+// owns one ci tile x both co tiles x half of the 21 kf taps: per K step 4 A reads, 2 B reads per
+// tap and 6 MFMAs per tap (88 accumulator registers).  80 KB of LDS at FI = 40: two workgroups
+// per CU, one staging while the other multiplies.
+// ---------------------------------------------------------------------------------------------
+template <int FI>
+struct Wrw16Geometry {
+    static constexpr int FO = FI / 2;
+    static constexpr int KS = (FO + 3) / 4;              // K steps per tile
+    static constexpr int SLOTS = 4 * KS;                 // dz slots (those >= FO stay zero)
+    static constexpr int PF = 2 * (SLOTS - 1) + C16_KF;  // positions 2 fo + kf
+    static constexpr int PFA = (PF + 3) & ~3;
+    static constexpr int X_CELLS = FI * 64;              // 16-byte cells of a tile's x slice
+    static constexpr int DZ_CELLS = FO * 64;             // ... of its dz slice (32 channels)
+    static constexpr int X_PER = (X_CELLS + 255) / 256, DZ_PER = (DZ_CELLS + 255) / 256;
+    static constexpr size_t LDS = ((size_t)PFA + SLOTS) * 1024;
+};
+
+// Column maxima and column sums of the masked dz [rows, cout]: max_bits[cout] (zeroed by the
+// caller) raised to the bit patterns of max |dz|, dbias[cout] += sums (optional).
+// gridDim.x * 256 must be a multiple of cout / 4.
+__global__ void __launch_bounds__(256)
+wrw16_colmax_kernel(const float *__restrict__ dz, const float *__restrict__ act, float upper,
+                    long cells4, int cout, unsigned *__restrict__ max_bits,
+                    float *__restrict__ dbias) {
+    __shared__ unsigned lmax[96];
+    __shared__ float lsum[96];
+    const int tid = threadIdx.x;
+    if (tid < 96) {
+        lmax[tid] = 0u;
+        lsum[tid] = 0.f;
+    }
+    __syncthreads();
+    const long stride = (long)gridDim.x * 256;
+    const long first = (long)blockIdx.x * 256 + tid;
+    const int c4 = (int)(first % (cout / 4));
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = first; i < cells4; i += stride) {
+        const float4 v = mask_dz16(reinterpret_cast<const float4 *>(dz)[i], act, (size_t)i, upper);
+        m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y));
+        m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    atomicMax(&lmax[4 * c4 + 0], __float_as_uint(m.x));
+    atomicMax(&lmax[4 * c4 + 1], __float_as_uint(m.y));
+    atomicMax(&lmax[4 * c4 + 2], __float_as_uint(m.z));
+    atomicMax(&lmax[4 * c4 + 3], __float_as_uint(m.w));
+    if (dbias) {
+        atomicAdd(&lsum[4 * c4 + 0], sum.x);
+        atomicAdd(&lsum[4 * c4 + 1], sum.y);
+        atomicAdd(&lsum[4 * c4 + 2], sum.z);
+        atomicAdd(&lsum[4 * c4 + 3], sum.w);
+    }
+    __syncthreads();
+    if (tid < cout) {
+        atomicMax(max_bits + tid, lmax[tid]);
+        if (dbias) atomicAdd(dbias + tid, lsum[tid]);
+    }
+}
+
+__device__ __forceinline__ void store_pieces8(u32x4 *dst, int piece_stride, const unsigned (&q)[8]) {
+    dst[0] = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                     (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+    dst[piece_stride] =
+        (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+}
+
+// x f32[B, T, FI, 32] -> x16 [(b / 8) T FI][piece][ci] cells of 8 halves (utterances b % 8)
+__global__ void __launch_bounds__(256)
+wrw16_pack_x_kernel(const float *__restrict__ x, float x_scale, u32x4 *__restrict__ x16, int B,
+                    long per_utt /* T FI 32 */, long cells /* ceil(B / 8) per_utt */) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    const long within = i % per_utt;
+    const int b0 = (int)(i / per_utt) * 8;
+    unsigned q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        q[e] = b0 + e < B ? f16_pieces(x[(long)(b0 + e) * per_utt + within] * x_scale) : 0u;
+    // cell index: ((bblk T FI + t FI + f) 2 + piece) 32 + ci
+    const long row = i / C16_CIN;
+    store_pieces8(x16 + row * 64 + (i % C16_CIN), 32, q);
+}
+
+// dz f32[B, T, FO, cout] (or [T, B, FO, cout]) -> dz16 [(b / 8) T FO][piece][cout] cells, masked
+// and scaled per channel
+__global__ void __launch_bounds__(256)
+wrw16_pack_dz_kernel(const float *__restrict__ dz, const float *__restrict__ act, float upper,
+                     const unsigned *__restrict__ max_bits, u32x4 *__restrict__ dz16, int B, int T,
+                     int fo_cout /* FO cout */, int cout, int time_major, long cells) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    const long per_utt = (long)T * fo_cout;
+    const long within = i % per_utt;
+    const int b0 = (int)(i / per_utt) * 8;
+    const int co = (int)(within % cout);
+    const int t = (int)(within / fo_cout);
+    const long in_frame = within % fo_cout;
+    const float s = scale_below_f16_max(max_bits[co]);
+    unsigned q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        q[e] = 0u;
+        if (b0 + e < B) {
+            const long at = time_major ? ((long)t * B + b0 + e) * fo_cout + in_frame
+                                       : (long)(b0 + e) * per_utt + within;
+            float v = dz[at];
+            if (act) {
+                const float a = act[at];
+                v = (a > 0.f && a < upper) ? v : 0.f;
+            }
+            q[e] = f16_pieces(v * s);
+        }
+    }
+    const long row = i / cout;                       // (bblk, t, fo)
+    store_pieces8(dz16 + row * 2 * cout + co, cout, q);
+}
+
+template <int FI>
+__global__ void __launch_bounds__(256, 2)
+wrw16_kernel(const u32x4 *__restrict__ x16, const u32x4 *__restrict__ dz16,
+             float *__restrict__ partial, int nblk, int T, int cout) {
+    using G = Wrw16Geometry<FI>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm16[];
+    u32x4 *xs = reinterpret_cast<u32x4 *>(wsm16);                    // [PFA][2][32] cells
+    u32x4 *dzs = xs + G::PFA * 64;                                   // [SLOTS][2][32] cells
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, nsplit = gridDim.x, kt = blockIdx.y, cg = blockIdx.z;
+    const int n = lane & 15, g = lane >> 4;
+    const int ci_tile = wave & 1, half = wave >> 1;
+    const int kf0 = half ? 11 : 0;
+    constexpr int TAPS = 11;                    // half 1 owns 10: its last one is skipped
+    const int tiles = nblk * T;
+
+    // borders of the position line and the unused dz slots: zero for the whole kernel
+    for (int i = tid; i < (G::PFA + G::SLOTS) * 64; i += 256) xs[i] = (u32x4){0u, 0u, 0u, 0u};
+
+    f32x4 acc[TAPS][2];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+        acc[k][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[k][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // tile = t * nblk + bblk; it contributes if frame t + kt - 5 of x exists
+    auto next_valid = [&](int tile) {
+        while (tile < tiles) {
+            const int ts = tile / nblk + kt - 5;
+            if (ts >= 0 && ts < T) break;
+            tile += nsplit;
+        }
+        return tile;
+    };
+    u32x4 rx[G::X_PER], rdz[G::DZ_PER];
+    auto fetch = [&](int tile) {
+        const int t = tile / nblk, bblk = tile % nblk;
+        const u32x4 *xsrc = x16 + ((size_t)bblk * T + (t + kt - 5)) * G::X_CELLS;
+#pragma unroll
+        for (int j = 0; j < G::X_PER; ++j) {
+            const int i = tid + j * 256;
+            if (G::X_CELLS % 256 == 0 || i < G::X_CELLS) rx[j] = xsrc[i];
+        }
+        // dz cells of a (slot, piece): cout of them, this workgroup's 32 at 32 cg
+        const u32x4 *dsrc = dz16 + ((size_t)bblk * T + t) * G::FO * 2 * cout + cg * 32;
+#pragma unroll
+        for (int j = 0; j < G::DZ_PER; ++j) {
+            const int i = tid + j * 256;
+            if (G::DZ_CELLS % 256 == 0 || i < G::DZ_CELLS) rdz[j] = dsrc[(i >> 5) * cout + (i & 31)];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < G::X_PER; ++j) {
+            const int i = tid + j * 256;
+            if (G::X_CELLS % 256 == 0 || i < G::X_CELLS) xs[9 * 64 + i] = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < G::DZ_PER; ++j) {
+            const int i = tid + j * 256;
+            if (G::DZ_CELLS % 256 == 0 || i < G::DZ_CELLS) dzs[i] = rdz[j];
+        }
+    };
+
+    int tile = next_valid(split);
+    if (tile < tiles) fetch(tile);
+    while (tile < tiles) {
+        __syncthreads();                 // the previous tile's fragment reads (first: the zeros)
+        stage();
+        __syncthreads();
+        const int next = next_valid(tile + nsplit);
+        if (next < tiles) fetch(next);
+#pragma unroll 1
+        for (int q = 0; q < G::KS; ++q) {
+            const int slot = 4 * q + g;
+            Frag16 a1[2], a2[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                a1[c].u = dzs[(slot * 2 + 0) * 32 + c * 16 + n];
+                a2[c].u = dzs[(slot * 2 + 1) * 32 + c * 16 + n];
+            }
+            const u32x4 *xb = xs + ((2 * slot + kf0) * 2) * 32 + ci_tile * 16 + n;
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) {
+                if (k < TAPS - 1 || !half) {               // wave-uniform
+                    Frag16 b1, b2;
+                    b1.u = xb[k * 64];
+                    b2.u = xb[k * 64 + 32];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        acc[k][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[c].h, b1.h, acc[k][c], 0, 0, 0);
+                        acc[k][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[c].h, b2.h, acc[k][c], 0, 0, 0);
+                        acc[k][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[c].h, b1.h, acc[k][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+    // D[row = 4 g + r][col = n]: co = 16 c + 4 g + r, ci = 16 ci_tile + n
+    float *out = partial + (((size_t)split * gridDim.z + cg) * C16_KT + kt) * C16_KF * 1024;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+        if (k < TAPS - 1 || !half) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(size_t)(kf0 + k) * 1024 + (c * 16 + 4 * g + r) * C16_CIN + ci_tile * 16 +
+                        n] = acc[k][c][r];
+        }
+    }
+}
+
+// dw[co][ci][kt][kf] = sum over splits of partial[split][co / 32][kt][kf][co % 32][ci], scales out
+__global__ void wrw16_reduce_kernel(const float *__restrict__ partial,
+                                    const unsigned *__restrict__ max_bits, float inv_x_scale,
+                                    float *__restrict__ dw, int nsplit, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * C16_CIN * C16_KT * C16_KF;
+    if (i >= total) return;
+    const int kf = i % C16_KF, kt = (i / C16_KF) % C16_KT, ci = (i / (C16_KF * C16_KT)) % C16_CIN;
+    const int co = i / (C16_KF * C16_KT * C16_CIN);
+    const int groups = cout / 32;
+    const size_t per_split = (size_t)groups * C16_KT * C16_KF * 1024;
+    const size_t off = (((size_t)(co / 32) * C16_KT + kt) * C16_KF + kf) * 1024 +
+                       (size_t)(co % 32) * C16_CIN + ci;
+    float sum = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) sum += partial[sp * per_split + off];
+    dw[i] = sum * (inv_x_scale / scale_below_f16_max(max_bits[co]));
+}
+
+int wrw16_splits(int B, int T, int cout) {
+    // two workgroups per CU (80 KB of LDS each at 40 input frequencies), never more than tiles
+    const int tiles = ((B + 7) / 8) * T;
+    const int want = 512 / (C16_KT * (cout / 32));
+    return tiles < want ? tiles : want;
+}
+
+struct Wrw16Workspace {
+    size_t max_bits, x16, dz16, partial, total;
+};
+Wrw16Workspace wrw16_workspace(int B, int T, int freq_in, int cout) {
+    const size_t nblk = (size_t)(B + 7) / 8;
+    Wrw16Workspace w;
+    w.max_bits = 0;
+    w.x16 = 512;
+    w.dz16 = w.x16 + nblk * T * freq_in * 1024;
+    w.partial = w.dz16 + nblk * T * (freq_in / 2) * 2 * cout * 16;
+    w.total = w.partial + (size_t)wrw16_splits(B, T, cout) * cout * C16_CIN * C16_KT * C16_KF * 4;
+    return w;
+}
+
 bool covered16(int freq_in, int cout) {
     return (freq_in == 40 && cout == 32) || (freq_in == 20 && cout == 96);
 }
@@ -521,4 +811,61 @@ extern "C" int ctcasr_conv_s12_fwd16(const float *x, float x_scale, const void *
                                     y_time_major, s);
     return launch_fwd16<96, 20>(x, x_scale, pieces, max_bits, bias, y, B, T, relu_cutoff,
                                 y_time_major, s);
+}
+
+extern "C" size_t ctcasr_conv_s12_wrw16_workspace_bytes(int B, int T, int freq_in, int cout) {
+    if (B <= 0 || T <= 0 || !covered16(freq_in, cout)) return 0;
+    return wrw16_workspace(B, T, freq_in, cout).total;
+}
+
+// dw = kernel gradient like ctcasr_conv_s12_wrw, the products as fp16 x 3: x (bounded:
+// |x| x_scale < 65504, the layer's input behind the clipped ReLU) and the masked dz, scaled per
+// output channel by the power of two that its largest magnitude asks for, are first written as
+// fp16 pieces with 8 utterances innermost (workspace), then one launch multiplies.  dbias as in
+// ctcasr_conv_s12_wrw.  Deterministic up to dbias (atomics).
+extern "C" int ctcasr_conv_s12_wrw16(const float *dz, const float *x, float x_scale, float *dw,
+                                     int B, int T, int freq_in, int cout, int dz_time_major,
+                                     const float *act, float relu_cutoff, float *dbias,
+                                     void *workspace, size_t workspace_bytes,
+                                     ctcasr_stream_t stream) {
+    if (!dz || !x || !dw || B <= 0 || T <= 0 || (act && relu_cutoff <= 0.f) || !(x_scale > 0.f))
+        return CTCASR_ERR_BAD_ARGUMENT;
+    if (!covered16(freq_in, cout)) return CTCASR_ERR_UNSUPPORTED;
+    const Wrw16Workspace w = wrw16_workspace(B, T, freq_in, cout);
+    if (!workspace || workspace_bytes < w.total) return CTCASR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *base = reinterpret_cast<char *>(workspace);
+    unsigned *max_bits = reinterpret_cast<unsigned *>(base + w.max_bits);
+    u32x4 *x16 = reinterpret_cast<u32x4 *>(base + w.x16);
+    u32x4 *dz16 = reinterpret_cast<u32x4 *>(base + w.dz16);
+    float *partial = reinterpret_cast<float *>(base + w.partial);
+    const int fo = freq_in / 2, nblk = (B + 7) / 8;
+    if (hipMemsetAsync(max_bits, 0, 512, s) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    const long cells4 = (long)B * T * fo * cout / 4;
+    wrw16_colmax_kernel<<<240, 256, 0, s>>>(dz, act, relu_cutoff, cells4, cout, max_bits, dbias);
+    const long per_utt = (long)T * freq_in * C16_CIN, xcells = (long)nblk * per_utt;
+    wrw16_pack_x_kernel<<<(unsigned)((xcells + 255) / 256), 256, 0, s>>>(x, x_scale, x16, B,
+                                                                        per_utt, xcells);
+    const long dcells = (long)nblk * T * fo * cout;
+    wrw16_pack_dz_kernel<<<(unsigned)((dcells + 255) / 256), 256, 0, s>>>(
+        dz, act, relu_cutoff, max_bits, dz16, B, T, fo * cout, cout, dz_time_major, dcells);
+    const int nsplit = wrw16_splits(B, T, cout);
+    dim3 grid(nsplit, C16_KT, cout / 32);
+    if (freq_in == 40) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wrw16_kernel<40>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Wrw16Geometry<40>::LDS) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+        wrw16_kernel<40><<<grid, 256, Wrw16Geometry<40>::LDS, s>>>(x16, dz16, partial, nblk, T, cout);
+    } else {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wrw16_kernel<20>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)Wrw16Geometry<20>::LDS) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
+        wrw16_kernel<20><<<grid, 256, Wrw16Geometry<20>::LDS, s>>>(x16, dz16, partial, nblk, T, cout);
+    }
+    const int total = cout * C16_CIN * C16_KT * C16_KF;
+    wrw16_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, max_bits, 1.0f / x_scale, dw,
+                                                            nsplit, cout);
+    return ctcasr_launch_status();
 }

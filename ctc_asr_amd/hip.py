@@ -68,6 +68,9 @@ SIGNATURES = {
     'ctcasr_conv_s12_fwd16': (_c_int, [_c_p, _c_f, _c_p, _c_p, _c_p] + [_c_int] * 4 +
                               [_c_f, _c_int, _c_p]),
     'ctcasr_conv_s12_bwd_data16': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
+    'ctcasr_conv_s12_wrw16_workspace_bytes': (_c_sz, [_c_int] * 4),
+    'ctcasr_conv_s12_wrw16': (_c_int, [_c_p, _c_p, _c_f, _c_p] + [_c_int] * 5 +
+                              [_c_p, _c_f, _c_p, _c_p, _c_sz, _c_p]),
     'ctcasr_conv_s12_bwd_data': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
     'ctcasr_conv_s12_wrw_workspace_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_conv_s12_wrw': (_c_int, [_c_p] * 3 + [_c_int] * 5 + [_c_p, _c_f, _c_p] +
@@ -835,6 +838,36 @@ def conv_s12_wrw(dz, x, out=None, time_major=False, act=None, relu_cutoff=0.0, d
                                           float(relu_cutoff), _dev(dbias, name='dbias'),
                                           _dev(workspace, torch.uint8, 'workspace'),
                                           workspace.numel(), _stream()), 'conv_s12_wrw')
+    return out
+
+
+@_on_tensor_device
+def conv_s12_wrw16(dz, x, x_scale, out=None, time_major=False, act=None, relu_cutoff=0.0,
+                   dbias=None):
+    """`conv_s12_wrw` with its products on the fp16 matrix pipe: for x with a known bound,
+    bound * x_scale < 65504 (``x_scale`` a power of two); dz is scaled per output channel on the
+    device."""
+    if time_major:
+        frames, batch, freq_out, cout = dz.shape
+    else:
+        batch, frames, freq_out, cout = dz.shape
+    if tuple(x.shape) != (batch, frames, 2 * freq_out, 32) or \
+            not conv_s12_supported(2 * freq_out, cout):
+        raise CtcAsrError('conv_s12_wrw16: unsupported layer shape {} / {}'.format(
+            tuple(dz.shape), tuple(x.shape)))
+    out = torch.empty((cout, 32, 11, 21), dtype=torch.float32, device=x.device) if out is None \
+        else out
+    workspace = _workspace(load().ctcasr_conv_s12_wrw16_workspace_bytes(batch, frames,
+                                                                        2 * freq_out, cout),
+                           x.device)
+    with _Timed('conv_s12_wrw'):
+        _check(load().ctcasr_conv_s12_wrw16(_dev(dz, name='dz'), _dev(x, name='x'),
+                                            float(x_scale), _dev(out, name='dw'), batch, frames,
+                                            2 * freq_out, cout, 1 if time_major else 0,
+                                            _dev(act, name='act'), float(relu_cutoff),
+                                            _dev(dbias, name='dbias'),
+                                            _dev(workspace, torch.uint8, 'workspace'),
+                                            workspace.numel(), _stream()), 'conv_s12_wrw16')
     return out
 
 

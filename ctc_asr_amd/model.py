@@ -384,6 +384,7 @@ class CTCModel:
         self._conv_packed16 = {}        # ... and the fp16 pieces for the fp16-pipe forward kernel
         # forward pass of the 11 x 21 convolutions on the fp16 matrix pipe (bounded input)
         self.conv_f16 = os.environ.get('CTCASR_CONV_F16', '1') == '1'
+        self.conv_wrw_f16 = os.environ.get('CTCASR_CONV_WRW_F16', '1') == '1'
         # backward of the conv epilogue (mask + bias gradient) inside the gradient kernels
         self.conv_fused_bwd = os.environ.get('CTCASR_CONV_FUSED_BWD', '1') == '1'
         # Side-stream work that should run BESIDE a half-chip persistent recurrence launch waits
@@ -676,8 +677,6 @@ class CTCModel:
                 elif own_kind[i] == 's12':
                     # weights change every step: re-pack (2 x 946 KB), then one launch
                     kernel = p['conv{}/kernel'.format(i)]
-                    self._conv_packed[i] = hip.conv_s12_pack_weights(kernel,
-                                                                     self._conv_packed.get(i))
                     last_time_major = fused and i == layers - 1
                     # the layer's input is the clipped ReLU of the layer before (fused epilogue
                     # or `bias_act_fwd`): bounded by relu_cutoff -> the forward product on the
@@ -692,12 +691,14 @@ class CTCModel:
                                                p['conv{}/bias'.format(i)], relu_cutoff=cutoff,
                                                time_major=last_time_major)
                     else:
+                        self._conv_packed[i] = hip.conv_s12_pack_weights(
+                            kernel, self._conv_packed.get(i))
                         y = hip.conv_s12_fwd(x.permute(0, 2, 3, 1), self._conv_packed[i],
                                              kernel.shape[0], p['conv{}/bias'.format(i)],
                                              relu_cutoff=cutoff, time_major=last_time_major)
                     acts.setdefault('arithmetic_front', {})['conv{}/forward'.format(i)] = \
                         'fp16x3' if x_scale is not None else 'fp32'
-                    acts.setdefault('conv_f16', {})[i] = x_scale is not None
+                    acts.setdefault('conv_f16', {})[i] = x_scale
                     if not last_time_major:
                         y = y.permute(0, 3, 1, 2)
                     conv_in.append(x)      # the own kernel gradient reads the plain input
@@ -1467,9 +1468,16 @@ class CTCModel:
                     # (deterministic two-stage reduction), then the data gradient (weights were
                     # packed by the forward pass of this step)
                     dz_phys = dz if tm else dz.permute(0, 2, 3, 1)
-                    hip.conv_s12_wrw(dz_phys, conv_in.permute(0, 2, 3, 1), out=g[name + '/kernel'],
-                                     time_major=tm,
-                                     dbias=g[name + '/bias'] if fused_bwd else None, **mask)
+                    if acts['conv_f16'].get(i) and self.conv_wrw_f16:
+                        # (the layer's input is bounded: the scale the forward pass used)
+                        hip.conv_s12_wrw16(dz_phys, conv_in.permute(0, 2, 3, 1),
+                                           acts['conv_f16'][i], out=g[name + '/kernel'],
+                                           time_major=tm,
+                                           dbias=g[name + '/bias'] if fused_bwd else None, **mask)
+                    else:
+                        hip.conv_s12_wrw(dz_phys, conv_in.permute(0, 2, 3, 1),
+                                         out=g[name + '/kernel'], time_major=tm,
+                                         dbias=g[name + '/bias'] if fused_bwd else None, **mask)
                     if i > 0 and acts['conv_f16'].get(i):
                         # (the fp16 pieces of this step's weights, packed by the forward pass)
                         dact = hip.conv_s12_bwd_data16(dz_phys, self._conv_packed16[i],

@@ -306,6 +306,17 @@ int ctcasr_conv_s12_fwd16(const float *x, float x_scale, const void *packed16, c
 int ctcasr_conv_s12_bwd_data16(const float *dz, const void *packed16, float *dx, int B, int T,
                                int freq_in, int cout, int dz_time_major, const float *act,
                                float relu_cutoff, ctcasr_stream_t stream);
+/* ... and the kernel gradient (arguments of ctcasr_conv_s12_wrw plus x_scale as in
+ * ctcasr_conv_s12_fwd16): the summation runs over (b, t, fo), so x * x_scale and the masked dz -
+ * scaled per OUTPUT CHANNEL by the power of two that the channel's largest magnitude asks for,
+ * found on the device - are first written to `workspace` as fp16 pieces with 8 utterances
+ * innermost (the one axis no tap shifts), then one launch multiplies (asr/util/tf_contrib.py:64-146
+ * under tf.gradients). */
+size_t ctcasr_conv_s12_wrw16_workspace_bytes(int B, int T, int freq_in, int cout);
+int ctcasr_conv_s12_wrw16(const float *dz, const float *x, float x_scale, float *dw, int B, int T,
+                          int freq_in, int cout, int dz_time_major, const float *act,
+                          float relu_cutoff, float *dbias, void *workspace,
+                          size_t workspace_bytes, ctcasr_stream_t stream);
 int ctcasr_conv_s12_fwd(const float *x, const float *packed, const float *bias, float *y, int B,
                         int T, int freq_in, int cout, float relu_cutoff, int y_time_major,
                         ctcasr_stream_t stream);

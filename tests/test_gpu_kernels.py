@@ -726,6 +726,53 @@ def test_conv_s12_data_gradient_on_the_fp16_matrix_pipe(hip, shape, layer):
 
 
 @pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
+@pytest.mark.parametrize('shape', [(1, 1), (2, 7), (9, 37), (16, 12), (3, 500)])
+def test_conv_s12_kernel_gradient_on_the_fp16_matrix_pipe(hip, shape, layer):
+    """`ctcasr_conv_s12_wrw16`: x in [0, 20] behind the clipped ReLU (many exact zeros), dz over
+    six decades across output channels and three across frames (one power-of-two scale per output
+    channel, found on the device), batches that do not fill a block of 8 utterances; against fp64
+    autograd next to the fp32-MFMA kernel: per output channel the error relative to the channel's
+    largest gradient is not above 3 x the fp32 kernel's; bias gradient, mask and time-major
+    layout as in `ctcasr_conv_s12_wrw`."""
+    batch, frames = shape
+    freq, cout = layer
+    rng = np.random.default_rng(5 * frames + cout + batch)
+    x_np = np.clip(rng.normal(size=(batch, frames, freq, 32)) * 6.0, 0.0, 20.0).astype(np.float32)
+    dz = rng.normal(size=(batch, frames, freq // 2, cout))
+    dz *= 10.0 ** rng.uniform(-6, 0, size=(1, 1, 1, cout))
+    dz *= 10.0 ** rng.uniform(-3, 0, size=(batch, frames, 1, 1))
+    dz[rng.random(dz.shape[:3]) < 0.1] = 0.0
+    dz = dz.astype(np.float32)
+    x_scale = 2.0 ** 11                       # 20 x 2^11 < 65504
+    dw32 = hip.conv_s12_wrw(_t(dz), _t(x_np))
+    db16 = torch.zeros(cout, device='cuda')
+    dw16 = hip.conv_s12_wrw16(_t(dz), _t(x_np), x_scale, dbias=db16)
+    x = torch.zeros(batch, 32, frames + 10, freq + 19, dtype=torch.float64)
+    x[:, :, 5:5 + frames, 9:9 + freq] = torch.tensor(x_np, dtype=torch.float64).permute(0, 3, 1, 2)
+    w64 = torch.zeros(cout, 32, 11, 21, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w64, stride=(1, 2))
+    y.backward(torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
+    ref = w64.grad
+    top = ref.abs().amax(dim=(1, 2, 3)).clamp_min(1e-300)
+
+    def channel_err(got):
+        return float(((got.double().cpu() - ref).abs().amax(dim=(1, 2, 3)) / top).max())
+    e16, e32 = channel_err(dw16), channel_err(dw32)
+    assert e16 < 3 * e32 + 1e-6, (e16, e32)
+    assert not torch.equal(dw16, dw32)
+    want_db = dz.astype(np.float64).sum(axis=(0, 1, 2))
+    assert np.abs(db16.cpu().numpy() - want_db).max() < 1e-4 * max(1e-30, np.abs(want_db).max())
+    dz_tm = _t(dz).permute(1, 0, 2, 3).contiguous()
+    assert torch.equal(hip.conv_s12_wrw16(dz_tm, _t(x_np), x_scale, time_major=True), dw16)
+    act = _t(rng.uniform(-1.0, 2.5, size=dz.shape).astype(np.float32))
+    masked = _t(dz) * ((act > 0) & (act < 1.5)).float()
+    db_mask, db_plain = torch.zeros(cout, device='cuda'), torch.zeros(cout, device='cuda')
+    got = hip.conv_s12_wrw16(_t(dz), _t(x_np), x_scale, act=act, relu_cutoff=1.5, dbias=db_mask)
+    assert torch.equal(got, hip.conv_s12_wrw16(masked, _t(x_np), x_scale, dbias=db_plain))
+    assert float((db_mask - db_plain).abs().max()) <= 1e-5 * float(db_plain.abs().max() + 1e-30)
+
+
+@pytest.mark.parametrize('layer', [(40, 32), (20, 96)])
 @pytest.mark.parametrize('shape', [(1, 1), (2, 7), (3, 16), (2, 37), (3, 65), (1, 500)])
 def test_conv_s12_kernels_match_the_library_convolution(hip, shape, layer):
     """Implicit-GEMM forward, data gradient and kernel gradient of the 11x21 / stride (1,2) layers (32 -> 32 channels

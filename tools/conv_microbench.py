@@ -45,6 +45,12 @@ def main():
     dw = torch.empty(32, 32, 11, 21, device='cuda')
     ms = timed(lambda: hip.conv_s12_wrw(dz, x, dw))
     print('conv_s12_wrw: {:.3f} ms  {:.1f} TFLOP/s'.format(ms, flops / ms / 1e9))
+    xb = x.clamp(0.0, 20.0)
+    ms = timed(lambda: hip.conv_s12_wrw16(dz, xb, 2.0 ** 11, dw))
+    print('conv_s12_wrw16: {:.3f} ms  {:.1f} TFLOP/s fp32-equivalent'.format(
+        ms, flops / ms / 1e9))
+    if os.environ.get('CONV_MICROBENCH_OWN_ONLY') == '1':
+        return
     xp = torch.zeros(batch, 32, frames + 10, 59, device='cuda') \
         .contiguous(memory_format=torch.channels_last)
     w_cl = weight.contiguous(memory_format=torch.channels_last)

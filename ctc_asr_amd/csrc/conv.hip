@@ -463,21 +463,19 @@ conv_wrw_kernel(const float *__restrict__ dz, const float *__restrict__ x,
                 acc[kf][r];
 }
 
-// dw[co][ci][kt][kf] = sum over splits of partial[split][co / 32][kt][kf][co % 32][ci]
+// dw[co][ci][kt][kf] = sum over splits of partial[split][co / 32][kt][kf][co % 32][ci]: one
+// thread per element in the partials' order (coalesced reads; the results are scattered)
 __global__ void conv_wrw_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw,
                                        int nsplit, int cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = cout * CV_CIN * CV_KT * CV_KF;
-    if (i >= total) return;
-    const int kf = i % CV_KF, kt = (i / CV_KF) % CV_KT, ci = (i / (CV_KF * CV_KT)) % CV_CIN;
-    const int co = i / (CV_KF * CV_KT * CV_CIN);
-    const int groups = cout / 32;
-    const size_t per_split = (size_t)groups * CV_KT * CV_KF * WR_TAP;
-    const size_t off = (((size_t)(co / 32) * CV_KT + kt) * CV_KF + kf) * WR_TAP +
-                       (size_t)(co % 32) * CV_CIN + ci;
+    if (j >= total) return;
+    const int ci = j & 31, co32 = (j >> 5) & 31, tap = (j >> 10) % (CV_KT * CV_KF);
+    const int co = (j >> 10) / (CV_KT * CV_KF) * 32 + co32;
     float sum = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) sum += partial[sp * per_split + off];
-    dw[i] = sum;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) sum += partial[(size_t)sp * total + j];
+    dw[((size_t)co * CV_CIN + ci) * (CV_KT * CV_KF) + tap] = sum;
 }
 
 int wrw_splits(int B, int T, int freq_in, int cout) {

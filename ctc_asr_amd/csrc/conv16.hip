@@ -700,22 +700,22 @@ wrw16_kernel(const u32x4 *__restrict__ x16, const u32x4 *__restrict__ dz16,
     }
 }
 
-// dw[co][ci][kt][kf] = sum over splits of partial[split][co / 32][kt][kf][co % 32][ci], scales out
+// dw[co][ci][kt][kf] = sum over splits of partial[split][co / 32][kt][kf][co % 32][ci], scales out.
+// One thread per element in the PARTIALS' order (coalesced reads of every split; the 0.9 MB of
+// results are scattered instead - in dw's order the reads were 4 KB apart: 146 us at C3).
 __global__ void wrw16_reduce_kernel(const float *__restrict__ partial,
                                     const unsigned *__restrict__ max_bits, float inv_x_scale,
                                     float *__restrict__ dw, int nsplit, int cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = cout * C16_CIN * C16_KT * C16_KF;
-    if (i >= total) return;
-    const int kf = i % C16_KF, kt = (i / C16_KF) % C16_KT, ci = (i / (C16_KF * C16_KT)) % C16_CIN;
-    const int co = i / (C16_KF * C16_KT * C16_CIN);
-    const int groups = cout / 32;
-    const size_t per_split = (size_t)groups * C16_KT * C16_KF * 1024;
-    const size_t off = (((size_t)(co / 32) * C16_KT + kt) * C16_KF + kf) * 1024 +
-                       (size_t)(co % 32) * C16_CIN + ci;
+    if (j >= total) return;
+    const int ci = j & 31, co32 = (j >> 5) & 31, tap = (j >> 10) % (C16_KT * C16_KF);
+    const int co = (j >> 10) / (C16_KT * C16_KF) * 32 + co32;
     float sum = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) sum += partial[sp * per_split + off];
-    dw[i] = sum * (inv_x_scale / scale_below_f16_max(max_bits[co]));
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) sum += partial[(size_t)sp * total + j];
+    dw[((size_t)co * C16_CIN + ci) * (C16_KT * C16_KF) + tap] =
+        sum * (inv_x_scale / scale_below_f16_max(max_bits[co]));
 }
 
 int wrw16_splits(int B, int T, int cout) {
@@ -867,5 +867,430 @@ extern "C" int ctcasr_conv_s12_wrw16(const float *dz, const float *x, float x_sc
     const int total = cout * C16_CIN * C16_KT * C16_KF;
     wrw16_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, max_bits, 1.0f / x_scale, dw,
                                                             nsplit, cout);
+    return ctcasr_launch_status();
+}
+
+// =============================================================================================
+// First convolution of the stack (1 -> 32 channels, 11 x 41 taps, stride (2, 2), SAME padding;
+// conv.hip's conv0 kernels) on the fp16 pipe.  conv.hip feeds one float per lane and fp32 MFMA
+// (K = 451 taps only): 24 - 26 TFLOP/s.  Here:
+//
+// forward   y[b, t, fo, co] = bias[co] + sum_{kt,kf} x[b, 2t + kt - pt0, 2fo + kf - 19] w[co, kt, kf]
+//   M = (t, fo) rows, N = co, K = taps in groups of 8 consecutive kf of one kt (6 groups per kt,
+//   the last one holds kf = 40 only; 66 groups = 16.5 K steps of 4 groups, 83 % of the K axis is
+//   real).  A lane's A fragment is 8 consecutive positions p = 2fo + kf .. + 7 of one input line -
+//   2 bytes apart from its neighbour row's, so never 16-byte aligned as it stands: the patch sits
+//   in LDS twice, as it is and shifted by two positions, and an M tile takes 16 rows of EQUAL fo
+//   parity (fo = 2i + rho, copy rho): fragment offset 4i + 8 kb halves = 8-byte aligned, two
+//   ds_read_b64.  The features have no bound: the workgroup scales its own patch by the power of
+//   two its largest magnitude asks for (found while it is staged) - a row's sum only ever reads
+//   that patch.  Weights: fp16 pieces in fragment order, packed per step, scale found on the
+//   device, whole set (68 KB) in LDS.
+//
+// kernel gradient   dw[co, kt, kf] = sum_{b,t,fo} dz[b, t, fo, co] x[b, 2t + kt - pt0, 2fo + kf - 19]
+//   the scheme of wrw16 above: both operands as fp16 pieces with 8 utterances innermost, dz
+//   scaled per output channel, x by the tensor's largest magnitude; a tile = one output frame x 8
+//   utterances (40 K slots), its 11 input lines [2 pieces][128 positions] and the dz slice in
+//   LDS; a wave owns the taps kt = wave, wave + 4, wave + 8 x 3 kf tiles x 2 co tiles.
+// =============================================================================================
+namespace {
+
+constexpr int Z0_KT = 11, Z0_KF = 41, Z0_FI = 80, Z0_FO = 40, Z0_TT = 16;
+constexpr int Z0_PW = 128;                          // positions of a line: fi = position - 19
+constexpr int Z0_PT = 2 * Z0_TT + Z0_KT - 2;        // 41 input lines per 16 output frames
+constexpr int Z0_GROUPS = Z0_KT * 6;                // K groups (kt, 8 kf)
+constexpr int Z0_QS = (Z0_GROUPS + 3) / 4;          // 17 K steps
+constexpr int Z0_W_CELLS = Z0_QS * 2 * 2 * 64;      // packed weights: [q][nt][piece][lane]
+constexpr int Z0_DW = 32 * Z0_KT * Z0_KF;
+constexpr size_t Z0_FWD_LDS = (size_t)2 * 2 * Z0_PT * Z0_PW * 2 + (size_t)Z0_W_CELLS * 16 + 16;
+constexpr size_t Z0_WRW_LDS = ((size_t)Z0_KT * 2 * Z0_PW + (size_t)Z0_FO * 2 * 32) * 16;
+constexpr int Z0_WRW_GRID = 256;
+
+// packed[((q * 2 + nt) * 2 + piece) * 64 + g * 16 + n] = 8 halves: piece of
+// w[co = 16 nt + n][kt][kf = 8 kb .. + 7] * s_w for K group 4 q + g = 6 kt + kb (zero beyond)
+__global__ void __launch_bounds__(256)
+conv0_pack_w16_kernel(const float *__restrict__ w, const unsigned *__restrict__ max_bits,
+                      u32x4 *__restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (q, nt, lane)
+    if (i >= Z0_QS * 2 * 64) return;
+    const int lane = i & 63, nt = (i >> 6) & 1, q = i >> 7;
+    const int n = lane & 15, g = lane >> 4, gi = 4 * q + g, kt = gi / 6, kb = gi % 6;
+    const float s_w = scale_below_f16_max(*max_bits);
+    unsigned p[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kf = 8 * kb + e;
+        p[e] = (gi < Z0_GROUPS && kf < Z0_KF)
+                   ? f16_pieces(w[((16 * nt + n) * Z0_KT + kt) * Z0_KF + kf] * s_w) : 0u;
+    }
+    store_pieces8(packed + ((size_t)(q * 2 + nt) * 2) * 64 + lane, 64, p);
+}
+
+__global__ void __launch_bounds__(256)
+conv0_fwd16_kernel(const float *__restrict__ x, const u32x4 *__restrict__ packed,
+                   const unsigned *__restrict__ w_max_bits, const float *__restrict__ bias,
+                   float *__restrict__ y, int T, int t_out, int pt0, float cutoff) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zsm[];
+    _Float16 *copies = reinterpret_cast<_Float16 *>(zsm);      // [rho][piece][Z0_PT][Z0_PW]
+    u32x4 *wl = reinterpret_cast<u32x4 *>(zsm + (size_t)2 * 2 * Z0_PT * Z0_PW * 2);
+    unsigned *pmax = reinterpret_cast<unsigned *>(wl + Z0_W_CELLS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * Z0_TT, b = blockIdx.y;
+    const int g = lane >> 4, n = lane & 15;
+    constexpr int PLANE = Z0_PT * Z0_PW;                        // halves per (copy, piece)
+
+    if (tid == 0) *pmax = 0u;
+    __syncthreads();
+    constexpr int PER = (PLANE + 255) / 256;
+    float v[PER];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * 256, col = i % Z0_PW, pr = i / Z0_PW;
+        const int ts = 2 * t0 - pt0 + pr, fi = col - 19;
+        v[j] = (i < PLANE && ts >= 0 && ts < T && fi >= 0 && fi < Z0_FI)
+                   ? x[((size_t)b * T + ts) * Z0_FI + fi] : 0.f;
+        m = fmaxf(m, fabsf(v[j]));
+    }
+    m = wave_max(m);
+    if (lane == 0) atomicMax(pmax, __float_as_uint(m));
+    for (int i = tid; i < Z0_W_CELLS; i += 256) wl[i] = packed[i];
+    __syncthreads();
+    const float s_x = scale_below_f16_max(*pmax);
+    // the copy for odd fo holds the line two positions to the left: its tail stays zero
+    for (int i = tid; i < 2 * Z0_PT; i += 256) {
+        _Float16 *tail = copies + (size_t)(2 + i / Z0_PT) * PLANE + (i % Z0_PT) * Z0_PW + Z0_PW - 2;
+        tail[0] = (_Float16)0.f;
+        tail[1] = (_Float16)0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * 256, col = i % Z0_PW;
+        if (i < PLANE) {
+            const unsigned p = f16_pieces(v[j] * s_x);
+            const _Float16 h1 = __builtin_bit_cast(_Float16, (unsigned short)(p & 0xFFFFu));
+            const _Float16 h2 = __builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
+            copies[i] = h1;
+            copies[PLANE + i] = h2;
+            if (col >= 2) {
+                copies[2 * PLANE + i - 2] = h1;
+                copies[3 * PLANE + i - 2] = h2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // a wave owns 4 output frames x 40 frequencies: per parity 80 rows (tt, i), fo = 2 i + rho,
+    // = 5 M tiles; tile 5 rho + k, lane row 16 k + n
+    int base_a[10];
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti) {
+        const int rho = ti / 5, mrow = (ti % 5) * 16 + n, tt = mrow / 20, i = mrow % 20;
+        base_a[ti] = rho * 2 * PLANE + 2 * (4 * wave + tt) * Z0_PW + 4 * i;
+    }
+    f32x4 acc[10][2];
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti) {
+        acc[ti][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[ti][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int q = 0; q < Z0_QS; ++q) {
+        const int gi = 4 * q + g, kt = gi / 6, kb = gi - 6 * kt;
+        const int off = gi < Z0_GROUPS ? kt * Z0_PW + 8 * kb : 0;     // (weights are zero beyond)
+        Frag16 b1[2], b2[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            b1[nt].u = wl[((q * 2 + nt) * 2 + 0) * 64 + lane];
+            b2[nt].u = wl[((q * 2 + nt) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 10; ++ti) {
+            const u32x2 *p1 = reinterpret_cast<const u32x2 *>(copies + base_a[ti] + off);
+            const u32x2 *p2 = reinterpret_cast<const u32x2 *>(copies + base_a[ti] + off + PLANE);
+            const u32x2 lo1 = p1[0], hi1 = p1[1], lo2 = p2[0], hi2 = p2[1];
+            Frag16 a1, a2;
+            a1.u = (u32x4){lo1.x, lo1.y, hi1.x, hi1.y};
+            a2.u = (u32x4){lo2.x, lo2.y, hi2.x, hi2.y};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1.h, b1[nt].h, acc[ti][nt], 0, 0, 0);
+                acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1.h, b2[nt].h, acc[ti][nt], 0, 0, 0);
+                acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2.h, b1[nt].h, acc[ti][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    const float inv = 1.0f / (s_x * scale_below_f16_max(*w_max_bits));
+    const float bias0 = bias ? bias[n] : 0.f, bias1 = bias ? bias[16 + n] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rho = ti / 5, mrow = (ti % 5) * 16 + 4 * g + r, tt = mrow / 20;
+            const int fo = 2 * (mrow % 20) + rho, t = t0 + 4 * wave + tt;
+            if (t < t_out) {
+                float *out = y + ((size_t)(b * t_out + t) * Z0_FO + fo) * 32 + n;
+                float v0 = acc[ti][0][r] * inv + bias0, v1 = acc[ti][1][r] * inv + bias1;
+                if (cutoff > 0.f) {
+                    v0 = fminf(fmaxf(v0, 0.f), cutoff);
+                    v1 = fminf(fmaxf(v1, 0.f), cutoff);
+                }
+                out[0] = v0;
+                out[16] = v1;
+            }
+        }
+}
+
+// x f32[B, T, 80] -> x16 [(b / 8) T][piece][80] cells of 8 halves (utterances b % 8), scaled by
+// the power of two for the tensor's largest magnitude (*max_bits)
+__global__ void __launch_bounds__(256)
+conv0_pack_x_kernel(const float *__restrict__ x, const unsigned *__restrict__ max_bits,
+                    u32x4 *__restrict__ x16, int B, long per_utt /* T 80 */, long cells) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    const long within = i % per_utt;
+    const int b0 = (int)(i / per_utt) * 8;
+    const float s = scale_below_f16_max(*max_bits);
+    unsigned p[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        p[e] = b0 + e < B ? f16_pieces(x[(long)(b0 + e) * per_utt + within] * s) : 0u;
+    const long line = i / Z0_FI;                      // (bblk, t)
+    store_pieces8(x16 + line * 2 * Z0_FI + (i % Z0_FI), Z0_FI, p);
+}
+
+__global__ void __launch_bounds__(256)
+conv0_wrw16_kernel(const u32x4 *__restrict__ x16, const u32x4 *__restrict__ dz16,
+                   float *__restrict__ partial, int nblk, int T, int t_out, int pt0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zsm[];
+    u32x4 *xl = reinterpret_cast<u32x4 *>(zsm);                 // [kt][piece][Z0_PW] cells
+    u32x4 *dzs = xl + Z0_KT * 2 * Z0_PW;                        // [fo][piece][32 co] cells
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int tiles = nblk * t_out;
+    constexpr int X_CELLS = Z0_KT * 2 * Z0_FI;                  // 1760 real cells per tile
+    constexpr int X_PER = (X_CELLS + 255) / 256, DZ_PER = Z0_FO * 64 / 256;
+
+    for (int i = tid; i < Z0_KT * 2 * Z0_PW; i += 256) xl[i] = (u32x4){0u, 0u, 0u, 0u};
+
+    f32x4 acc[3][3][2];                      // [kt = wave + 4 k][kf tile][co tile]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            acc[k][nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[k][nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    u32x4 rx[X_PER], rdz[DZ_PER];
+    auto fetch = [&](int tile) {             // tile = t * nblk + bblk
+        const int t = tile / nblk, bblk = tile % nblk;
+#pragma unroll
+        for (int j = 0; j < X_PER; ++j) {
+            const int i = tid + j * 256, kt = i / (2 * Z0_FI), rest = i % (2 * Z0_FI);
+            const int ts = 2 * t + kt - pt0;
+            rx[j] = (u32x4){0u, 0u, 0u, 0u};
+            if (i < X_CELLS && ts >= 0 && ts < T)
+                rx[j] = x16[((size_t)bblk * T + ts) * 2 * Z0_FI + rest];
+        }
+        const u32x4 *dsrc = dz16 + ((size_t)bblk * t_out + t) * Z0_FO * 64;
+#pragma unroll
+        for (int j = 0; j < DZ_PER; ++j) rdz[j] = dsrc[tid + j * 256];
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < X_PER; ++j) {
+            const int i = tid + j * 256, kt = i / (2 * Z0_FI), rest = i % (2 * Z0_FI);
+            if (i < X_CELLS)
+                xl[(kt * 2 + rest / Z0_FI) * Z0_PW + 19 + rest % Z0_FI] = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DZ_PER; ++j) dzs[tid + j * 256] = rdz[j];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < tiles) fetch(tile);
+    while (tile < tiles) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < tiles) fetch(next);
+#pragma unroll 1
+        for (int q = 0; q < Z0_FO / 4; ++q) {
+            const int slot = 4 * q + g;
+            Frag16 a1[2], a2[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                a1[mt].u = dzs[(slot * 2 + 0) * 32 + mt * 16 + n];
+                a2[mt].u = dzs[(slot * 2 + 1) * 32 + mt * 16 + n];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int kt = wave + 4 * k;
+                if (kt < Z0_KT) {                              // wave-uniform
+                    const u32x4 *xb = xl + (kt * 2) * Z0_PW + 2 * slot + n;
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        Frag16 b1, b2;
+                        b1.u = xb[16 * nt];
+                        b2.u = xb[16 * nt + Z0_PW];
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            acc[k][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                a1[mt].h, b1.h, acc[k][nt][mt], 0, 0, 0);
+                            acc[k][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                a1[mt].h, b2.h, acc[k][nt][mt], 0, 0, 0);
+                            acc[k][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                a2[mt].h, b1.h, acc[k][nt][mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+    float *out = partial + (size_t)blockIdx.x * Z0_DW;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int kt = wave + 4 * k;
+        if (kt < Z0_KT) {
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const int kf = 16 * nt + n;
+                if (kf < Z0_KF) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            out[((16 * mt + 4 * g + r) * Z0_KT + kt) * Z0_KF + kf] =
+                                acc[k][nt][mt][r];
+                }
+            }
+        }
+    }
+}
+
+// dw[co][kt][kf] = sum of the workgroups' partials, scales out (ch_bits: per output channel,
+// x_bits: the features')
+__global__ void __launch_bounds__(256)
+conv0_wrw16_reduce_kernel(const float *__restrict__ partial, const unsigned *__restrict__ ch_bits,
+                          const unsigned *__restrict__ x_bits, float *__restrict__ dw, int parts) {
+    // 64 elements x 4 bands of parts per workgroup (one thread per element alone would walk all
+    // parts serially on 57 workgroups)
+    __shared__ float band_sum[4][64];
+    const int e = threadIdx.x & 63, band = threadIdx.x >> 6, i = blockIdx.x * 64 + e;
+    float sum = 0.f;
+    if (i < Z0_DW) {
+#pragma unroll 8
+        for (int part = band; part < parts; part += 4) sum += partial[(size_t)part * Z0_DW + i];
+    }
+    band_sum[band][e] = sum;
+    __syncthreads();
+    if (band == 0 && i < Z0_DW)
+        dw[i] = (band_sum[0][e] + band_sum[1][e] + (band_sum[2][e] + band_sum[3][e])) /
+                (scale_below_f16_max(ch_bits[i / (Z0_KT * Z0_KF)]) * scale_below_f16_max(*x_bits));
+}
+
+struct Z0Workspace {
+    size_t x16, dz16, partial, total;
+    int parts;
+};
+Z0Workspace z0_workspace(int B, int T) {
+    const size_t nblk = (size_t)(B + 7) / 8, t_out = (size_t)(T + 1) / 2;
+    Z0Workspace w;
+    w.x16 = 512;                                       // [0, 128): channel maxima; [256]: max |x|
+    w.dz16 = w.x16 + nblk * T * 2 * Z0_FI * 16;
+    w.partial = w.dz16 + nblk * t_out * Z0_FO * 64 * 16;
+    const size_t tiles = nblk * t_out;
+    w.parts = (int)(tiles < (size_t)Z0_WRW_GRID ? tiles : (size_t)Z0_WRW_GRID);
+    w.total = w.partial + (size_t)w.parts * Z0_DW * 4;
+    return w;
+}
+
+int conv0_pt0(int T) {
+    const int t_out = (T + 1) / 2;
+    const int total = (t_out - 1) * 2 + Z0_KT - T;          // TensorFlow SAME padding
+    return total > 0 ? total / 2 : 0;
+}
+
+}  // namespace
+
+extern "C" size_t ctcasr_conv0_pack16_bytes(void) { return 16 + (size_t)Z0_W_CELLS * 16; }
+
+// w [32, 1, 11, 41] -> `packed16`: the bit pattern of max |w| (16 bytes reserved), then the fp16
+// pieces of w * s_w in the forward kernel's fragment order.
+extern "C" int ctcasr_conv0_pack_weights16(const float *w, void *packed16, ctcasr_stream_t stream) {
+    if (!w || !packed16) return CTCASR_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *max_bits = reinterpret_cast<unsigned *>(packed16);
+    if (hipMemsetAsync(max_bits, 0, 16, s) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    conv16_absmax_kernel<<<8, 256, 0, s>>>(w, Z0_DW, max_bits);
+    conv0_pack_w16_kernel<<<(Z0_QS * 2 * 64 + 255) / 256, 256, 0, s>>>(
+        w, max_bits, reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(packed16) + 16));
+    return ctcasr_launch_status();
+}
+
+// y = conv(x) + bias like ctcasr_conv0_fwd, the products as fp16 x 3; no bound on x is assumed
+// (a power-of-two scale per workgroup patch, found while it is staged).
+extern "C" int ctcasr_conv0_fwd16(const float *x, const void *packed16, const float *bias, float *y,
+                                  int B, int T, float relu_cutoff, ctcasr_stream_t stream) {
+    if (!x || !packed16 || !y || B <= 0 || T <= 0) return CTCASR_ERR_BAD_ARGUMENT;
+    if (B > 65535) return CTCASR_ERR_UNSUPPORTED;
+    const int t_out = (T + 1) / 2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_fwd16_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)Z0_FWD_LDS) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    dim3 grid((t_out + Z0_TT - 1) / Z0_TT, B);
+    conv0_fwd16_kernel<<<grid, 256, Z0_FWD_LDS, (hipStream_t)stream>>>(
+        x, reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(packed16) + 16),
+        reinterpret_cast<const unsigned *>(packed16), bias, y, T, t_out, conv0_pt0(T), relu_cutoff);
+    return ctcasr_launch_status();
+}
+
+extern "C" size_t ctcasr_conv0_wrw16_workspace_bytes(int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    return z0_workspace(B, T).total;
+}
+
+// dw = kernel gradient like ctcasr_conv0_wrw, the products as fp16 x 3 (dz scaled per output
+// channel, x by the tensor's largest magnitude, both found on the device).
+extern "C" int ctcasr_conv0_wrw16(const float *dz, const float *x, float *dw, int B, int T,
+                                  const float *act, float relu_cutoff, float *dbias,
+                                  void *workspace, size_t workspace_bytes,
+                                  ctcasr_stream_t stream) {
+    if (!dz || !x || !dw || B <= 0 || T <= 0 || (act && relu_cutoff <= 0.f))
+        return CTCASR_ERR_BAD_ARGUMENT;
+    const Z0Workspace w = z0_workspace(B, T);
+    if (!workspace || workspace_bytes < w.total) return CTCASR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *base = reinterpret_cast<char *>(workspace);
+    unsigned *ch_bits = reinterpret_cast<unsigned *>(base);
+    unsigned *x_bits = reinterpret_cast<unsigned *>(base + 256);
+    u32x4 *x16 = reinterpret_cast<u32x4 *>(base + w.x16);
+    u32x4 *dz16 = reinterpret_cast<u32x4 *>(base + w.dz16);
+    float *partial = reinterpret_cast<float *>(base + w.partial);
+    const int t_out = (T + 1) / 2, nblk = (B + 7) / 8;
+    if (hipMemsetAsync(base, 0, 512, s) != hipSuccess) return CTCASR_ERR_LAUNCH;
+    const long cells4 = (long)B * t_out * Z0_FO * 32 / 4;
+    wrw16_colmax_kernel<<<240, 256, 0, s>>>(dz, act, relu_cutoff, cells4, 32, ch_bits, dbias);
+    const long n_x = (long)B * T * Z0_FI;
+    conv16_absmax_kernel<<<512, 256, 0, s>>>(x, (int)n_x, x_bits);
+    const long per_utt = (long)T * Z0_FI, xcells = (long)nblk * per_utt;
+    conv0_pack_x_kernel<<<(unsigned)((xcells + 255) / 256), 256, 0, s>>>(x, x_bits, x16, B, per_utt,
+                                                                        xcells);
+    const long dcells = (long)nblk * t_out * Z0_FO * 32;
+    wrw16_pack_dz_kernel<<<(unsigned)((dcells + 255) / 256), 256, 0, s>>>(
+        dz, act, relu_cutoff, ch_bits, dz16, B, t_out, Z0_FO * 32, 32, 0, dcells);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_wrw16_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)Z0_WRW_LDS) != hipSuccess)
+        return CTCASR_ERR_LAUNCH;
+    conv0_wrw16_kernel<<<w.parts, 256, Z0_WRW_LDS, s>>>(x16, dz16, partial, nblk, T, t_out,
+                                                        conv0_pt0(T));
+    conv0_wrw16_reduce_kernel<<<(Z0_DW + 63) / 64, 256, 0, s>>>(partial, ch_bits, x_bits, dw,
+                                                                  w.parts);
     return ctcasr_launch_status();
 }

@@ -155,11 +155,19 @@ class GradientReducer:
                 torch.cuda.current_stream(device).wait_event(done)
         return _Work
 
-    def finish(self):
+    def finish(self, guard=None):
+        """Flush and wait.  ``guard`` (the int32 words of `CTCModel.step_guard`): with more than
+        one rank its MAXIMUM over ranks comes back in place - a step that one replica must not
+        apply carries that replica's gradients in every rank's sum, so every replica drops it
+        (the Adam kernel's skip flag) and the parameters stay replicated until the error the
+        bad rank raises stops the job."""
         if not self.active:
             return
         self.released = self.hold_until is None
         self._flush()
+        if guard is not None and self.world > 1 and self.stand_in is None:
+            self.works.append(dist.all_reduce(guard, op=dist.ReduceOp.MAX, group=self.group,
+                                              async_op=True))
         for work in self.works:
             work.wait()
         self.works = []
@@ -284,7 +292,8 @@ class Trainer:
         # Invalid gradients never reach the parameters: the guard word is computed on the device
         # from this step's CTC status, its loss and the recurrence time-out words, and the Adam
         # kernel drops the update when it is set - whenever the host gets to look.
-        # (N > 1: every rank guards its own shard; the error it raises stops the job.)
+        # (N > 1: the guard words are max-reduced with the gradients, every replica drops the
+        # step that one of them must not apply; the rank that hit it raises.)
         guard = self.model.step_guard()
         if check:
             status = self.model.last_status
@@ -294,7 +303,7 @@ class Trainer:
             copied = torch.cuda.Event()
             copied.record(torch.cuda.current_stream(self.model.device))
             self._pending_status.append((copied, host, self.model.step_count + 1))
-        self.reducer.finish()
+        self.reducer.finish(guard)      # (N > 1: the guard words become their maxima over ranks)
         self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
                                    grad_scale=1.0 / self.world, skip=guard)
         done = torch.cuda.Event()

@@ -68,6 +68,12 @@ SIGNATURES = {
     'ctcasr_conv_s12_fwd16': (_c_int, [_c_p, _c_f, _c_p, _c_p, _c_p] + [_c_int] * 4 +
                               [_c_f, _c_int, _c_p]),
     'ctcasr_conv_s12_bwd_data16': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_f, _c_p]),
+    'ctcasr_conv0_pack16_bytes': (_c_sz, []),
+    'ctcasr_conv0_pack_weights16': (_c_int, [_c_p, _c_p, _c_p]),
+    'ctcasr_conv0_fwd16': (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_f, _c_p]),
+    'ctcasr_conv0_wrw16_workspace_bytes': (_c_sz, [_c_int, _c_int]),
+    'ctcasr_conv0_wrw16': (_c_int, [_c_p] * 3 + [_c_int, _c_int, _c_p, _c_f, _c_p, _c_p, _c_sz,
+                                                 _c_p]),
     'ctcasr_conv_s12_wrw16_workspace_bytes': (_c_sz, [_c_int] * 4),
     'ctcasr_conv_s12_wrw16': (_c_int, [_c_p, _c_p, _c_f, _c_p] + [_c_int] * 5 +
                               [_c_p, _c_f, _c_p, _c_p, _c_sz, _c_p]),
@@ -885,6 +891,54 @@ def conv0_fwd(x, weight, bias=None, out=None, relu_cutoff=0.0):
         _check(load().ctcasr_conv0_fwd(_dev(x, name='x'), _dev(weight, name='weight'),
                                        _dev(bias, name='bias'), _dev(out, name='y'), batch,
                                        frames, float(relu_cutoff), _stream()), 'conv0_fwd')
+    return out
+
+
+@_on_tensor_device
+def conv0_pack_weights16(weight, out=None):
+    """weight f32[32, 1, 11, 41] -> uint8 buffer for `conv0_fwd16` (fp16 pieces in fragment order,
+    scale found on the device); re-pack whenever the weights change."""
+    if tuple(weight.shape) != (32, 1, 11, 41):
+        raise CtcAsrError('conv0_pack_weights16 covers w [32,1,11,41] only.')
+    nbytes = load().ctcasr_conv0_pack16_bytes()
+    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device) if out is None else out
+    _check(load().ctcasr_conv0_pack_weights16(_dev(weight, name='weight'),
+                                              _dev(out, torch.uint8, 'packed16'), _stream()),
+           'conv0_pack_weights16')
+    return out
+
+
+@_on_tensor_device
+def conv0_fwd16(x, packed16, bias=None, out=None, relu_cutoff=0.0):
+    """`conv0_fwd` with its products on the fp16 matrix pipe (no bound on x is assumed)."""
+    batch, frames = x.shape[0], x.shape[1]
+    if x.shape[2] != 80:
+        raise CtcAsrError('conv0_fwd16 covers x [B,T,80] only.')
+    out = torch.empty((batch, (frames + 1) // 2, 40, 32), dtype=torch.float32,
+                      device=x.device) if out is None else out
+    with _Timed('conv0_fwd'):
+        _check(load().ctcasr_conv0_fwd16(_dev(x, name='x'), _dev(packed16, torch.uint8, 'packed16'),
+                                         _dev(bias, name='bias'), _dev(out, name='y'), batch,
+                                         frames, float(relu_cutoff), _stream()), 'conv0_fwd16')
+    return out
+
+
+@_on_tensor_device
+def conv0_wrw16(dz, x, out=None, act=None, relu_cutoff=0.0, dbias=None):
+    """`conv0_wrw` with its products on the fp16 matrix pipe."""
+    batch, frames = x.shape[0], x.shape[1]
+    if x.shape[2] != 80 or tuple(dz.shape) != (batch, (frames + 1) // 2, 40, 32):
+        raise CtcAsrError('conv0_wrw16 covers x [B,T,80], dz [B,ceil(T/2),40,32] only.')
+    out = torch.empty((32, 1, 11, 41), dtype=torch.float32, device=x.device) if out is None \
+        else out
+    workspace = _workspace(load().ctcasr_conv0_wrw16_workspace_bytes(batch, frames), x.device)
+    with _Timed('conv0_wrw'):
+        _check(load().ctcasr_conv0_wrw16(_dev(dz, name='dz'), _dev(x, name='x'),
+                                         _dev(out, name='dw'), batch, frames,
+                                         _dev(act, name='act'), float(relu_cutoff),
+                                         _dev(dbias, name='dbias'),
+                                         _dev(workspace, torch.uint8, 'workspace'),
+                                         workspace.numel(), _stream()), 'conv0_wrw16')
     return out
 
 

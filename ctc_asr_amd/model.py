@@ -670,8 +670,16 @@ class CTCModel:
                 cutoff = cfg.relu_cutoff if fused else 0.0
                 if own_kind[i] == 'conv0':
                     # first layer: straight from the [B, T, 80] features, no padded copy
-                    y = hip.conv0_fwd(sequences, p['conv0/kernel'], p['conv0/bias'],
-                                      relu_cutoff=cutoff).permute(0, 3, 1, 2)
+                    if self.conv_f16:
+                        self._conv_packed16[0] = hip.conv0_pack_weights16(
+                            p['conv0/kernel'], self._conv_packed16.get(0))
+                        y = hip.conv0_fwd16(sequences, self._conv_packed16[0], p['conv0/bias'],
+                                            relu_cutoff=cutoff).permute(0, 3, 1, 2)
+                    else:
+                        y = hip.conv0_fwd(sequences, p['conv0/kernel'], p['conv0/bias'],
+                                          relu_cutoff=cutoff).permute(0, 3, 1, 2)
+                    acts.setdefault('arithmetic_front', {})['conv0/forward'] = \
+                        'fp16x3' if self.conv_f16 else 'fp32'
                     conv_in.append(None)
                     acts['features'] = sequences
                 elif own_kind[i] == 's12':
@@ -1457,9 +1465,10 @@ class CTCModel:
                 pt0, pt1, pf0, pf1 = acts['pads'][i]
                 if own == 'conv0':
                     # first layer: kernel gradient straight from the features, no padded copy
-                    hip.conv0_wrw(dz.permute(0, 2, 3, 1), acts['features'],
-                                  out=g[name + '/kernel'],
-                                  dbias=g[name + '/bias'] if fused_bwd else None, **mask)
+                    wrw0 = hip.conv0_wrw16 if (self.conv_f16 and self.conv_wrw_f16) \
+                        else hip.conv0_wrw
+                    wrw0(dz.permute(0, 2, 3, 1), acts['features'], out=g[name + '/kernel'],
+                         dbias=g[name + '/bias'] if fused_bwd else None, **mask)
                     done(name)
                     continue
                 conv_in = acts['conv_in'][i]

@@ -349,6 +349,21 @@ int ctcasr_conv0_wrw(const float *dz, const float *x, float *dw, int B, int T, c
                      float relu_cutoff, float *dbias, void *workspace, size_t workspace_bytes,
                      ctcasr_stream_t stream);
 
+/* ... the same two on the fp16 matrix pipe (round 4; csrc/conv16.hip).  fwd16: the weights as
+ * fp16 pieces in fragment order (`packed16`: ctcasr_conv0_pack16_bytes() bytes, re-packed every
+ * step, scale found on the device); the features have no bound, every workgroup scales its own
+ * input patch by the power of two its largest magnitude asks for.  wrw16: dz scaled per output
+ * channel, x by the tensor's largest magnitude, both written to `workspace` as fp16 pieces with
+ * 8 utterances innermost (see ctcasr_conv_s12_wrw16). */
+size_t ctcasr_conv0_pack16_bytes(void);
+int ctcasr_conv0_pack_weights16(const float *w, void *packed16, ctcasr_stream_t stream);
+int ctcasr_conv0_fwd16(const float *x, const void *packed16, const float *bias, float *y, int B,
+                       int T, float relu_cutoff, ctcasr_stream_t stream);
+size_t ctcasr_conv0_wrw16_workspace_bytes(int B, int T);
+int ctcasr_conv0_wrw16(const float *dz, const float *x, float *dw, int B, int T, const float *act,
+                       float relu_cutoff, float *dbias, void *workspace, size_t workspace_bytes,
+                       ctcasr_stream_t stream);
+
 /* out[n][c][r] = in[n][r][c] for n < batch (weight re-layouts, e.g. w_hh -> w_hh_t). */
 int ctcasr_transpose_batched(const float *in, float *out, int batch, int rows, int cols,
                              ctcasr_stream_t stream);

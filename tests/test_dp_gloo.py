@@ -57,7 +57,11 @@ def _reducer_worker(rank, world, port, out):
     for name, start, stop in reversed(slices):
         reducer.hook(name, start, stop)
     assert len(reducer.works) == 4 and reducer.launched == 4
-    reducer.finish()
+    # the guard words of a step travel with its gradients: their maximum over ranks comes back,
+    # so every replica drops a step that ONE of them must not apply
+    guard = torch.tensor([1 if rank == 1 else 0, 5 * rank], dtype=torch.int32)
+    reducer.finish(guard)
+    assert guard.tolist() == [1, 5 * (world - 1)]
     assert torch.all(arena == 3.0)
     # force=True runs the collectives whatever the world size; inactive = no-op
     idle = GradientReducer(arena, 1, bucket_bytes=4)

@@ -889,6 +889,67 @@ def test_conv0_fwd_matches_the_library_convolution(hip, shape):
     assert float((dbias - dbias_ref).abs().max()) < 1e-4 * max(1.0, float(dbias_ref.abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(1, 1), (2, 6), (3, 33), (9, 64), (16, 47), (2, 999)])
+def test_conv0_on_the_fp16_matrix_pipe(hip, shape):
+    """`ctcasr_conv0_fwd16` / `ctcasr_conv0_wrw16` against fp64 next to the fp32-MFMA kernels:
+    features whose magnitude varies over four decades between utterances and frames (the forward
+    kernel scales every workgroup's patch on its own), dz over six decades across channels.
+    Forward: per (utterance, frame) the error relative to the frame's largest output is not above
+    3 x the fp32 kernel's; kernel gradient: per output channel likewise."""
+    from ctc_asr_amd.model import same_padding
+    batch, frames = shape
+    rng = np.random.default_rng(11 * frames + batch)
+    x_np = rng.normal(size=(batch, frames, 80))
+    x_np *= 10.0 ** rng.uniform(-4, 0.5, size=(batch, 1, 1))
+    x_np *= 10.0 ** rng.uniform(-1, 0, size=(batch, frames, 1))
+    x_np = x_np.astype(np.float32)
+    weight = (rng.normal(size=(32, 1, 11, 41)) * 0.1).astype(np.float32)
+    bias = (rng.normal(size=32) * 1e-3).astype(np.float32)
+    packed16 = hip.conv0_pack_weights16(_t(weight))
+    y32 = hip.conv0_fwd(_t(x_np), _t(weight), _t(bias))
+    y16 = hip.conv0_fwd16(_t(x_np), packed16, _t(bias))
+    y_act = hip.conv0_fwd16(_t(x_np), packed16, _t(bias), relu_cutoff=0.7)
+    assert float((y_act - y16.clamp(0.0, 0.7)).abs().max()) < 1e-6
+    t_out, pt0, pt1 = same_padding(frames, 11, 2)
+    x = torch.nn.functional.pad(torch.tensor(x_np, dtype=torch.float64).unsqueeze(1),
+                                (19, 20, pt0, pt1))
+    ref = torch.nn.functional.conv2d(x, torch.tensor(weight, dtype=torch.float64),
+                                     torch.tensor(bias, dtype=torch.float64),
+                                     stride=(2, 2)).permute(0, 2, 3, 1)
+    assert tuple(y16.shape) == tuple(ref.shape) == (batch, t_out, 40, 32)
+    top = ref.abs().amax(dim=(2, 3)).clamp_min(1e-30)
+
+    def frame_err(got):
+        return float(((got.double().cpu() - ref).abs().amax(dim=(2, 3)) / top).max())
+    e16, e32 = frame_err(y16), frame_err(y32)
+    assert e16 < 3 * e32 + 1e-6, (e16, e32)
+    assert not torch.equal(y16, y32)
+
+    dz = rng.normal(size=(batch, t_out, 40, 32))
+    dz *= 10.0 ** rng.uniform(-6, 0, size=(1, 1, 1, 32))
+    dz[rng.random(dz.shape[:3]) < 0.1] = 0.0
+    dz = dz.astype(np.float32)
+    dw32 = hip.conv0_wrw(_t(dz), _t(x_np))
+    db16 = torch.zeros(32, device=DEV)
+    dw16 = hip.conv0_wrw16(_t(dz), _t(x_np), dbias=db16)
+    w64 = torch.tensor(weight, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x, w64, stride=(2, 2)).backward(
+        torch.tensor(dz, dtype=torch.float64).permute(0, 3, 1, 2))
+    ref_dw = w64.grad
+    top_c = ref_dw.abs().amax(dim=(1, 2, 3)).clamp_min(1e-300)
+
+    def channel_err(got):
+        return float(((got.double().cpu() - ref_dw).abs().amax(dim=(1, 2, 3)) / top_c).max())
+    c16, c32 = channel_err(dw16), channel_err(dw32)
+    assert c16 < 3 * c32 + 1e-6, (c16, c32)
+    want_db = dz.astype(np.float64).sum(axis=(0, 1, 2))
+    assert np.abs(db16.cpu().numpy() - want_db).max() < 1e-4 * max(1e-30, np.abs(want_db).max())
+    act = _t(rng.uniform(-0.5, 1.0, size=dz.shape).astype(np.float32))
+    masked = _t(dz) * ((act > 0) & (act < 0.7)).float()
+    assert torch.equal(hip.conv0_wrw16(_t(dz), _t(x_np), act=act, relu_cutoff=0.7),
+                       hip.conv0_wrw16(masked, _t(x_np)))
+
+
 def test_beam_search_random_sweep_against_the_oracle(hip):
     """The register-resident beam set of round 2 against the C oracle over a sweep of shapes:
     few and many classes, widths around the 64-lane and 256 / 1024 register-tile boundaries,

@@ -83,9 +83,8 @@ def dtype_label(model):
              if on]
     rec = '; {} recurrence (h x W_hh / dgates x W_hh) as fp16x3 split, fp32 accumulate'.format(
         ' and '.join(which)) if which else ''
-    if getattr(model, 'conv_f16', False) and len(model.cfg.conv_filters) > 1 and \
-            model.cfg.used_model == 'ds2':
-        rec += '; the 32-input-channel convolutions (forward, data gradient) as fp16x3 split'
+    if getattr(model, 'conv_f16', False) and model.cfg.used_model == 'ds2':
+        rec += '; the convolutions (forward, data gradient, kernel gradient) as fp16x3 split'
     if not model.split_gemm:
         return 'f32' if not rec else 'f32 tensors / accumulate / GEMMs' + rec
     gemms = 'bf16x6 split (24 significand bits)'
@@ -97,9 +96,9 @@ def dtype_label(model):
     return 'f32 tensors / accumulate / own kernels; projection GEMMs: ' + gemms + rec
 
 
-def forward_flops_per_utt(cfg, frames):
-    """SURVEY.md 8d formula: conv + input/recurrent projections + dense4 + logits."""
-    from ctc_asr_amd.model import CONV_KERNEL_SIZES, GATES
+def conv_flops_per_utt(cfg, frames):
+    """Forward FLOPs of the convolution front end (SURVEY.md 8d formula's first term)."""
+    from ctc_asr_amd.model import CONV_KERNEL_SIZES
     t_out = cfg.output_time(frames)
     flops, c_in, freq = 0.0, 1, cfg.num_features
     if cfg.used_model == 'ds2':
@@ -108,6 +107,14 @@ def forward_flops_per_utt(cfg, frames):
             k_t, k_f = CONV_KERNEL_SIZES[i]
             flops += 2.0 * t_out * freq * c_out * k_t * k_f * c_in
             c_in = c_out
+    return flops
+
+
+def forward_flops_per_utt(cfg, frames):
+    """SURVEY.md 8d formula: conv + input/recurrent projections + dense4 + logits."""
+    from ctc_asr_amd.model import GATES
+    t_out = cfg.output_time(frames)
+    flops = conv_flops_per_utt(cfg, frames)
     gates, hidden = GATES[cfg.cell], cfg.num_units_rnn
     in_size = cfg.rnn_input_size()
     for _ in range(cfg.num_layers_rnn):
@@ -119,7 +126,7 @@ def forward_flops_per_utt(cfg, frames):
 
 
 def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f16=True,
-               bwd_f16=True, rec_f16=(False, False)):
+               bwd_f16=True, rec_f16=(False, False), conv_f16=False):
     """Time one step would take with every FLOP at the peak of the pipe it runs on: the fp32
     matrix pipe (157.3 TF) for the own kernels; for the split GEMMs the 16-bit matrix pipe
     (2500 TF) divided by the products per fp32 product - three fp16 products where the layer's
@@ -142,6 +149,11 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
     # fp32 pipe for three fp16 products where the fp16-pipe persistent kernels run them
     rec16 = rec * sum(1 for on in rec_f16 if on) if cfg.cell == 'lstm' else 0.0
     fp32 -= rec16
+    # ... and the convolutions (forward, data gradient, kernel gradient: csrc/conv16.hip)
+    conv16 = 3.0 * conv_flops_per_utt(cfg, frames) if (conv_f16 and cfg.used_model == 'ds2') \
+        else 0.0
+    fp32 -= conv16
+    rec16 += conv16
     roof_ms = utterances / world * (
         (three + rec16) * 3.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
         (split - three) * 6.0 / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
@@ -149,12 +161,13 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
     return {'ms_per_step_at_peak': round(roof_ms, 3), 'frac': round(roof_ms / ms_per_step, 4),
             'fp32_equiv_tflop_split_gemms': round(utterances / world * split / 1e12, 3),
             'of_which_fp16x3': round(utterances / world * three / 1e12, 3),
-            'tflop_recurrences_fp16x3': round(utterances / world * rec16 / 1e12, 3),
+            'tflop_recurrences_fp16x3': round(utterances / world * (rec16 - conv16) / 1e12, 3),
+            'tflop_convolutions_fp16x3': round(utterances / world * conv16 / 1e12, 3),
             'tflop_fp32_pipe': round(utterances / world * fp32 / 1e12, 3),
             'note': 'per GPU; split GEMMs priced at 2500 TF / 3 (fp16 pieces: bounded layer inputs, '
                     'their gradient GEMMs with per-column / per-row scales of dxw; the recurrences\' '
-                    'own products where the fp16-pipe kernels run) and 2500 TF / 6 (bf16 pieces), '
-                    'the other own kernels at 157.3 TF'}
+                    'own products and the convolutions where the fp16-pipe kernels run) and '
+                    '2500 TF / 6 (bf16 pieces), the other own kernels at 157.3 TF'}
 
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
@@ -541,7 +554,8 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
             'roof': mixed_roof(cfg, frames, batch * world, ms_per_step, model.split_gemm, world,
                                model.fwd_f16, model.bwd_f16,
                                (model.arithmetic().get('rnn0/recurrence_fwd') == 'fp16x3',
-                                model.arithmetic().get('rnn0/recurrence_bwd') == 'fp16x3')),
+                                model.arithmetic().get('rnn0/recurrence_bwd') == 'fp16x3'),
+                               conv_f16=model.arithmetic().get('conv0/forward') == 'fp16x3'),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),

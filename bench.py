@@ -876,8 +876,11 @@ PROBE_BATCH, PROBE_FRAMES, PROBE_LABEL_LEN = 4, 199, 30        # T' = 100
 # which GEMM arithmetic a probe variant runs: attributes of CTCModel
 PROBE_VARIANTS = (
     ('default', {}),
-    ('bf16x6', {'fwd_f16': False, 'bwd_f16': False, 'rnn_fwd_f16': False, 'rnn_bwd_f16': False}),
-    ('fp32_library_gemms', {'split_gemm': False, 'rnn_fwd_f16': False, 'rnn_bwd_f16': False}),
+    # (both: every own kernel on the fp32 pipe - recurrences and convolutions)
+    ('bf16x6', {'fwd_f16': False, 'bwd_f16': False, 'rnn_fwd_f16': False, 'rnn_bwd_f16': False,
+                'conv_f16': False}),
+    ('fp32_library_gemms', {'split_gemm': False, 'rnn_fwd_f16': False, 'rnn_bwd_f16': False,
+                            'conv_f16': False}),
 )
 
 

@@ -373,8 +373,9 @@ def test_assembled_c3_model_at_the_benchmark_shape():
 def test_fifty_training_steps_track_the_all_fp32_path(monkeypatch):
     """Drift: 50 Adam steps of the C3 model at the benchmark's shape on the same batch, once
     through the default arithmetic (fp16 / bf16 pieces on the 16-bit matrix pipe for the
-    projection GEMMs and both recurrences) and once with every product on the fp32 pipe
-    (CTCASR_SPLIT_GEMM=0, CTCASR_RNN_FWD_F16=0, CTCASR_RNN_BWD_F16=0): the loss trajectories
+    projection GEMMs, both recurrences and every convolution kernel) and once with every product
+    on the fp32 pipe (CTCASR_SPLIT_GEMM=0, CTCASR_RNN_FWD_F16=0, CTCASR_RNN_BWD_F16=0,
+    CTCASR_CONV_F16=0): the loss trajectories
     agree to 1e-3 relative at every step (they start bit-close and part only as fast as fp32
     round-off of either path is amplified by training itself)."""
     cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
@@ -386,20 +387,22 @@ def test_fifty_training_steps_track_the_all_fp32_path(monkeypatch):
     labels = CTCModel.pack_labels([list(rng.integers(1, 28, size=150)) for _ in range(32)], 'cuda')
 
     def trajectory(fp32_everything):
-        for name in ('CTCASR_SPLIT_GEMM', 'CTCASR_RNN_FWD_F16', 'CTCASR_RNN_BWD_F16'):
+        for name in ('CTCASR_SPLIT_GEMM', 'CTCASR_RNN_FWD_F16', 'CTCASR_RNN_BWD_F16',
+                     'CTCASR_CONV_F16'):
             if fp32_everything:
                 monkeypatch.setenv(name, '0')
             else:
                 monkeypatch.delenv(name, raising=False)
         model = CTCModel(cfg, 'cuda', seed=3)
         assert model.split_gemm != fp32_everything and model.rnn_bwd_f16 != fp32_everything
+        assert model.conv_f16 != fp32_everything
         losses = []
         for _ in range(50):
             losses.append(model.forward_backward(feats, flen, labels, check=False))
             model.apply_gradients(learning_rate=1e-4)
         model.check_rnn_error()
-        form = model.arithmetic()['rnn2/recurrence_bwd']
-        assert form == ('fp32' if fp32_everything else 'fp16x3')
+        for key in ('rnn2/recurrence_bwd', 'conv0/forward', 'conv1/forward'):
+            assert model.arithmetic()[key] == ('fp32' if fp32_everything else 'fp16x3'), key
         out = torch.stack(losses).double().cpu().numpy()
         del model
         torch.cuda.empty_cache()

@@ -131,7 +131,7 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
     matrix pipe (157.3 TF) for the own kernels; for the split GEMMs the 16-bit matrix pipe
     (2500 TF) divided by the products per fp32 product - three fp16 products where the layer's
     input is bounded (forward projections; with `bwd_f16` their gradient GEMMs too, dxw scaled per
-    column / row), six bf16 products for the rest (dense4's gradients; everything behind a
+    column / row), six bf16 products for the rest (dense4's kernel gradient; everything behind a
     ReLU-RNN cell)."""
     split, fp32 = training_flops_by_pipe(cfg, frames)
     if not split_gemm:
@@ -144,7 +144,7 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
     if split_gemm and fwd_f16 and cfg.cell != 'rnn_relu':
         three = (split - rec) / 3.0                       # the forward products
         if bwd_f16:
-            three = split - 2.0 * dense4                  # + every gradient GEMM but dense4's
+            three = split - dense4            # + every gradient GEMM but dense4's kernel gradient
     # the recurrences' own products (h W_hh^T forward, dgates W_hh backward: `rec` each) leave the
     # fp32 pipe for three fp16 products where the fp16-pipe persistent kernels run them
     rec16 = rec * sum(1 for on in rec_f16 if on) if cfg.cell == 'lstm' else 0.0

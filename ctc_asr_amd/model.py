@@ -598,7 +598,15 @@ class CTCModel:
                 else:
                     pieces.make_fwd(buf('dense4/bf16', lambda: torch.empty(
                         (6,) + tuple(k4.shape), dtype=torch.bfloat16, device=self.device)))
-                if training:        # (dense4's gradients keep the bf16 form: dz has no bound)
+                if training and dense4_f16 and self.bwd_f16:
+                    # data gradient dz K^T in the fp16 form (dz split with a scale per row on
+                    # the device, like a recurrent layer's dxw): the kernel's own rows are the
+                    # [N, 3, K] pieces it reads - no transpose
+                    pieces.tr16 = split_gemm.split16(
+                        k4, split_gemm.W_SCALE, split_gemm.H_B,
+                        out=buf('dense4/t16', lambda: split_gemm.empty16(
+                            k4.shape[0], k4.shape[1], split_gemm.H_B, self.device)))
+                elif training:      # (bf16 form: six products)
                     pieces.make_tr(buf('dense4/tbf16', lambda: split_gemm.empty(
                         k4.shape[0], k4.shape[1], split_gemm.A_ORDER, self.device)), None)
                 self._w_split['dense4'] = pieces
@@ -1150,19 +1158,26 @@ class CTCModel:
         dz = hip.bias_act_bwd(acts['dense4'], d_dense4, cfg.relu_cutoff,
                               cfg.dense_dropout_rate if training else 0.0, g['dense4/bias'])
         k4_split = self._weight_split('dense4', True, acts) if acts['flat_uses_split'] else None
-        if k4_split is not None:
+        dz_split = None
+        if k4_split is not None and k4_split[3] is not None:
+            # (the kernel gradient's bf16 pieces of dz are made where it runs: the side stream)
+            dy = split_gemm.dgrad16(dz, k4_split[3], split_gemm.W_SCALE) \
+                .view(t_out, batch, 2 * hidden)
+            acts['arithmetic']['dense4/data_gradient'] = 'fp16x3'
+        elif k4_split is not None:
             dz_split = split_gemm.split(dz, split_gemm.B_ORDER)
             dy = split_gemm.mm_nt(dz_split, k4_split[1]).view(t_out, batch, 2 * hidden)
         else:
-            dz_split = None
             dy = torch.mm(dz, p['dense4/kernel'].t()).view(t_out, batch, 2 * hidden)
         # `early_hooks` (opt-in, N > 1): a layer's hook - its bucket's all-reduce - fires on the
         # side stream right behind that layer's weight-gradient GEMMs instead of after the whole
         # backlog, so the collective hides behind the layers below (engine.Trainer)
         early = self.early_hooks
 
-        def dense4_weight_grad():
-            if dz_split is not None:
+        def dense4_weight_grad(dz_split=dz_split):
+            if k4_split is not None:
+                if dz_split is None:
+                    dz_split = split_gemm.split(dz, split_gemm.B_ORDER)
                 if acts['flat_split'] is None:      # (the forward pass used fp16 pieces)
                     acts['flat_split'] = split_gemm.split(acts['rnn_flat'], split_gemm.A_ORDER)
                 split_gemm.mm_tn_rows(g['dense4/kernel'], acts['flat_split'], dz_split, 0, rows,

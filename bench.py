@@ -486,6 +486,9 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                     roofline['exchange_load_path'] = {
                         'bytes_per_cu_per_time_step': per_cu,
                         'gb_per_s_per_cu': round(per_cu * launch_steps / avg_s / 1e9, 1),
+                        # a CU's vector-memory path moves 64 B per clock (MI355X_MICROARCH.md)
+                        'peak_gb_per_s_per_cu': 153.6,
+                        'frac': round(per_cu * launch_steps / avg_s / 1e9 / 153.6, 4),
                         'note': 'all-gather of dgates: B x 4H x 4 bytes per workgroup and step '
                                 'whatever the decomposition; a CU sustains ~100 - 125 GB/s on '
                                 'freshly written cross-XCD data (L1 path peak 64 B/clk = 150)'}

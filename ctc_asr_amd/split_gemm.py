@@ -219,11 +219,15 @@ def wgrad16(out, d16, inv, x16, x_scale, x_lo, x_cols=slice(None), d_rows=slice(
     return hip.rescale_rows(tmp, inv, 1.0 / x_scale, out, accumulate=True)
 
 
-def dgrad16(d2d, wt16, w_scale, out=None):
+def dgrad16(d2d, wt16, w_scale, out=None, before_gemm=None):
     """out[R, N] = D[R, K] . W[K, N] from the fp16 pieces of W^T [N, 3, K] (order H_B, scale
     w_scale): D is split with a scale per ROW found on the fly; the row scales and 1 / w_scale
-    come back out of the product in place."""
+    come back out of the product in place.  ``before_gemm()`` runs between the split pass and the
+    library GEMM (the caller's "one library GEMM in flight" wait: the split - an HBM-bound own
+    kernel - may run beside whatever that wait is for)."""
     d16, inv = hip.split_f16_rows(d2d, H_A)
+    if before_gemm is not None:
+        before_gemm()
     rows, _, k = d16.shape
     tmp = torch.mm(d16.view(rows, 3 * k), wt16.concat().t(), out_dtype=F32) if out is None else \
         torch.mm(d16.view(rows, 3 * k), wt16.concat().t(), out_dtype=F32, out=out)

@@ -1,5 +1,7 @@
-// The 11 x 21, stride (1, 2) convolutions over 32 input channels (conv.hip) with their products on
-// the fp16 matrix pipe: forward pass and data gradient (round 4).
+// The convolutions of the DS2 front end (conv.hip) with their products on the fp16 matrix pipe
+// (round 4): forward pass, data gradient and kernel gradient of the 11 x 21, stride (1, 2) layers
+// over 32 input channels, and - at the end of the file - forward pass and kernel gradient of the
+// first layer (1 -> 32 channels, 11 x 41, stride (2, 2)).
 //
 // conv.hip's kernels run at 110 - 140 TFLOP/s of fp32 MFMA (157 peak): MFMA-issue bound, the last
 // fp32-MFMA kernels of the training step.  The forward product's operands are both bounded - the

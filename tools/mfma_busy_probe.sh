@@ -1,4 +1,4 @@
-# MFMA-busy and effective clock of every GEMM-like dispatch of a script:
+# MFMA-busy and effective clock of every GEMM-like / convolution dispatch of a script:
 #   tools/mfma_busy_probe.sh <out.md> python tools/split_gemm_kernel_probe.py
 # (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace; busy = MFMA cycles /
 #  (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs), clock = GRBM_GUI_ACTIVE / 8 / duration)
@@ -20,7 +20,7 @@ for (name, start, end), c in by.items():
     if 'GRBM_GUI_ACTIVE' not in c or 'SQ_VALU_MFMA_BUSY_CYCLES' not in c:
         continue
     dur = (end - start) / 1e3
-    if dur < 200 or not ('Cijk' in name or 'split_gemm' in name):
+    if dur < 60 or not any(tag in name for tag in ('Cijk', 'split_gemm', 'conv', 'wrw16')):
         continue
     key = name[:88]
     agg.setdefault(key, []).append((dur, c['GRBM_GUI_ACTIVE'] / 8.0 / (dur * 1e3),

@@ -38,6 +38,13 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+class NanLossDuringTrainingError(RuntimeError, FloatingPointError):
+    """The training loss is NaN or infinite: what the reference's ``NanTensorHook`` raises
+    (``asr/model.py:368``; ``tf.train.NanLossDuringTrainingError`` is a RuntimeError).  Raised by
+    the deferred checks of `Trainer` (the guard word of the step that hit it, at most
+    `max_steps_ahead` steps later) and by `train.train_epoch` where it reads the loss."""
+
+
 class GradientReducer:
     """Bucketed sum-all-reduce of the flat gradient arena.
 
@@ -213,6 +220,7 @@ class Trainer:
         self.release = 'early' if early else 'held'
         if world_size > 1:   # identical replicas: rank 0's initial parameters win
             dist.broadcast(self.model.arena.param, src=0)
+            self.model.arena.touch()
         # The host enqueues a step several times faster than the GPU runs it.  Left alone it
         # runs ahead without bound: every step's activations (5 GB at C3) are then allocated
         # anew - blocks freed by the host are still in use by steps the GPU has not reached -
@@ -251,8 +259,9 @@ class Trainer:
                 # is read (and the barrier words reset) by the synchronous poll, which raises
                 self.model.check_rnn_error()
             if words[-2] != 0:
-                raise FloatingPointError('non-finite CTC loss in training step {}; its update '
-                                         'was not applied'.format(step))
+                raise NanLossDuringTrainingError(
+                    'NaN loss during training. [non-finite CTC loss in training step {}; its '
+                    'update was not applied]'.format(step))
 
     def drain_checks(self):
         """Wait for the steps in flight and raise what they have to report: CTC status of every

@@ -263,6 +263,11 @@ class ParamArena:
     def num_parameters(self):
         return sum(int(np.prod(s)) for s in self.shapes.values())
 
+    def touch(self):
+        """The parameters were replaced wholesale (a restore, a broadcast): whatever was derived
+        from the previous ones - the lagged weight maxima of the fp16 range guard - is stale."""
+        self.version += 1
+
     def load(self, flat_params):
         """Copy a name->array dict in the shared layout into the parameter arena."""
         for name in self.offsets:

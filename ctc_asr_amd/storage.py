@@ -61,6 +61,7 @@ def restore_checkpoint(path, model):
     if state['shapes'] != arena.shapes:
         raise ValueError('Checkpoint {} was written for a different network layout.'.format(path))
     arena.param.copy_(state['param'])
+    arena.touch()
     arena.m.copy_(state['m'])
     arena.v.copy_(state['v'])
     model.step_count = int(state['step'])

@@ -18,15 +18,11 @@ import numpy as np
 import torch
 
 from ctc_asr_amd import storage, summaries, tf_bundle
-from ctc_asr_amd.engine import Trainer, init_distributed
+from ctc_asr_amd.engine import NanLossDuringTrainingError, Trainer, init_distributed
 from ctc_asr_amd.evaluate import evaluate_dataset
 from ctc_asr_amd.input_functions import input_fn_generator
 from ctc_asr_amd.model import ModelConfig
 from ctc_asr_amd.params import FLAGS, get_parameters
-
-
-class NanLossDuringTrainingError(RuntimeError):
-    """Raised when the training loss is NaN or infinite."""
 
 
 def train_epoch(trainer, target, epoch, rank, world, writer=None, seed=None):

@@ -221,6 +221,39 @@ def test_deferred_checks_still_raise_where_tensorflow_raises():
             torch.cuda.synchronize()
 
 
+def test_a_nan_loss_raises_what_the_reference_raises():
+    """A non-finite loss stops training with `NanLossDuringTrainingError` - the reference's
+    NanTensorHook (asr/model.py:368) - from the Trainer's deferred checks as well (the
+    guard word used to surface as a bare FloatingPointError before `train_epoch`'s own test of the
+    loss could run); the step's update is dropped on the device."""
+    from ctc_asr_amd import train
+    from ctc_asr_amd.engine import NanLossDuringTrainingError, Trainer
+    from ctc_asr_amd.model import ModelConfig
+    assert train.NanLossDuringTrainingError is NanLossDuringTrainingError
+    assert issubclass(NanLossDuringTrainingError, RuntimeError)
+    cfg = ModelConfig(used_model='ds2', conv_filters=(4, 4), num_units_dense=32, num_layers_rnn=1,
+                      num_units_rnn=64, rnn_cell='lstm', cudnn=True, dense_dropout_rate=0.0)
+    trainer = Trainer(cfg, device='cuda', seed=3)
+    rng = np.random.default_rng(5)
+    feats = torch.tensor(rng.normal(size=(2, 21, 80)).astype(np.float32))
+    flen = torch.tensor([21, 21], dtype=torch.int32)
+    labels = [[1, 2, 3], [4, 5]]
+    trainer.train_step(feats, flen, labels)
+    trainer.drain_checks()
+    before = trainer.model.arena.param.clone()
+    poisoned = feats.clone()
+    poisoned[1, 7, 3] = float('nan')
+    trainer.train_step(poisoned, flen, labels)
+    torch.cuda.synchronize()
+    assert torch.equal(trainer.model.arena.param, before)
+    with pytest.raises(NanLossDuringTrainingError, match='NaN loss during training'):
+        trainer.drain_checks()
+    trainer.drain_checks()
+    trainer.train_step(feats, flen, labels)
+    trainer.drain_checks()
+    assert torch.isfinite(trainer.model.arena.param).all()
+
+
 def test_step_guard_words():
     """`ctcasr_step_guard`: the skip word is set by a CTC status word, by a non-finite loss and by
     a recurrence time-out word, and only then; `adam_step(skip=)` honours it."""

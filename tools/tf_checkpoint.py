@@ -46,6 +46,7 @@ def main(argv):
             raise SystemExit('{} was written for a different network layout (check the flags)'
                              .format(latest))
         arena.param.copy_(state['param'])
+        arena.touch()
         print(storage.export_tf_checkpoint(FLAGS.train_dir, arena, cfg, int(state['step'])))
         return 0
     step = storage.import_tf_checkpoint(checkpoint or FLAGS.train_dir, arena, cfg)

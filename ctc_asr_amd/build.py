@@ -16,6 +16,8 @@ HOST_LIB_PATH = os.path.join(PKG_DIR, 'libctcasr_host.so')     # plain C helpers
 HOST_SOURCES = [os.path.join(PKG_DIR, 'host', 'crc32c.c')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# per-file additions (dgrad16.hip: see the note at its `fold1`)
+FILE_FLAGS = {'dgrad16.hip': ['-fno-slp-vectorize']}
 
 
 def sources():
@@ -63,7 +65,7 @@ def build(force=False, verbose=True):
                 max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC_DIR, '*.h'))),
                 os.path.getmtime(os.path.join(PKG_DIR, '..', 'include', 'ctcasr.h'))):
             continue
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -2539,6 +2539,20 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
 #undef PRNN_BWD
 }
 
+// Where prnn_bwd16_kernel keeps what it publishes, for the block-scaled data-gradient kernel that
+// reads it after the pass (csrc/dgrad16.hip): the exchange blocks (the all-zero block first, then
+// one per step) and the inverse scales, of a pass over T steps of B <= 32 rows.
+// (``sync``: the barrier words of the pass's row block, rnn_step.hip: rnn_workspace_sync_block0)
+int prnn_b16_published(void *sync, int T, int B, int H, const char **xchg, const float **scales) {
+    if (!sync || H != PRNN_RS_H || B < 1 || B > PRNN_BLOCK_ROWS || T < 1)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    const char *x = reinterpret_cast<const char *>(sync) + sizeof(SyncWords);
+    *xchg = x;
+    *scales = reinterpret_cast<const float *>(x + prnn_step_exchange_bytes(T, B, H, 4) +
+                                              prnn_rs_ring_bytes());
+    return CTCASR_OK;
+}
+
 size_t prnn_error_offset() { return offsetof(SyncWords, error); }
 
 int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t s) {

@@ -313,6 +313,12 @@ static size_t rnn_state_bytes(int B, int H) {
     return ctcasr_align_up((size_t)6 * B * H * sizeof(float), 256);
 }
 
+// (dgrad16.hip) the barrier words of row block 0 inside a recurrence workspace: the exchange
+// buffer of a pass over B <= 32 rows follows them
+void *rnn_workspace_sync_block0(void *workspace, int B, int H) {
+    return reinterpret_cast<char *>(workspace) + rnn_state_bytes(B, H);
+}
+
 extern "C" size_t ctcasr_rnn_reserve_bytes(int cell, int T, int B, int H) {
     if (T <= 0 || B <= 0 || H <= 0) return 0;
     if (cell == CTCASR_CELL_LSTM) return (size_t)T * B * 2 * 5 * H * sizeof(float);

@@ -14,7 +14,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libctcasr.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BUILD_PROBE_WRONG_RESULTS, BUILD_NONDEFAULT_TUNING = 1, 2      # ctcasr_build_flags() bits
 RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP, RNN_ONE_BARRIER = 0, 1, 2, 4   # rnn_fwd/bwd `flags`
 RNN_REDUCE_SCATTER = 8
@@ -102,6 +102,12 @@ SIGNATURES = {
                                       _c_int, _c_p]),
     'ctcasr_gemm_split_tn': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
                                       _c_int, _c_p]),
+    'ctcasr_dgrad16_packed_bytes': (_c_sz, [_c_int]),
+    'ctcasr_dgrad16_pack_weights': (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_f, _c_p, _c_p]),
+    'ctcasr_dgrad16_supported': (_c_int, [_c_int] * 4),
+    'ctcasr_dgrad16_published_offsets': (_c_int, [_c_int, _c_int, _c_int, _c_p, _c_p]),
+    'ctcasr_dgrad16_blockscaled': (_c_int, [_c_p, _c_int, _c_int, _c_int, _c_p, _c_f, _c_int, _c_p,
+                                            _c_i64] + [_c_int] * 5 + [_c_p]),
     'ctcasr_features_num_frames': (_c_int, [_c_int]),
     'ctcasr_features_tables_bytes': (_c_sz, []),
     'ctcasr_features_init_tables': (_c_int, [_c_p, _c_int, _c_p]),
@@ -670,6 +676,71 @@ def gemm_split_nt(a, b, out=None, accumulate=False):
                                        b.stride(0) if n > 1 else k, out.data_ptr(),
                                        out.stride(0) if m > 1 else n, m, n, k, int(accumulate),
                                        _stream()), 'gemm_split_nt')
+    return out
+
+
+def dgrad16_supported(cell, num_steps, batch, hidden):
+    """Whether the block-scaled data-gradient kernel covers a backward pass of this shape (it reads
+    what the fp16-pipe LSTM-1024 backward recurrence published; include/ctcasr.h, ABI v6)."""
+    return bool(load().ctcasr_dgrad16_supported(CELL_IDS[cell], int(num_steps), int(batch),
+                                                int(hidden)))
+
+
+def dgrad16_published_offsets(num_steps, batch, hidden):
+    """(exchange, inverse scales) byte offsets inside a recurrence workspace of what the fp16-pipe
+    backward recurrence publishes for a pass over (num_steps, batch)."""
+    exchange, scales = ctypes.c_size_t(), ctypes.c_size_t()
+    _check(load().ctcasr_dgrad16_published_offsets(int(num_steps), int(batch), int(hidden),
+                                                   ctypes.byref(exchange), ctypes.byref(scales)),
+           'dgrad16_published_offsets')
+    return exchange.value, scales.value
+
+
+@_on_tensor_device
+def dgrad16_pack_weights(w_ih, hidden, scale, out=None):
+    """fp16 pieces of ``w_ih`` [2 * 4 * hidden, n] * scale in the K order / fragment order the
+    block-scaled data-gradient kernel reads (uint8 buffer of ctcasr_dgrad16_packed_bytes(n))."""
+    if (w_ih.dim() != 2 or w_ih.dtype != torch.float32 or not w_ih.is_cuda or
+            w_ih.stride(1) != 1 or w_ih.shape[0] != 8 * hidden):
+        raise CtcAsrError('dgrad16_pack_weights: w_ih must be an f32 [2 * 4H, n] matrix in HBM '
+                          'with unit column stride.')
+    n = w_ih.shape[1]
+    need = load().ctcasr_dgrad16_packed_bytes(n)
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=w_ih.device)
+    elif out.dtype != torch.uint8 or out.numel() < need or not out.is_contiguous() or \
+            out.device != w_ih.device:
+        raise CtcAsrError('dgrad16_pack_weights: out must be a contiguous uint8 buffer of {} bytes.'
+                          .format(need))
+    _check(load().ctcasr_dgrad16_pack_weights(w_ih.data_ptr(), w_ih.stride(0), int(hidden), n,
+                                              float(scale), out.data_ptr(), _stream()),
+           'dgrad16_pack_weights')
+    return out
+
+
+@_on_tensor_device
+def dgrad16_blockscaled(workspace, num_steps, batch, hidden, packed, scale, n, out=None,
+                        steps=None, dirs=(0, 2), accumulate=False):
+    """dx [T * B, n] (+)= dxw . W_ih from the fp16 pieces an fp16-pipe backward recurrence pass
+    over (num_steps, batch) left in ``workspace`` and the packed pieces of W_ih
+    (`dgrad16_pack_weights`); ``steps`` = (t_lo, t_hi) restricts the rows, ``dirs`` the directions
+    whose gate columns are summed (include/ctcasr.h: ctcasr_dgrad16_blockscaled)."""
+    if not workspace.is_cuda or not packed.is_cuda:
+        raise CtcAsrError('dgrad16_blockscaled: workspace and packed weights must live in HBM.')
+    rows = num_steps * batch
+    if out is None:
+        if accumulate:
+            raise CtcAsrError('dgrad16_blockscaled: accumulate needs out.')
+        out = torch.empty((rows, n), dtype=torch.float32, device=workspace.device)
+    elif (out.dtype != torch.float32 or tuple(out.shape) != (rows, n) or out.stride(1) != 1 or
+          out.device != workspace.device):
+        raise CtcAsrError('dgrad16_blockscaled: out must be an f32 [T * B, n] view with unit '
+                          'column stride.')
+    t_lo, t_hi = (0, num_steps) if steps is None else steps
+    _check(load().ctcasr_dgrad16_blockscaled(
+        workspace.data_ptr(), int(num_steps), int(batch), int(hidden), packed.data_ptr(),
+        float(scale), int(n), out.data_ptr(), out.stride(0), int(t_lo), int(t_hi), int(dirs[0]),
+        int(dirs[1]), int(accumulate), _stream()), 'dgrad16_blockscaled')
     return out
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTCASR_ABI_VERSION 5
+#define CTCASR_ABI_VERSION 6
 
 enum {
     CTCASR_OK = 0,
@@ -443,6 +443,43 @@ int ctcasr_gemm_split_nt(const float *a, int64_t lda, const float *b, int64_t ld
  *   dW = dxw^T x of asr/model.py:203-214's layers); any K, no alignment requirement. */
 int ctcasr_gemm_split_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
                          int64_t ldc, int m, int n, int k, int accumulate, ctcasr_stream_t stream);
+
+/* ABI v6: the data gradient of a recurrent layer's input projection straight from what the fp16
+ * backward recurrence published (csrc/dgrad16.hip) - the gradient of the cuDNN input projection,
+ * asr/model.py:194-215, which TensorFlow computes as one cuBLAS GEMM over dxw:
+ *   dx[T * B, n] (+)= dxw[T * B, 2 * 4H] . W_ih[2 * 4H, n]
+ * where dxw is NOT read as fp32: a pass of ctcasr_rnn_bwd_steps with CTCASR_RNN_F16 (LSTM,
+ * H = 1024, B <= 32, every row running all T steps) has left each step's dgates in the workspace's
+ * exchange buffer as two fp16 pieces per value, scaled per (row, 64 gate columns) by a power of two,
+ * in MFMA operand order, with the inverse scales beside them; the kernel multiplies those into the
+ * packed fp16 pieces of W_ih with one fresh accumulator per 32-column stage that enters the fp32
+ * total times the row's inverse scale (22 significand bits relative to a (row, 64-column block)
+ * maximum; piece product h2 w2 dropped).  No library GEMM, no inter-workgroup waits.
+ *   workspace   the recurrence workspace the backward pass ran in (same T, B as that pass);
+ *               valid until the next persistent launch in that workspace
+ *   packed      ctcasr_dgrad16_packed_bytes(n) bytes from ctcasr_dgrad16_pack_weights(W_ih [2 * 4H,
+ *               n] with leading dimension ld_w, scale): fp16 pieces of W_ih * scale (saturating at
+ *               +-60000: the caller keeps |w| * scale in range), K order and fragment order of the
+ *               exchange buffer
+ *   [t_lo, t_hi)    the time steps (rows t * B .. ) to produce;  [dir_lo, dir_hi) the directions
+ *               whose gate columns enter the sum (0..2: both) - a finished direction / step range
+ *               can be multiplied while the other is still running, the rest added later
+ *               (accumulate != 0)
+ * ctcasr_dgrad16_supported says whether (cell, T, B, H) qualifies.
+ * ctcasr_dgrad16_published_offsets: byte offsets inside the recurrence workspace of the exchange
+ * blocks (block 0 all-zero, block 1 + s = step s: [dir][producer][half][piece][k group][b][8 halves],
+ * step s = time s of direction 0 and time T - 1 - s of direction 1) and of the inverse scales
+ * ([step][dir][producer][32 rows] floats) of a pass over (T, B) - the layout contract between the
+ * recurrence kernel and this one, exposed for tests and for other consumers of the pieces. */
+size_t ctcasr_dgrad16_packed_bytes(int n);
+int ctcasr_dgrad16_published_offsets(int T, int B, int hidden, size_t *exchange,
+                                     size_t *inverse_scales);
+int ctcasr_dgrad16_pack_weights(const float *w_ih, int64_t ld_w, int hidden, int n, float scale,
+                                void *packed, ctcasr_stream_t stream);
+int ctcasr_dgrad16_supported(int cell, int T, int B, int hidden);
+int ctcasr_dgrad16_blockscaled(void *workspace, int T, int B, int hidden, const void *packed,
+                               float scale, int n, float *dx, int64_t ld_dx, int t_lo, int t_hi,
+                               int dir_lo, int dir_hi, int accumulate, ctcasr_stream_t stream);
 
 /* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
  * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):

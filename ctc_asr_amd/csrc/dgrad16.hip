@@ -84,6 +84,9 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 #ifndef DG_SCHED
 #define DG_SCHED 1              // pin the MFMA / VALU / LDS issue order of a row unit
 #endif
+#ifndef DG_PROBE
+#define DG_PROBE 0              // timing probes, results wrong on purpose (ctcasr_build_flags):
+#endif                          // 1 every stage re-reads stage 0's bytes, 2 no MFMAs, 3 no DMA
 #ifndef DG_FOLD_VALU
 #define DG_FOLD_VALU 2          // VALU instructions of the fold in the shadow of one MFMA
 #endif
@@ -155,6 +158,8 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
     auto issue = [&](int ks, unsigned buf) {
+        if (DG_PROBE == 1) ks = 0;
+        if (DG_PROBE == 3 && ks != p.ks_lo) return;
         const int d = ks / DG_STAGES_PER_DIR, pm = ks % DG_STAGES_PER_DIR;
         const size_t a_off = (size_t)pm * 2 * B * 64;
 #pragma unroll
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
         };
         fetch(0, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < (DG_PROBE == 2 ? 0 : 8); ++i) {
             const int sl = i & 1;
             if (i + 1 < 8) fetch(i + 1, sl ^ 1);
 #pragma unroll
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
             }
 #endif
         }
-        fold(7, 1);
+        if (DG_PROBE != 2) fold(7, 1);
     }
 
     // C / D map of the 16 x 16 MFMA: column lane & 15, rows 4 (lane >> 4) + r
@@ -316,6 +321,15 @@ __global__ void __launch_bounds__(256) dgrad16_pack_kernel(const float *w, int64
 int prnn_b16_published(void *sync, int T, int B, int H, const char **xchg, const float **scales);
 // (rnn_step.hip) the barrier words of row block 0 of a recurrence workspace
 void *rnn_workspace_sync_block0(void *workspace, int B, int H);
+
+// this file's share of ctcasr_build_flags() (rnn_persistent.hip)
+unsigned dgrad16_build_flags() {
+    unsigned flags = 0;
+    if (DG_PROBE != 0) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
+    if (DG_SCHED != 1 || DG_FOLD_VALU != 2 || DG_DMA_BUILTIN != 0)
+        flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
+    return flags;
+}
 
 extern "C" size_t ctcasr_dgrad16_packed_bytes(int n) {
     return n > 0 ? (size_t)2 * DG_STAGES_PER_DIR * ((n + 15) / 16) * 2048 : 0;

@@ -2562,8 +2562,9 @@ int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t
 }
 
 // Which non-default tuning / probe macros this library was compiled with (include/ctcasr.h).
+unsigned dgrad16_build_flags();     // (dgrad16.hip)
 extern "C" unsigned ctcasr_build_flags(void) {
-    unsigned flags = 0;
+    unsigned flags = dgrad16_build_flags();
     if (PRNN_PROBE_HALF_LOADS) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
         PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2)

@@ -686,6 +686,10 @@ def dgrad16_supported(cell, num_steps, batch, hidden):
                                                 int(hidden)))
 
 
+def dgrad16_packed_bytes(n):
+    return int(load().ctcasr_dgrad16_packed_bytes(int(n)))
+
+
 def dgrad16_published_offsets(num_steps, batch, hidden):
     """(exchange, inverse scales) byte offsets inside a recurrence workspace of what the fp16-pipe
     backward recurrence publishes for a pass over (num_steps, batch)."""

@@ -321,6 +321,7 @@ class _WeightPieces:
     def __init__(self, model, name, matrix, training):
         self.model, self.name, self.matrix, self.training = model, name, matrix, training
         self.fwd16 = self.tr16 = None
+        self.dg16 = None        # packed for `hip.dgrad16_blockscaled` (instead of ``tr16``)
         self._fwd = self._tr = None
 
     def make_fwd(self, out=None):
@@ -342,6 +343,15 @@ class _WeightPieces:
             hip.transpose_batched(self.matrix.view(1, rows, cols), out=scratch.view(1, cols, rows))
             self._tr = split_gemm.split(scratch, split_gemm.A_ORDER, out=out)
         return self._tr
+
+    def make_tr16(self, out=None, scratch=None):
+        """fp16 pieces of the transpose (the library form of the data gradient)."""
+        rows, cols = self.matrix.shape
+        if scratch is None:
+            scratch = torch.empty((cols, rows), dtype=torch.float32, device=self.matrix.device)
+        hip.transpose_batched(self.matrix.view(1, rows, cols), out=scratch.view(1, cols, rows))
+        self.tr16 = split_gemm.split16(scratch, split_gemm.W_SCALE, split_gemm.H_B, out=out)
+        return self.tr16
 
     def __getitem__(self, index):
         if index == 0:
@@ -424,6 +434,11 @@ class CTCModel:
         # scaled per column (weight gradients) / per row (data gradient) on the device
         self.bwd_f16 = os.environ.get('CTCASR_BWD_F16', '1') == '1'
         self.split_wgrad = os.environ.get('CTCASR_SPLIT_WGRAD', '1') == '1'
+        # the data gradient dxw W_ih of an LSTM-1024 layer by the own block-scaled kernel that reads
+        # the fp16 pieces the fp16-pipe backward recurrence published (csrc/dgrad16.hip): no row
+        # split of dxw, no library GEMM on the main stream - and so no "one library GEMM at a
+        # time" wait for the side stream in front of it
+        self.own_dgrad = os.environ.get('CTCASR_OWN_DGRAD', '1') == '1'
         # the forward recurrence's own product h_(t-1) W_hh^T as two fp16 pieces per operand and
         # three products on the fp16 matrix pipe (LSTM-1024 persistent kernel; |h| <= 1, W_hh
         # scaled per workgroup inside the kernel) instead of fp32 MFMAs
@@ -512,7 +527,7 @@ class CTCModel:
         limit = 0.5 * split_gemm.F16_MAX / split_gemm.W_SCALE
         return {name: bool(guard['max'][k] <= limit) for k, name in enumerate(names)}
 
-    def _prepare_weight_splits(self, rows, training):
+    def _prepare_weight_splits(self, rows, training, batch=None):
         """Pieces of the weights the split GEMMs of this step read (split_gemm.py).  Per recurrent
         layer whose input is bounded (every layer of the BASELINE configurations) and whose W_ih
         is in range: the fp16 pieces of W_ih [2GH, 3, in] for the forward projection and of its
@@ -560,6 +575,15 @@ class CTCModel:
             return bufs[key]
 
         dense4_f16 = dense4 and f16_form(cfg.num_layers_rnn, 'dense4')
+        # the layers whose data gradient the own block-scaled kernel will compute (it reads what
+        # the fp16-pipe backward recurrence publishes): W_ih packed for it, no transposed pieces
+        hidden = cfg.num_units_rnn
+        own_dgrad = bool(
+            training and batch and self.own_dgrad and self.bwd_f16 and self.rnn_bwd_f16 and
+            cfg.cell == 'lstm' and cfg.cudnn and rows % batch == 0 and
+            hip.dgrad16_supported(cfg.cell, rows // batch, batch, hidden) and
+            hip.rnn_bwd_f16_supported(cfg.cell, rows // batch, batch, hidden,
+                                      self.rnn_bwd_flags | hip.RNN_F16))
         with torch.cuda.stream(side):
             for i, name, w_ih in jobs:
                 cols = w_ih.shape[1]
@@ -574,14 +598,18 @@ class CTCModel:
                     # the transpose are needed - made on demand
                     above_f16 = f16_form(i + 1, 'rnn{}'.format(i + 1)) \
                         if i + 1 < cfg.num_layers_rnn else dense4_f16
-                    if training and self.bwd_f16 and above_f16:
-                        scratch = buf(name + '/t', lambda: torch.empty(
-                            (cols, gh2), dtype=torch.float32, device=self.device))
-                        hip.transpose_batched(w_ih.view(1, gh2, -1), out=scratch.view(1, -1, gh2))
-                        pieces.tr16 = split_gemm.split16(
-                            scratch, split_gemm.W_SCALE, split_gemm.H_B,
-                            out=buf(name + '/t16', lambda: split_gemm.empty16(
-                                cols, gh2, split_gemm.H_B, self.device)))
+                    if training and self.bwd_f16 and above_f16 and own_dgrad:
+                        pieces.dg16 = hip.dgrad16_pack_weights(
+                            w_ih, hidden, split_gemm.W_SCALE,
+                            out=buf(name + '/dg16', lambda: torch.empty(
+                                hip.dgrad16_packed_bytes(cols), dtype=torch.uint8,
+                                device=self.device)))
+                    elif training and self.bwd_f16 and above_f16:
+                        pieces.make_tr16(
+                            buf(name + '/t16', lambda: split_gemm.empty16(
+                                cols, gh2, split_gemm.H_B, self.device)),
+                            buf(name + '/t', lambda: torch.empty(
+                                (cols, gh2), dtype=torch.float32, device=self.device)))
                 else:
                     pieces.make_fwd(buf(name + '/bf16', lambda: split_gemm.empty(
                         gh2, cols, split_gemm.B_ORDER, self.device)))
@@ -658,7 +686,7 @@ class CTCModel:
         sequences = sequences.to(self.device, torch.float32).contiguous()
         batch, frames, _ = sequences.shape
         acts = {'training': training, 'batch': batch, 'conv_f16': {}}
-        self._prepare_weight_splits(cfg.output_time(frames) * batch, training)
+        self._prepare_weight_splits(cfg.output_time(frames) * batch, training, batch)
         if cfg.used_model == 'ds2':
             # conv dropout: the reference never forwards `training` to conv_layers, so a
             # non-zero conv_dropout_rate fires in evaluation too (asr/model.py:161).
@@ -1244,7 +1272,8 @@ class CTCModel:
             else:
                 y16 = acts['flat16'] if acts['flat_of'] is y else None
             g16 = (self.bwd_f16 and use_split and x16 is not None and y16 is not None and
-                   w_pieces[3] is not None and 2 * gh <= 16384 and self.split_wgrad)
+                   (w_pieces[3] is not None or w_pieces.dg16 is not None) and
+                   2 * gh <= 16384 and self.split_wgrad)
             ds = drs = None
             if use_split and not g16:
                 ds = split_gemm.empty(rows, 2 * gh, split_gemm.B_ORDER, dy.device)
@@ -1390,7 +1419,22 @@ class CTCModel:
             # step); GEMMs beside this package's own kernels are fine, those never wait on them.
             dy_below = None
             if i > 0 or need_dx_first:
-                if g16:
+                own_dg = (g16 and w_pieces.dg16 is not None and f16_rec and
+                          acts['rnn_len'] is None and
+                          hip.dgrad16_supported(cell, t_out, batch, hidden))
+                arith['rnn{}/data_gradient'.format(i)] = \
+                    'fp16x3 block-scaled (own kernel)' if own_dg else \
+                    'fp16x3' if g16 else 'bf16x6' if use_split else 'fp32'
+                if own_dg:
+                    # straight from the pieces the recurrence launches above published into the
+                    # workspace (valid until the next persistent launch): an own kernel that
+                    # waits for no other workgroup - the side stream keeps its backlog
+                    dy_below = hip.dgrad16_blockscaled(
+                        acts['rnn_ws'], t_out, batch, hidden, w_pieces.dg16, split_gemm.W_SCALE,
+                        w_ih.shape[1]).view(t_out, batch, -1)
+                elif g16:
+                    if w_pieces[3] is None:     # (packed for the own kernel, which did not apply)
+                        w_pieces.make_tr16()
                     # (the row split of dxw runs beside what is left of the side stream's
                     # backlog - 0.2 - 0.3 ms per C3 layer; only the GEMM has to wait for it)
                     dy_below = split_gemm.dgrad16(

@@ -61,32 +61,32 @@ struct DgArgs {
 // outstanding DMA itself and waits vmcnt(0) in front of the first LDS read it cannot prove
 // disjoint - in the middle of the stage that is supposed to hide the transfer.  Here the waits are
 // explicit (`dma_wait` in front of the stage barrier).
-#ifndef DG_DMA_BUILTIN
-#define DG_DMA_BUILTIN 0
-#endif
-__device__ __forceinline__ void dma16(const char *src, unsigned lds_base) {
-#if DG_DMA_BUILTIN
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)(uintptr_t)lds_base,
-                                     16, 0, 0);
-    return;
-#endif
+// (address = 64-bit uniform base in SGPRs + the lane's own 32-bit offset: per DMA one scalar add,
+// no vector address arithmetic)
+__device__ __forceinline__ void dma16(const char *base, unsigned lane_off, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(src), "s"(lds_base)
+                 : "v"(lane_off), "s"(base), "s"(lds_base)
                  : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // tuning switches of the stage loop (reported by ctcasr_build_flags when not at their defaults)
 #ifndef DG_SCHED
-#define DG_SCHED 1              // pin the MFMA / VALU / LDS issue order of a row unit
+#define DG_SCHED 0              // pin the MFMA / VALU / LDS issue order of a row unit (slower)
+#endif
+#ifndef DG_YOUNG_PRIO
+#define DG_YOUNG_PRIO 0         // s_setprio of waves 4 - 7 (0: none)
+#endif
+#ifndef DG_LOADERS
+#define DG_LOADERS 4            // waves that issue the DMAs (8: every wave its eighth)
 #endif
 #ifndef DG_PROBE
 #define DG_PROBE 0              // timing probes, results wrong on purpose (ctcasr_build_flags):
-#endif                          // 1 every stage re-reads stage 0's bytes, 2 no MFMAs, 3 no DMA
+#endif                          // 1 every stage re-reads stage 0's bytes, 2 no MFMAs, 3 no DMA,
+                                // 4 phase clocks of workgroup 0 into the first floats of dx
 #ifndef DG_FOLD_VALU
 #define DG_FOLD_VALU 2          // VALU instructions of the fold in the shadow of one MFMA
 #endif
@@ -122,63 +122,65 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
     const int nt0 = tn * (DG_BN / 16);
     const size_t x_step = (size_t)2 * B * DG_GH * sizeof(float);
 
-    // ---- what this lane fetches per stage -------------------------------------------------------
-    // A: the wave's two row units x two pieces; lane l of a chunk = k group l >> 4, row l & 15
-    const char *a_src[2][2];
+    // ---- DMA addressing: uniform 64-bit bases (scalar arithmetic per DMA) + one 32-bit offset per
+    // lane.  A chunk (unit u, piece): lane l = k group l >> 4, row l & 15 of the unit's 16 rows -
+    // the lane's part depends on the unit's half h only; B chunk: lane-linear
+    unsigned a_lane[2];
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-        const int u = 2 * wave + uu;
-        const int t = min(t0 + u / ups, p.t_hi - 1), h = u % ups;
-        const int row = min(h * 16 + (lane & 15), B - 1);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int s = d == 0 ? t : p.T - 1 - t;
-            a_src[uu][d] = p.xchg + (size_t)(1 + s) * x_step +
-                           ((size_t)d * B * DG_GH + (size_t)(lane >> 4) * B * 4 + (size_t)row * 4) *
-                               sizeof(float);
-        }
-    }
-    // B: the wave's two column tiles x two pieces, lane-linear
-    const char *b_src[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-        b_src[jj] = p.wpk + (size_t)min(nt0 + 2 * wave + jj, p.nt_total - 1) * 2048 + lane * 16;
-    // inverse scales (wave 7): lane l = unit l >> 2, rows 4 (l & 3) .. + 3
-    const float *s_src[2];
+    for (int h = 0; h < 2; ++h)
+        a_lane[h] = (unsigned)(((lane >> 4) * B * 4 + min(h * 16 + (lane & 15), B - 1) * 4) *
+                               sizeof(float));
+    const unsigned b_lane = lane * 16;
+    // inverse scales: lane l = unit l >> 2, rows 4 (l & 3) .. + 3
+    unsigned s_off[2];
     {
         const int u = lane >> 2;
         const int t = min(t0 + u / ups, p.t_hi - 1), h = u % ups;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             const int s = d == 0 ? t : p.T - 1 - t;
-            s_src[d] = p.scales + ((size_t)s * 2 + d) * (DG_H / 16) * DG_SCALE_ROWS + h * 16 +
-                       4 * (lane & 3);
+            s_off[d] = (unsigned)((((size_t)s * 2 + d) * (DG_H / 16) * DG_SCALE_ROWS + h * 16 +
+                                   4 * (lane & 3)) * sizeof(float));
         }
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
-    auto issue = [&](int ks, unsigned buf) {
+    // The 65 DMAs of a stage take the CU's one vector-memory issue path ~16 clocks each (1 KB at
+    // 64 B per clock), and a wave sits in that queue while its DMAs wait.  The first DG_LOADERS
+    // waves issue them all: they are the older half of the workgroup, win every arbitration and
+    // would otherwise wait ~1700 clocks at the stage barrier for the younger half.
+    constexpr int PER = 32 / DG_LOADERS;        // chunks of A and of B per loading wave
+    // (what does not change from stage to stage, as 32-bit offsets: scalar registers)
+    unsigned a_unit[PER / 2][2], b_tile[PER / 2];
+#pragma unroll
+    for (int c = 0; c < PER / 2; ++c) {
+        const int u = (wave % DG_LOADERS) * (PER / 2) + c;
+        const int t = min(t0 + u / ups, p.t_hi - 1);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+            a_unit[c][d] = __builtin_amdgcn_readfirstlane((unsigned)(
+                (size_t)(1 + (d == 0 ? t : p.T - 1 - t)) * x_step + (size_t)d * B * DG_GH * sizeof(float)));
+        b_tile[c] = __builtin_amdgcn_readfirstlane(
+            (unsigned)(min(nt0 + u, p.nt_total - 1) * 2048));
+    }
+    // quarter q (0 .. 3) of a loading wave's DMAs for stage ks
+    auto issue = [&](int ks, unsigned buf, int q) {
         if (DG_PROBE == 1) ks = 0;
-        if (DG_PROBE == 3 && ks != p.ks_lo) return;
+        if ((DG_PROBE == 3 && ks != p.ks_lo) || wave >= DG_LOADERS) return;
         const int d = ks / DG_STAGES_PER_DIR, pm = ks % DG_STAGES_PER_DIR;
-        const size_t a_off = (size_t)pm * 2 * B * 64;
+        const char *a_base = p.xchg + (size_t)pm * 2 * B * 64;
+        const char *b_base = p.wpk + (size_t)ks * p.nt_total * 2048;
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
-                dma16((d ? a_src[uu][1] : a_src[uu][0]) + a_off + (size_t)pc * B * 64,
-                      buf + ((2 * wave + uu) * 2 + pc) * 1024);
-        const size_t b_off = (size_t)ks * p.nt_total * 2048;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
-                dma16(b_src[jj] + b_off + pc * 1024,
-                      buf + DG_A_BYTES + ((2 * wave + jj) * 2 + pc) * 1024);
-        if (wave == 7)
-            dma16(reinterpret_cast<const char *>((d ? s_src[1] : s_src[0]) +
-                                                 (size_t)(pm >> 1) * DG_SCALE_ROWS),
-                  buf + DG_A_BYTES + DG_B_BYTES);
+        for (int c = q * (PER / 4); c < (q + 1) * (PER / 4); ++c) {
+            const int chunk = wave * PER + c, u = chunk >> 1, pc = chunk & 1;
+            dma16(b_base + b_tile[c >> 1] + (c & 1) * 1024, b_lane,
+                  buf + DG_A_BYTES + (wave * PER + c) * 1024);
+            dma16(a_base + (d ? a_unit[c >> 1][1] : a_unit[c >> 1][0]) + (size_t)pc * B * 64,
+                  (u % ups) ? a_lane[1] : a_lane[0], buf + chunk * 1024);
+        }
+        if (q == 0 && wave == DG_LOADERS - 1)
+            dma16(reinterpret_cast<const char *>(p.scales + (size_t)(pm >> 1) * DG_SCALE_ROWS),
+                  d ? s_off[1] : s_off[0], buf + DG_A_BYTES + DG_B_BYTES);
     };
 
     f32x4 total[8][4];
@@ -188,24 +190,56 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
         for (int j = 0; j < 4; ++j) total[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    issue(p.ks_lo, lds0);
+#if DG_YOUNG_PRIO
+    // (the younger half of the workgroup loses every arbitration to the older one, which issues the
+    // DMAs and still finishes its stage ~800 clocks earlier: a static priority for the second half)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(DG_YOUNG_PRIO);
+#endif
+    for (int q = 0; q < 4; ++q) issue(p.ks_lo, lds0, q);
+    unsigned long long pt[4] = {0, 0, 0, 0}, pc0 = 0;
     for (int ks = p.ks_lo; ks < p.ks_hi; ++ks) {
         const int par = (ks - p.ks_lo) & 1;
         const char *cur = smem + par * DG_STAGE_BYTES;
         // this stage has landed (every wave waits for its own chunks, then the barrier) and
         // everybody is done reading the other buffer: refill it, then multiply
+        if (DG_PROBE == 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long c = __builtin_readcyclecounter();
+            if (ks > p.ks_lo) pt[3] += c - pc0;
+            pc0 = c;
+        }
         dma_wait();
+        if (DG_PROBE == 4) {
+            const unsigned long long c = __builtin_readcyclecounter();
+            pt[0] += c - pc0; pc0 = c;
+        }
         __syncthreads();
-        if (ks + 1 < p.ks_hi) issue(ks + 1, lds0 + (par ^ 1) * DG_STAGE_BYTES);
+        if (DG_PROBE == 4) {
+            const unsigned long long c = __builtin_readcyclecounter();
+            pt[1] += c - pc0; pc0 = c;
+        }
+        const unsigned nxt = lds0 + (par ^ 1) * DG_STAGE_BYTES;
+        const bool more = ks + 1 < p.ks_hi;
+        if (more)
+            for (int q = 0; q < 4; ++q) issue(ks + 1, nxt, q);
+        if (DG_PROBE == 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long c = __builtin_readcyclecounter();
+            pt[2] += c - pc0; pc0 = c;
+        }
 
+        // (one address register per operand: everything that is not a compile-time constant - the
+        // buffer's parity, the wave's place in the tile, the lane - sits in the base, the reads
+        // carry immediate offsets)
+        const char *a_rd = cur + wr * (8 * 2048) + lane * 16;
+        const char *b_rd = cur + DG_A_BYTES + wc * (4 * 2048) + lane * 16;
+        const char *s_rd = cur + DG_A_BYTES + DG_B_BYTES + wr * (8 * 64) + (lane >> 4) * 16;
         DgFrag w1[4], w2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const char *bp = cur + DG_A_BYTES + ((4 * wc + j) * 2) * 1024 + lane * 16;
-            w1[j].u = *reinterpret_cast<const u32x4 *>(bp);
-            w2[j].u = *reinterpret_cast<const u32x4 *>(bp + 1024);
+            w1[j].u = *reinterpret_cast<const u32x4 *>(b_rd + j * 2048);
+            w2[j].u = *reinterpret_cast<const u32x4 *>(b_rd + j * 2048 + 1024);
         }
-        const float *stab = reinterpret_cast<const float *>(cur + DG_A_BYTES + DG_B_BYTES);
         // Software pipeline over the wave's 8 row units: the fragments and inverse scales of unit
         // i + 1 are read and unit i - 1's fresh accumulators are folded into the totals while
         // unit i's 12 MFMAs issue (two sets of fresh accumulators).
@@ -213,10 +247,9 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
         float4 iv[3];               // (unit i - 1's are still needed when unit i + 1's arrive)
         f32x4 f[2][4];
         auto fetch = [&](int i, int slot) {
-            const int u = 8 * wr + i;
-            d1[slot].u = *reinterpret_cast<const u32x4 *>(cur + (u * 2) * 1024 + lane * 16);
-            d2[slot].u = *reinterpret_cast<const u32x4 *>(cur + (u * 2 + 1) * 1024 + lane * 16);
-            iv[i % 3] = *reinterpret_cast<const float4 *>(stab + u * 16 + 4 * (lane >> 4));
+            d1[slot].u = *reinterpret_cast<const u32x4 *>(a_rd + i * 2048);
+            d2[slot].u = *reinterpret_cast<const u32x4 *>(a_rd + i * 2048 + 1024);
+            iv[i % 3] = *reinterpret_cast<const float4 *>(s_rd + i * 64);
         };
         auto fold = [&](int i, int slot) {
             const float4 s4 = iv[i % 3];
@@ -282,6 +315,12 @@ __global__ void __launch_bounds__(DG_THREADS) dgrad16_bs_kernel(DgArgs p) {
         store_tiles(std::true_type{});
     else
         store_tiles(std::false_type{});
+    if (DG_PROBE == 4 && blockIdx.x == 0 && lane == 0) {
+        // [wave][dma wait, barrier, issue, multiply] in clocks per stage
+        __syncthreads();
+        for (int k = 0; k < 4; ++k)
+            p.out[(size_t)p.ldc * 300 + wave * 4 + k] = (float)pt[k] / (float)(p.ks_hi - p.ks_lo);
+    }
 }
 
 // W_ih [2 * 4H, N] (row = dir * 4H + gate * H + unit) -> fp16 pieces of w * scale in the K order of
@@ -326,7 +365,7 @@ void *rnn_workspace_sync_block0(void *workspace, int B, int H);
 unsigned dgrad16_build_flags() {
     unsigned flags = 0;
     if (DG_PROBE != 0) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
-    if (DG_SCHED != 1 || DG_FOLD_VALU != 2 || DG_DMA_BUILTIN != 0)
+    if (DG_SCHED != 0 || DG_LOADERS != 4 || DG_YOUNG_PRIO != 0 || DG_FOLD_VALU != 2 || 0)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

@@ -439,6 +439,13 @@ class CTCModel:
         # split of dxw, no library GEMM on the main stream - and so no "one library GEMM at a
         # time" wait for the side stream in front of it
         self.own_dgrad = os.environ.get('CTCASR_OWN_DGRAD', '1') == '1'
+        # ... and, being no library kernel, in halves: a finished launch of the backward recurrence
+        # has published one direction's dgates for its range of time steps - that direction's share
+        # of dx (half of the K axis) is multiplied beside the next launch ('side': on the side
+        # stream ahead of the range's weight gradients, 'own': on a third stream), only the last
+        # launch's share stays on the main stream ('0': the whole product behind the last launch)
+        self.dgrad_early = os.environ.get('CTCASR_DGRAD_EARLY', '0')
+        self._dgrad_stream = None
         # the forward recurrence's own product h_(t-1) W_hh^T as two fp16 pieces per operand and
         # three products on the fp16 matrix pipe (LSTM-1024 persistent kernel; |h| <= 1, W_hh
         # scaled per workgroup inside the kernel) instead of fp32 MFMAs
@@ -1391,6 +1398,25 @@ class CTCModel:
                 if f16_rec and g16 else None
             if colmax is not None:
                 side_tensors.append(colmax)
+            need_dx = i > 0 or need_dx_first
+            own_dg = (need_dx and g16 and w_pieces.dg16 is not None and f16_rec and
+                      acts['rnn_len'] is None and
+                      hip.dgrad16_supported(cell, t_out, batch, hidden))
+            early_dg = own_dg and chunks > 1 and self.dgrad_early in ('side', 'own') and \
+                side is not main
+            dx2d, dg_done = None, []
+            if early_dg:
+                # every share accumulates (odd T': the ranges of the two directions overlap by a row)
+                dx2d = torch.zeros((rows, w_ih.shape[1]), dtype=torch.float32, device=dy.device)
+                side_tensors.append(dx2d)
+
+            def dgrad_share(lo, hi, dx2d=dx2d, w_pieces=w_pieces, n=w_ih.shape[1]):
+                # steps [lo, hi) of the pass: direction 0's times [lo, hi), direction 1's mirrored
+                for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
+                    hip.dgrad16_blockscaled(acts['rnn_ws'], t_out, batch, hidden, w_pieces.dg16,
+                                            split_gemm.W_SCALE, n, out=dx2d, steps=(a, b),
+                                            dirs=(d, d + 1), accumulate=True)
+
             for c in range(chunks):
                 hip.rnn_bwd(cell, dy, y, self._w_hh_t[i], acts['reserves'][i], acts['rnn_len'],
                             dxw=dxw, dbias=dbias, workspace=acts['rnn_ws'],
@@ -1398,8 +1424,26 @@ class CTCModel:
                             ticket=self._take_ticket() if persistent and not whole_chip_rnn
                             else 0, colmax=None if colmax is None else colmax[c])
                 if c + 1 < chunks:
+                    if early_dg and self.dgrad_early == 'own':
+                        if self._dgrad_stream is None:
+                            self._dgrad_stream = torch.cuda.Stream(self.device)
+                        ready = torch.cuda.Event()
+                        ready.record(main)
+                        with torch.cuda.stream(self._dgrad_stream):
+                            self._dgrad_stream.wait_event(ready)
+                            if persistent:      # (let the next launch take its 128 CUs first)
+                                self._gate_side_stream(cell, acts['rnn_ws'], t_out, batch, hidden)
+                            dgrad_share(bounds[c + 1], bounds[c])
+                            dg_done.append(torch.cuda.Event())
+                            dg_done[-1].record(self._dgrad_stream)
+                        dx2d.record_stream(self._dgrad_stream)
+
                     def finished_steps(lo=bounds[c + 1], hi=bounds[c],
                                        colmax=None if colmax is None else colmax[c]):
+                        if early_dg and self.dgrad_early == 'side':
+                            dgrad_share(lo, hi)
+                            dg_done.append(torch.cuda.Event())
+                            dg_done[-1].record(torch.cuda.current_stream(self.device))
                         if ds is not None:  # these steps' pieces: beside the next launch as well
                             split_steps(lo, hi)
                             split_done.append(torch.cuda.Event())
@@ -1418,14 +1462,18 @@ class CTCModel:
             # stream against a [4096 x 640] weight gradient on the side stream, second training
             # step); GEMMs beside this package's own kernels are fine, those never wait on them.
             dy_below = None
-            if i > 0 or need_dx_first:
-                own_dg = (g16 and w_pieces.dg16 is not None and f16_rec and
-                          acts['rnn_len'] is None and
-                          hip.dgrad16_supported(cell, t_out, batch, hidden))
+            if need_dx:
                 arith['rnn{}/data_gradient'.format(i)] = \
                     'fp16x3 block-scaled (own kernel)' if own_dg else \
                     'fp16x3' if g16 else 'bf16x6' if use_split else 'fp32'
-                if own_dg:
+                if early_dg:
+                    # the earlier launches' shares ran beside the launches after them; the last
+                    # launch's share here
+                    for event in dg_done:
+                        main.wait_event(event)
+                    dgrad_share(0, bounds[-2])
+                    dy_below = dx2d.view(t_out, batch, -1)
+                elif own_dg:
                     # straight from the pieces the recurrence launches above published into the
                     # workspace (valid until the next persistent launch): an own kernel that
                     # waits for no other workgroup - the side stream keeps its backlog

@@ -52,6 +52,9 @@ print('shape [{} x {}] x [{} x {}]'.format(T * B, 8 * H, 8 * H, N))
 print('own kernel       {:.3f} ms  {:.0f} TFLOP/s fp32-equivalent ({:.0f} on the fp16 pipe)  '
       'rms / row error {:.2e} / {:.2e}'.format(ms_own, flop / ms_own * 1e-9, 3 * flop / ms_own * 1e-9,
                                                *rel_errors(got, ref)))
+if os.environ.get('DG_PROF'):
+    print('phase clocks per stage [wave][dma wait, barrier, issue, multiply]:')
+    print(got[300, :32].view(8, 4).cpu().numpy().round(0))
 print('pack of W_ih     {:.3f} ms'.format(ms_pack))
 print('library path     {:.3f} ms (row split alone {:.3f})  rms / row error {:.2e} / {:.2e}'
       .format(ms_lib, ms_split, *rel_errors(lib, ref)))

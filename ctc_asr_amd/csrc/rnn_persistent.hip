@@ -33,6 +33,12 @@
 #define PRNN_GROUPS 8
 #endif
 #define PRNN_SPIN_LIMIT (1u << 22)
+// timing probe only (wrong results): the reduce-scatter backward kernel issues this many of its 4
+// K quarters of MFMAs - 1 prices the form's exchange pattern with the matrix work of the fp16 pipe
+// (96 short MFMAs where the fp32 kernel issues 256 long ones), profiles/r05_rnn_bwd_reduce_scatter_f16.md
+#ifndef PRNN_PROBE_RS_Q
+#define PRNN_PROBE_RS_Q 4
+#endif
 #ifndef PRNN_PROBE_HALF_LOADS
 #define PRNN_PROBE_HALF_LOADS 0
 #endif
@@ -1682,7 +1688,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
             for (int jp = 0; jp < JW; jp += 2) {
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < PRNN_PROBE_RS_Q; ++q)
                     mma4x2(acc0, acc1, a[q], bfrag(jp * 4 + q), a[q], bfrag((jp + 1) * 4 + q));
                 store16_sc1(x_rsrc, wr + (unsigned)(jp * NWG) * PRNN_RS_TILE_BYTES,
                             acc0[0], acc0[1], acc0[2], acc0[3]);
@@ -2565,7 +2571,7 @@ int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t
 unsigned dgrad16_build_flags();     // (dgrad16.hip)
 extern "C" unsigned ctcasr_build_flags(void) {
     unsigned flags = dgrad16_build_flags();
-    if (PRNN_PROBE_HALF_LOADS) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
+    if (PRNN_PROBE_HALF_LOADS || PRNN_PROBE_RS_Q != 4) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
         PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;

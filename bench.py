@@ -147,7 +147,8 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
             three = split - dense4            # + every gradient GEMM but dense4's kernel gradient
     # the recurrences' own products (h W_hh^T forward, dgates W_hh backward: `rec` each) leave the
     # fp32 pipe for three fp16 products where the fp16-pipe persistent kernels run them
-    rec16 = rec * sum(1 for on in rec_f16 if on) if cfg.cell == 'lstm' else 0.0
+    # (LSTM: both passes have fp16-pipe kernels; GRU: the forward pass)
+    rec16 = rec * sum(1 for on in rec_f16 if on) if cfg.cell in ('lstm', 'gru') else 0.0
     fp32 -= rec16
     # ... and the convolutions (forward, data gradient, kernel gradient: csrc/conv16.hip)
     conv16 = 3.0 * conv_flops_per_utt(cfg, frames) if (conv_f16 and cfg.used_model == 'ds2') \
@@ -219,30 +220,36 @@ def _cpu_baseline_worker(spec):
             opt.step()
         return one_step
 
+    # the thread count is chosen AT THE MEASURED BATCH (a batch-4 proxy picked 16
+    # threads for batch 32): one warm-up + one timed step per candidate, most promising first,
+    # until the sweep budget is spent or a candidate is clearly slower than the best so far
     sweep = {}
-    proxy = make_step(spec['proxy_batch'])
-    deadline = time.perf_counter() + spec['sweep_budget_s']
+    full = make_step(spec['batch'])
+    t_start = time.perf_counter()
+    warm = None
     for threads in spec['candidates']:
         torch.set_num_threads(threads)
-        proxy()                                   # warm-up at this thread count
         t0 = time.perf_counter()
-        proxy()
+        full()                                    # warm-up at this thread count
+        warm = warm or time.perf_counter() - t0
+        t0 = time.perf_counter()
+        full()
         sweep[threads] = time.perf_counter() - t0
-        # more threads only get slower from here (oversubscribed LSTM steps): stop sweeping
-        if time.perf_counter() > deadline or sweep[threads] > 1.5 * min(sweep.values()):
+        spent = time.perf_counter() - t_start
+        if spent + 2.2 * sweep[threads] > spec['sweep_budget_s'] or \
+                sweep[threads] > 1.5 * min(sweep.values()):
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    full = make_step(spec['batch'])
-    t0 = time.perf_counter()
-    full()                                        # warm-up (also tells us how long a step takes)
-    warm = time.perf_counter() - t0
-    steps = int(max(1, min(10, (spec['budget_s'] - warm) // max(warm, 1e-3))))
-    t0 = time.perf_counter()
+    steps = int(max(0, min(4, (spec['budget_s'] - (time.perf_counter() - t_start)) //
+                           max(sweep[best], 1e-3))))
+    total, count = sweep[best], 1
     for _ in range(steps):
+        t0 = time.perf_counter()
         full()
-    per_step = (time.perf_counter() - t0) / steps
-    print(json.dumps({'steps': steps, 'per_step': per_step, 'warm': warm, 'threads': best,
+        total += time.perf_counter() - t0
+        count += 1
+    print(json.dumps({'steps': count, 'per_step': total / count, 'warm': warm, 'threads': best,
                       'sweep': {str(k): round(v, 3) for k, v in sweep.items()}}))
 
 
@@ -261,18 +268,19 @@ def host_cores():
     return logical, physical
 
 
-def cpu_baseline(cfg_kwargs, batch, seconds, frames, budget_s=25.0, hard_limit_s=300.0):
+def cpu_baseline(cfg_kwargs, batch, seconds, frames, budget_s=90.0, hard_limit_s=300.0):
     """CPU baseline (kind "port") at the SAME batch as the GPU line, in a child process with a
     hard time limit so that a slow host can never stall the benchmark.  The thread count is
-    swept up to all physical cores (torch's CPU LSTM stops scaling well before that on a big
-    host) on a 4-utterance proxy batch; the full batch then runs with the fastest count."""
+    swept at that batch (torch's CPU LSTM stops scaling well before all cores of a big host):
+    16, 32, 64, then 8 and everything, while the sweep budget lasts."""
     logical, physical = host_cores()
-    candidates = sorted({c for c in (8, 16, 32, 64, 128, physical) if c <= physical} or {1})
+    candidates = [c for c in (16, 32, 64, 8, 128, physical) if c <= physical] or [1]
+    candidates = list(dict.fromkeys(candidates))
     code = ('import json,sys; sys.path.insert(0, {!r}); import bench; '
             'bench._cpu_baseline_worker(json.loads(sys.argv[1]))').format(ROOT)
     spec = {'cfg': cfg_kwargs, 'candidates': candidates, 'batch': batch,
-            'proxy_batch': min(4, batch), 'seconds': seconds, 'frames': frames,
-            'budget_s': budget_s, 'sweep_budget_s': 60.0}
+            'seconds': seconds, 'frames': frames,
+            'budget_s': budget_s, 'sweep_budget_s': 75.0}
     try:
         out = subprocess.run([sys.executable, '-c', code, json.dumps(spec)],
                              capture_output=True, text=True, timeout=hard_limit_s)
@@ -285,11 +293,11 @@ def cpu_baseline(cfg_kwargs, batch, seconds, frames, budget_s=25.0, hard_limit_s
             'cores': info['threads'], 'kind': 'port',
             'sample': '{} timed fwd+bwd+Adam step(s) after 1 warm-up, batch {} x {:.0f} s (the '
                       'GPU line\'s batch), torch {} CPU ops (oracle/torch_ref.py), {:.2f} s/step '
-                      'with {} threads = fastest of a sweep over {} threads on a batch-{} proxy '
-                      '(s/step {}); host: {} physical / {} logical cores'.format(
+                      'with {} threads = fastest of a sweep over {} threads at this batch '
+                      '(s/step {}; one warm-up step per thread count); host: {} physical / {} '
+                      'logical cores'.format(
                           info['steps'], batch, seconds, torch.__version__, info['per_step'],
-                          info['threads'], candidates, spec['proxy_batch'], info['sweep'],
-                          physical, logical)}
+                          info['threads'], candidates, info['sweep'], physical, logical)}
 
 
 # ------------------------------------------------------------------------------ measurement
@@ -428,6 +436,14 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         elapsed = max(float(t.item()) for t in every)          # MAX over ranks (the contract)
     checks()
+    # (with --no-step-checks / at N > 1 the per-step checks are off: a sticky guard word would make
+    # every later step a no-op that is still timed - never report such a run as throughput)
+    skipped = trainer.skipped_step_count()
+    if skipped:
+        failure.append('rank {}: {} training step(s) were dropped on the device (guard word set)'
+                       .format(rank, skipped))
+        if world == 1:
+            raise hip.CtcAsrError(failure[-1])
     failed_ranks = 0
     if world > 1:
         flag = torch.tensor([1.0 if failure else 0.0], device=device)
@@ -507,7 +523,10 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                     'us_per_time_step': round(avg_s * 1e6 / launch_steps, 3),
                     'share_of_step': round(dom_ms / (elapsed * 1e3), 3),
                     'other_pass': {
-                        'kernel': 'prnn_{}_kernel'.format('fwd' if dom == 'rnn_bwd' else 'bwd'),
+                        'kernel': 'prnn_{}{}_kernel'.format(
+                            'fwd' if dom == 'rnn_bwd' else 'bwd',
+                            '16' if model.arithmetic().get('rnn0/recurrence_{}'.format(
+                                'fwd' if dom == 'rnn_bwd' else 'bwd')) == 'fp16x3' else ''),
                         'us_per_time_step': round(
                             kernel_events['fwd' if dom == 'rnn_bwd' else 'bwd'][1] * 1e3 /
                             max(1.0, t_out * args.steps * cfg.num_layers_rnn), 3)}})
@@ -565,6 +584,22 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
             'hbm_reserved_gb': round(torch.cuda.max_memory_reserved(device) / 2.0 ** 30, 2),
             'roofline': roofline,
         }
+        if events.get('dgrad16', (0, 0.0))[0]:
+            # the own block-scaled data-gradient kernel (csrc/dgrad16.hip), HIP event pairs around
+            # its launches inside the timed region: dx = dxw W_ih of every recurrent layer
+            calls_dg, ms_dg = events['dgrad16']
+            in_sizes = [cfg.rnn_input_size()] + [2 * hidden] * (cfg.num_layers_rnn - 1)
+            flop = sum(2.0 * t_out * batch * 2 * gates * hidden * n for n in in_sizes) * args.steps
+            result['data_gradient_kernel'] = {
+                'kernel': 'dgrad16_bs_kernel (dxw read as the fp16 pieces the backward recurrence '
+                          'published; block-scaled, LDS-DMA operands, no library GEMM)',
+                'launches': calls_dg, 'avg_launch_us': round(ms_dg * 1e3 / calls_dg, 1),
+                'bound': 'mfma', 'unit': 'TFLOP/s',
+                'achieved': round(flop / (ms_dg * 1e-3) / 1e12, 1),
+                'peak': round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1),
+                'frac': round(flop / (ms_dg * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4),
+                'pipe': 'fp16 MFMA, 3 piece products per fp32 product',
+                'share_of_step': round(ms_dg / (elapsed * 1e3), 3)}
         if world > 1:
             result['allreduce'] = {
                 'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ''),
@@ -726,7 +761,7 @@ def measure_c5(args, rank, local_rank, world):
                         for item in batches)
         t_outs = [item['t_out'] for item in batches]
         arith = model.arithmetic()
-        bwd_f16 = bool(model.rnn_bwd_f16 and arith.get('rnn0/recurrence_fwd') == 'fp16x3')
+        bwd_f16 = arith.get('rnn0/recurrence_bwd') == 'fp16x3'
         bwd_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if bwd_f16 else FP32_MFMA_PEAK_TFLOPS
         result = {
             'metric': 'audio-seconds/s training throughput (DS2, mixed-length bucketed batches '
@@ -775,7 +810,8 @@ def measure_c5(args, rank, local_rank, world):
                 'frac_of_fp32_mfma_peak':
                     round(rnn_flops / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
                     if bwd_ms else None,
-                'traffic': None, 'launches': bwd_calls,
+                'launches': bwd_calls,
+                'mean_time_steps_per_launch': round(sum(t_outs) * layers / max(bwd_calls, 1), 2),
                 'avg_launch_us': round(bwd_ms * 1e3 / max(bwd_calls, 1), 1),
                 'cus_occupied': 128,
                 'other_pass': {'kernel': 'prnn_fwd{}_kernel'.format(
@@ -784,6 +820,10 @@ def measure_c5(args, rank, local_rank, world):
                                'achieved': round(rnn_flops / (fwd_ms * 1e-3) / 1e12, 2)
                                if fwd_ms else None}},
         }
+    if result is not None and 'mean_time_steps_per_launch' in result.get('roofline', {}):
+        # (PMC passes over this very bucket sequence: mean bytes per launch, mean steps per launch)
+        result['roofline'].update(pmc_traffic('c5', 'rnn_bwd',
+                                              result['roofline']['mean_time_steps_per_launch']))
     del trainer, model
     torch.cuda.empty_cache()
     return result

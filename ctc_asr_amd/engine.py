@@ -237,6 +237,7 @@ class Trainer:
         # run-ahead above also holds for real training, not only for the benchmark.
         self.rnn_poll_every = 50
         self._pending_status = collections.deque()
+        self._skipped = None
         self._steps_since_poll = 0
 
     def _check_finished_steps(self, wait=False):
@@ -313,12 +314,25 @@ class Trainer:
             copied.record(torch.cuda.current_stream(self.model.device))
             self._pending_status.append((copied, host, self.model.step_count + 1))
         self.reducer.finish(guard)      # (N > 1: the guard words become their maxima over ranks)
+        # (how many updates the device has dropped so far: `skipped_step_count()` - a run whose
+        # steps were silently skipped must not be reported as throughput)
+        if self._skipped is None:
+            self._skipped = torch.zeros(1, dtype=torch.int32, device=self.model.device)
+        self._skipped += (guard[:1] != 0).to(torch.int32)
         self.model.apply_gradients(self.lr, self.beta1, self.beta2, self.eps,
                                    grad_scale=1.0 / self.world, skip=guard)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.model.device))
         self._step_done.append(done)
         return loss
+
+    def skipped_step_count(self):
+        """Training steps whose update the device dropped (guard word set: CTC status, non-finite
+        loss, recurrence time-out) since this trainer was built; synchronises.  The step counter
+        of Adam's bias correction advances for such a step as well (TensorFlow's global step
+        would not): one extra power of beta per dropped step, and a dropped step always raises
+        at the next check of `train_step(check=True)` / `drain_checks()`."""
+        return 0 if self._skipped is None else int(self._skipped.item())
 
     def global_mean(self, value):
         """Average a device scalar over ranks (logged loss, eval metrics)."""

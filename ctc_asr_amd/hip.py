@@ -126,7 +126,7 @@ _lib = None
 # Optional per-entry-point timing: set ``EVENTS = {}`` and every wrapped call listed in
 # ``TIMED`` is bracketed by HIP events on the launch stream (``drain_events`` returns ms sums).
 EVENTS = None
-TIMED = ('rnn_fwd', 'rnn_bwd', 'ctc_loss_fwd_bwd')
+TIMED = ('rnn_fwd', 'rnn_bwd', 'ctc_loss_fwd_bwd', 'dgrad16')
 
 
 class _Timed:
@@ -741,10 +741,11 @@ def dgrad16_blockscaled(workspace, num_steps, batch, hidden, packed, scale, n, o
         raise CtcAsrError('dgrad16_blockscaled: out must be an f32 [T * B, n] view with unit '
                           'column stride.')
     t_lo, t_hi = (0, num_steps) if steps is None else steps
-    _check(load().ctcasr_dgrad16_blockscaled(
-        workspace.data_ptr(), int(num_steps), int(batch), int(hidden), packed.data_ptr(),
-        float(scale), int(n), out.data_ptr(), out.stride(0), int(t_lo), int(t_hi), int(dirs[0]),
-        int(dirs[1]), int(accumulate), _stream()), 'dgrad16_blockscaled')
+    with _Timed('dgrad16'):
+        _check(load().ctcasr_dgrad16_blockscaled(
+            workspace.data_ptr(), int(num_steps), int(batch), int(hidden), packed.data_ptr(),
+            float(scale), int(n), out.data_ptr(), out.stride(0), int(t_lo), int(t_hi),
+            int(dirs[0]), int(dirs[1]), int(accumulate), _stream()), 'dgrad16_blockscaled')
     return out
 
 

@@ -62,7 +62,9 @@ def main(src, workload, out_md):
     fetch, write, sq = pmc_rows(read('fetch.md')), pmc_rows(read('write.md')), pmc_rows(read('sq.md'))
     filters, layers, hidden, dense, batch, seconds, cell = bench.WORKLOADS[workload]
     gates = {'lstm': 4, 'gru': 3}.get(cell, 1)
-    t_out = line['config']['ctc_steps']
+    # (c5: a bucket sequence - mean steps per launch of the backward pass, two launches per layer)
+    t_out = line['config'].get('ctc_steps') or \
+        round(2 * line['roofline']['mean_time_steps_per_launch'])
     timeline = [l for l in read('timeline.txt').splitlines()
                 if not any(k in l for k in ('elementwise_kernel', 'copyBuffer', 'SubTensor',
                                             'batched_transpose', 'vectorized_elementwise',
@@ -78,8 +80,11 @@ def main(src, workload, out_md):
         # launches per layer-pass as the model cuts them (bench's own roofline for the dominant
         # pass, the model defaults for the other)
         dominant = line['roofline']['kernel'].startswith('prnn_' + which[4:])
-        steps = round(line['roofline']['algorithmic_flops_per_launch'] /
-                      (2.0 * 2 * batch * hidden * gates * hidden)) if dominant else t_out
+        if 'mean_time_steps_per_launch' in line['roofline']:
+            steps = line['roofline']['mean_time_steps_per_launch'] * (1 if dominant else 2)
+        else:
+            steps = round(line['roofline']['algorithmic_flops_per_launch'] /
+                          (2.0 * 2 * batch * hidden * gates * hidden)) if dominant else t_out
         alg = algorithmic_bytes(which, batch, hidden, gates, steps)
         busy = value(sq, kernel, 'SQ_VALU_MFMA_BUSY_CYCLES')
         gui = value(sq, kernel, 'GRBM_GUI_ACTIVE')

@@ -1223,16 +1223,22 @@ def main():
     if world == 1 and args.collective_stand_in and args.workload != 'c5':
         # one GPU cannot run RCCL beside itself; its CU footprint can be stood in for
         report = {'stand_in': '24 workgroups x 256 threads per bucket, resident for bytes / '
-                              '150 GB/s, own stream, waited for like an async all-reduce',
+                              '150 GB/s, own stream, waited for like an async all-reduce; '
+                              '`*_traffic`: the same workgroups stream 6 x the bucket\'s bytes '
+                              'through L2 / fabric / HBM meanwhile (a ring all-reduce\'s reads and '
+                              'writes: ctcasr_collective_traffic)',
                   'plain_ms_per_step': result['ms_per_step']}
-        for mode in ('held', 'early'):
+        for mode in ('held', 'early', 'held_traffic', 'early_traffic'):
             try:
                 leg, _ = measure(args.workload, args, rank, local_rank, world,
-                                 allreduce_early=(mode == 'early'), stand_in=(24, 150.0))
+                                 allreduce_early=mode.startswith('early'),
+                                 stand_in=(24, 150.0, mode.endswith('traffic')))
                 report[mode] = {'ms_per_step': leg['ms_per_step'],
                                 'inflation_ms': round(leg['ms_per_step'] - result['ms_per_step'], 3),
                                 'inflation_frac': round(leg['ms_per_step'] / result['ms_per_step']
-                                                        - 1.0, 4)}
+                                                        - 1.0, 4),
+                                'backward_recurrence_us_per_time_step':
+                                    leg['roofline'].get('us_per_time_step')}
             except Exception as err:        # noqa: BLE001 - a time-out is the finding
                 report[mode] = {'error': '{}: {}'.format(type(err).__name__, err)}
         result['collective_stand_in'] = report

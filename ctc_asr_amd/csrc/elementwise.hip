@@ -216,6 +216,31 @@ __global__ void __launch_bounds__(256) occupy_kernel(unsigned long long busy_tic
     while (wall_clock64() - start < busy_ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// ... and with a ring all-reduce's memory traffic as well: the workgroups stream `total4` float4
+// sums a[i] += b[i] through a scratch pair (16 B read twice, written once per element), paced so
+// that the whole launch takes `busy_ticks` - resident like a collective's ring kernels, but loading
+// the L2s, the fabric and HBM the way a reduce-scatter + all-gather over the payload does.
+__global__ void __launch_bounds__(256) collective_traffic_kernel(float4 *a, const float4 *b,
+                                                                 long long n4, long long total4,
+                                                                 unsigned long long busy_ticks) {
+    const unsigned long long start = wall_clock64();
+    const long long share = total4 / gridDim.x;
+    const long long first = (long long)blockIdx.x * share;
+    constexpr long long SLAB = 256 * 16;                // float4 per pacing slab (64 KB)
+    for (long long base = 0; base < share; base += SLAB) {
+#pragma unroll 4
+        for (long long i = base + threadIdx.x; i < min(base + SLAB, share); i += 256) {
+            const long long idx = (first + i) % n4;
+            const float4 x = a[idx], y = b[idx];
+            a[idx] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        }
+        const unsigned long long due = (unsigned long long)(
+            (double)busy_ticks * (double)(base + SLAB) / (double)share);
+        while (wall_clock64() - start < due) __builtin_amdgcn_s_sleep(8);
+    }
+    while (wall_clock64() - start < busy_ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 int grid_for(int64_t work_items) {
     int64_t blocks = (work_items + 255) / 256;
     if (blocks > 2048) blocks = 2048;   // 256 CUs x 8, grid-stride the rest
@@ -327,6 +352,21 @@ extern "C" int ctcasr_occupy_cus(int workgroups, int busy_us, ctcasr_stream_t st
     if (workgroups < 1 || workgroups > 256 || busy_us < 0 || busy_us > 100000)
         return CTCASR_ERR_BAD_ARGUMENT;
     occupy_kernel<<<workgroups, 256, 0, (hipStream_t)stream>>>((unsigned long long)busy_us * 100ull);
+    return ctcasr_launch_status();
+}
+
+extern "C" int ctcasr_collective_traffic(int workgroups, int busy_us, float *a, const float *b,
+                                         int64_t scratch_floats, int64_t payload_bytes,
+                                         ctcasr_stream_t stream) {
+    if (workgroups < 1 || workgroups > 256 || busy_us < 0 || busy_us > 100000 || !a || !b ||
+        scratch_floats < 1024 || scratch_floats % 4 != 0 || payload_bytes < 0 ||
+        (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 != 0)
+        return CTCASR_ERR_BAD_ARGUMENT;
+    // two phases (reduce-scatter, all-gather), each one pass over the payload
+    const long long total4 = 2 * (payload_bytes / 16);
+    collective_traffic_kernel<<<workgroups, 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<float4 *>(a), reinterpret_cast<const float4 *>(b), scratch_floats / 4,
+        total4, (unsigned long long)busy_us * 100ull);
     return ctcasr_launch_status();
 }
 

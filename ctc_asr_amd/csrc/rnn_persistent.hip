@@ -338,6 +338,16 @@ __device__ __forceinline__ void resident_signal(SyncWords *sy, unsigned ticket) 
     }
 }
 
+// A time-out word that is already set when a launch starts (sticky until the host polls it): every
+// result since is invalid anyway - the workgroup leaves at once instead of running its steps with
+// waits that each give up only after another 1024 polls (a release mode that
+// wedges one barrier at N > 1 must not turn the rest of a benchmark leg into minutes of spinning).
+// Workgroups of the SAME launch that are already waiting for this one time out within 1024 polls
+// per step, as before.
+__device__ __forceinline__ bool launch_poisoned(SyncWords *sy) {
+    return __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+
 __global__ void resident_gate_kernel(SyncWords *sy, unsigned ticket, unsigned long long ticks) {
     const unsigned long long start = wall_clock64();
     for (;;) {
@@ -375,6 +385,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_fwd_kernel(PArgs p
     constexpr int ITEMS = (16 * MT * UPB + PRNN_THREADS - 1) / PRNN_THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
     float4 *frag = reinterpret_cast<float4 *>(smem);
     constexpr int RED_FLOATS = 4 * NT * MT * 16 * 17;
     // chain = batch tile with its own barrier (CHAINS = 2: waves 0-3 / 4-7); `tid` and `wave`
@@ -798,6 +809,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
     static_assert(16 * UPB <= PRNN_THREADS, "one item per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
     u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
     float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(u32x4));
     float *wave_top = red + 4 * NT * 16 * 17;
@@ -1110,6 +1122,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_kernel(PArgs p
     static_assert(!TWO_TILES || (G == 1 && REGW > 0), "two tiles: plain RNN, static slot map");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
     float4 *frag = reinterpret_cast<float4 *>(smem);
     constexpr int RED_FLOATS = 4 * NT * MT * 16 * 17;
     // chain = batch tile with its own barrier (see ChainSync); `tid` / `wave` count within it
@@ -1532,6 +1545,7 @@ __global__ void __launch_bounds__(PRNN_THREADS * CHAINS) prnn_bwd_rs_kernel(PArg
     constexpr int RED_FLOATS = 4 * 16 * 17, A_FLOATS = 16 * PRNN_RS_APITCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
     float4 *frag = reinterpret_cast<float4 *>(smem);
     const int chain =
         CHAINS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / PRNN_THREADS)
@@ -1806,6 +1820,7 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
     constexpr int DD = D < NPW ? D : NPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
     u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
     float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 64 * sizeof(u32x4));
     constexpr int IVL = 4 * NPW;            // float4 slots of a wave's inverse scales per tile

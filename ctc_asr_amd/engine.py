@@ -67,6 +67,7 @@ class GradientReducer:
         # `force`.  Gradients are left alone (a one-rank sum).
         self.stand_in = stand_in
         self._stand_in_stream = None
+        self._stand_in_scratch = None
         # `force`: run the collectives even with a single rank (a world-size-1 process group is
         # legal): tests use it to put the real backend (RCCL) under the real backward pass on a
         # one-GPU box
@@ -144,15 +145,25 @@ class GradientReducer:
         collective runs on the backend's own stream behind everything enqueued so far on the
         launching stream; `wait()` makes the then-current stream wait for it."""
         from ctc_asr_amd import hip
-        workgroups, gb_per_s = self.stand_in
+        workgroups, gb_per_s = self.stand_in[:2]
+        traffic = len(self.stand_in) > 2 and bool(self.stand_in[2])
         device = self.grad.device
+        if traffic and self._stand_in_scratch is None:
+            # (zeros: a += b stays zero however often it runs)
+            self._stand_in_scratch = tuple(torch.zeros(16 << 20, dtype=torch.float32,
+                                                       device=device) for _ in range(2))
         if self._stand_in_stream is None:
             self._stand_in_stream = torch.cuda.Stream(device)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(device))
         with torch.cuda.stream(self._stand_in_stream):
             self._stand_in_stream.wait_event(ready)
-            hip.occupy_cus(workgroups, max(1, int(nbytes / (gb_per_s * 1e3))))
+            busy_us = max(1, int(nbytes / (gb_per_s * 1e3)))
+            if traffic:
+                hip.collective_traffic(self._stand_in_scratch[0], self._stand_in_scratch[1],
+                                       workgroups, busy_us, nbytes)
+            else:
+                hip.occupy_cus(workgroups, busy_us)
             done = torch.cuda.Event()
             done.record(self._stand_in_stream)
 

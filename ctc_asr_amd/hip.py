@@ -102,6 +102,7 @@ SIGNATURES = {
                                       _c_int, _c_p]),
     'ctcasr_gemm_split_tn': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
                                       _c_int, _c_p]),
+    'ctcasr_collective_traffic': (_c_int, [_c_int, _c_int, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     'ctcasr_dgrad16_packed_bytes': (_c_sz, [_c_int]),
     'ctcasr_dgrad16_pack_weights': (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_f, _c_p, _c_p]),
     'ctcasr_dgrad16_supported': (_c_int, [_c_int] * 4),
@@ -1091,6 +1092,16 @@ def occupy_cus(workgroups, busy_us):
     """Diagnostic: `workgroups` workgroups hold their CUs for `busy_us` on the current stream (the
     CU footprint of a collective's ring kernels; `engine.GradientReducer(stand_in=...)`)."""
     _check(load().ctcasr_occupy_cus(int(workgroups), int(busy_us), _stream()), 'occupy_cus')
+
+
+@_on_tensor_device
+def collective_traffic(scratch_a, scratch_b, workgroups, busy_us, payload_bytes):
+    """Diagnostic: `occupy_cus` with a ring all-reduce's memory traffic - 2 x payload_bytes of
+    a[i] += b[i] streamed through the scratch pair, paced over busy_us (include/ctcasr.h)."""
+    _check(load().ctcasr_collective_traffic(
+        int(workgroups), int(busy_us), _dev(scratch_a, name='scratch_a'),
+        _dev(scratch_b, name='scratch_b'), scratch_a.numel(), int(payload_bytes), _stream()),
+        'collective_traffic')
 
 
 @_on_tensor_device

@@ -511,6 +511,14 @@ size_t ctcasr_rnn_timeout_word_offset(int cell, int T, int B, int H, int block);
  * measuring on ONE GPU what such kernels cost beside the persistent recurrences (NCCL / RCCL
  * refuse two ranks on one device).  Not used by the training path. */
 int ctcasr_occupy_cus(int workgroups, int busy_us, ctcasr_stream_t stream);
+/* DIAGNOSTIC (ABI v6): the same footprint WITH a ring all-reduce's memory traffic - the workgroups
+ * stream 2 x payload_bytes of a[i] += b[i] (16-byte elements, read twice and written once: 6 x
+ * payload_bytes over L2 / fabric / HBM) through the scratch pair a, b (scratch_floats each, 16-byte
+ * aligned), paced over busy_us: what a reduce-scatter + all-gather of the payload does to the
+ * memory system beside the persistent recurrences and the library GEMMs.  Not used by training. */
+int ctcasr_collective_traffic(int workgroups, int busy_us, float *a, const float *b,
+                              int64_t scratch_floats, int64_t payload_bytes,
+                              ctcasr_stream_t stream);
 /* max_bits[0] = max(max_bits[0], bit pattern of max |x[i]|) (atomicMax; the caller zeroes it):
  * range guard of operands that go to the fp16 matrix pipe under a FIXED scale (the input
  * projections' weights, split_gemm.py) */

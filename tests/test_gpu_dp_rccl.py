@@ -227,8 +227,9 @@ def test_bench_two_ranks_on_one_gpu_report_both_release_modes():
     assert line['allreduce']['stubbed_ms_per_step'] > 0
 
 
+@pytest.mark.parametrize('traffic', [False, True])
 @pytest.mark.parametrize('early', [False, True])
-def test_collective_shaped_kernels_beside_the_persistent_recurrences(early):
+def test_collective_shaped_kernels_beside_the_persistent_recurrences(early, traffic):
     """The first N > 1 run must not be the first time resident, non-yielding workgroups share
     the chip with the persistent recurrences.  NCCL refuses two ranks on one
     device, so the stand-in: every gradient bucket launches a kernel of 24 workgroups that holds
@@ -238,7 +239,10 @@ def test_collective_shaped_kernels_beside_the_persistent_recurrences(early):
     whole-chip forward recurrence (held).  DS2 2 x BiLSTM-1024 at batch 32 (the two-tile kernels):
     no recurrence time-out, the losses of the plain run bit for bit (nothing touches the
     gradients), several launches per step; the step-time inflation is printed (DESIGN.md 6 quotes
-    bench.py --collective-stand-in for the C3 figure)."""
+    bench.py --collective-stand-in for the C3 figure).  ``traffic`` (round 5): the resident
+    workgroups also stream 6 x the bucket's bytes through L2 / fabric / HBM meanwhile
+    (`ctcasr_collective_traffic`) - a ring all-reduce's memory side beside the recurrences' exchange
+    and beside the library's stream-K weight-gradient GEMMs (early mode runs next to both)."""
     from ctc_asr_amd.engine import Trainer
     from ctc_asr_amd.model import CTCModel, ModelConfig
     cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
@@ -266,11 +270,12 @@ def test_collective_shaped_kernels_beside_the_persistent_recurrences(early):
         return torch.stack(losses).cpu().numpy(), ms, trainer.reducer.launched
 
     plain, plain_ms, launched0 = run(None)
-    busy, busy_ms, launched = run((24, 150.0))
+    busy, busy_ms, launched = run((24, 150.0, traffic))
     assert launched0 == 0 and launched >= 8 * 2
     assert np.isfinite(busy).all()
     # (the step itself is deterministic to fp32 summation order only: atomics in the CTC gradient)
     assert np.abs(busy - plain).max() < 1e-4 * np.abs(plain).max()
-    print('collective stand-in, {} release: {:.2f} -> {:.2f} ms per step ({} launches)'.format(
-        'early' if early else 'held', plain_ms, busy_ms, launched))
+    print('collective stand-in{}, {} release: {:.2f} -> {:.2f} ms per step ({} launches)'.format(
+        ' with memory traffic' if traffic else '', 'early' if early else 'held', plain_ms,
+        busy_ms, launched))
     assert busy_ms < plain_ms * 1.5

@@ -1025,3 +1025,38 @@ def test_reduce_scatter_backward_equals_the_all_gather_kernels(hip, batch, lengt
                     steps=(lo, hi), flags=hip.RNN_REDUCE_SCATTER)
     hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
     assert torch.equal(cut, got)
+
+
+@pytest.mark.parametrize('flags', ['RNN_DEFAULT', 'RNN_F16'])
+def test_a_set_time_out_word_ends_every_later_launch_at_once(hip, flags):
+    """The persistent kernels' time-out word is sticky until the host polls it.  A launch that
+    finds it set returns immediately (round 5): whatever it would compute is invalid anyway, and a
+    wedged barrier at N > 1 must not turn the rest of a benchmark leg into minutes of bounded
+    spinning.  The poll reports the time-out, clears the word, and the next launch is whole."""
+    import time
+    num_steps, batch, hidden = 300, 16, 1024
+    flags = getattr(hip, flags)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xw = torch.randn(num_steps, batch, 2, 4 * hidden, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, 4 * hidden, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g)
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh, flags=flags)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    address = hip.rnn_timeout_words('lstm', ws, num_steps, batch, hidden)[0]
+    offset = address - ws.data_ptr()
+    ws[offset:offset + 4].view(torch.int32).fill_(1)
+    w_hh_t = hip.transpose_batched(w_hh)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y2 = torch.full_like(y, 7.0)
+    hip.rnn_fwd('lstm', xw, w_hh, y=y2, reserve=reserve.clone(), workspace=ws, flags=flags)
+    dxw = torch.full((num_steps, batch, 2, 4 * hidden), 7.0, device=DEV)
+    hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, dxw=dxw, workspace=ws, flags=flags)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05          # (a whole pass takes ~1 ms per 300 steps)
+    assert bool((y2 == 7.0).all()) and bool((dxw == 7.0).all())      # nothing ran
+    with pytest.raises(hip.CtcAsrError, match='time'):
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    y3, _, _ = hip.rnn_fwd('lstm', xw, w_hh, workspace=ws, flags=flags)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    assert torch.equal(y3, y)

@@ -89,8 +89,10 @@ def dtype_label(model):
         return 'f32' if not rec else 'f32 tensors / accumulate / GEMMs' + rec
     gemms = 'bf16x6 split (24 significand bits)'
     if model.fwd_f16:
-        gemms = 'fp16x3 split (22 significand bits) where the layer input is bounded - {} - ' \
+        gemms = 'fp16x3 split (22 significand bits) where the layer input is bounded{} - {} - ' \
                 'bf16x6 split (24 bits) elsewhere'.format(
+                    ' or, behind a ReLU cell, scaled per row / per column on the device'
+                    if getattr(model, 'unbounded_f16', False) else '',
                     'forward projections and their gradient GEMMs' if model.bwd_f16
                     else 'forward projections')
     return 'f32 tensors / accumulate / own kernels; projection GEMMs: ' + gemms + rec
@@ -126,7 +128,7 @@ def forward_flops_per_utt(cfg, frames):
 
 
 def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f16=True,
-               bwd_f16=True, rec_f16=(False, False), conv_f16=False):
+               bwd_f16=True, rec_f16=(False, False), conv_f16=False, unbounded_f16=False):
     """Time one step would take with every FLOP at the peak of the pipe it runs on: the fp32
     matrix pipe (157.3 TF) for the own kernels; for the split GEMMs the 16-bit matrix pipe
     (2500 TF) divided by the products per fp32 product - three fp16 products where the layer's
@@ -141,7 +143,7 @@ def mixed_roof(cfg, frames, utterances, ms_per_step, split_gemm, world=1, fwd_f1
     rec = 2.0 * t_out * 2 * GATES[cfg.cell] * cfg.num_units_rnn ** 2 * cfg.num_layers_rnn
     dense4 = 2.0 * t_out * 2 * cfg.num_units_rnn * cfg.num_units_dense
     three = 0.0
-    if split_gemm and fwd_f16 and cfg.cell != 'rnn_relu':
+    if split_gemm and fwd_f16 and (cfg.cell != 'rnn_relu' or unbounded_f16):
         three = (split - rec) / 3.0                       # the forward products
         if bwd_f16:
             three = split - dense4            # + every gradient GEMM but dense4's kernel gradient
@@ -577,7 +579,8 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                                model.fwd_f16, model.bwd_f16,
                                (model.arithmetic().get('rnn0/recurrence_fwd') == 'fp16x3',
                                 model.arithmetic().get('rnn0/recurrence_bwd') == 'fp16x3'),
-                               conv_f16=model.arithmetic().get('conv0/forward') == 'fp16x3'),
+                               conv_f16=model.arithmetic().get('conv0/forward') == 'fp16x3',
+                               unbounded_f16=model.unbounded_f16),
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 3) for k, v in events.items()},
             # time the host needed to enqueue a step; close to ms_per_step = launch-bound
             'host_enqueue_ms_per_step': round(issued / args.steps * 1e3, 3),

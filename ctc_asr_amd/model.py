@@ -322,6 +322,7 @@ class _WeightPieces:
         self.model, self.name, self.matrix, self.training = model, name, matrix, training
         self.fwd16 = self.tr16 = None
         self.dg16 = None        # packed for `hip.dgrad16_blockscaled` (instead of ``tr16``)
+        self.rows_form = False  # fp16 pieces for an UNBOUNDED input (scales per row / column)
         self._fwd = self._tr = None
 
     def make_fwd(self, out=None):
@@ -439,6 +440,11 @@ class CTCModel:
         # split of dxw, no library GEMM on the main stream - and so no "one library GEMM at a
         # time" wait for the side stream in front of it
         self.own_dgrad = os.environ.get('CTCASR_OWN_DGRAD', '1') == '1'
+        # layers whose input has no bound (behind a ReLU-cell layer: the reference's default model)
+        # in an fp16 form as well - the input split with a scale per ROW for the projection (as a
+        # layer's dxw is for the data gradient), per COLUMN for the weight gradients
+        # (`split_gemm.mm_rows16`, `ColScaled`) - instead of the bf16 form's six products
+        self.unbounded_f16 = os.environ.get('CTCASR_UNBOUNDED_F16', '1') == '1'
         # ... and, being no library kernel, in halves: a finished launch of the backward recurrence
         # has published one direction's dgates for its range of time steps - that direction's share
         # of dx (half of the K axis) is multiplied beside the next launch ('side': on the side
@@ -572,9 +578,14 @@ class CTCModel:
             views = [w for _, _, w in jobs] + ([k4] if dense4 else [])
             in_range = self._weights_in_f16_range(names, views, side)
 
+        def rows_form(layer, name):
+            # no bound on the input: fp16 pieces under scales found on the device (ReLU cells)
+            return (self.fwd_f16 and self.unbounded_f16 and in_range.get(name, False) and
+                    bounds[layer] is None)
+
         def f16_form(layer, name):
             return (self.fwd_f16 and in_range.get(name, False) and
-                    split_gemm.f16_scale(bounds[layer]) is not None)
+                    split_gemm.f16_scale(bounds[layer]) is not None) or rows_form(layer, name)
 
         def buf(key, make):
             if key not in bufs:
@@ -595,6 +606,7 @@ class CTCModel:
             for i, name, w_ih in jobs:
                 cols = w_ih.shape[1]
                 pieces = _WeightPieces(self, name, w_ih, training)
+                pieces.rows_form = rows_form(i, name)
                 if f16_form(i, name):
                     pieces.fwd16 = split_gemm.split16(
                         w_ih, split_gemm.W_SCALE, split_gemm.H_B,
@@ -629,6 +641,7 @@ class CTCModel:
                 self._w_split[name] = pieces
             if dense4:
                 pieces = _WeightPieces(self, 'dense4', k4, training)
+                pieces.rows_form = rows_form(cfg.num_layers_rnn, 'dense4')
                 if dense4_f16:
                     stacked16 = buf('dense4/f16', lambda: torch.empty(
                         (3,) + tuple(k4.shape), dtype=torch.float16, device=self.device))
@@ -837,7 +850,14 @@ class CTCModel:
             elif self._weight_split('rnn{}'.format(i)) is not None:
                 w_pieces = self._weight_split('rnn{}'.format(i))
                 scale = split_gemm.f16_scale(in_bound) if w_pieces[2] is not None else None
-                if scale is not None:
+                if scale is None and w_pieces[2] is not None and w_pieces.rows_form:
+                    # no bound (behind a ReLU cell): a scale per row for this product, per column
+                    # (made in the backward pass, on the side stream) for the weight gradients
+                    x2d = x.view(t_out * batch, -1)
+                    xw = split_gemm.mm_rows16(x2d, w_pieces[2], split_gemm.W_SCALE)
+                    pieces16 = split_gemm.ColScaled(x2d)
+                    form = 'fp16x3 (row / column scales)'
+                elif scale is not None:
                     # bounded input: two fp16 pieces, three products (the bf16 pieces the weight
                     # gradients want are made in the backward pass, on the side stream); the
                     # pieces of a recurrent layer's output come out of its fp16-pipe forward
@@ -904,7 +924,15 @@ class CTCModel:
         acts['flat16'] = None
         flat_scale = split_gemm.f16_scale(in_bound) \
             if k4_pieces is not None and k4_pieces[2] is not None else None
-        if flat_scale is not None:
+        if flat_scale is None and k4_pieces is not None and k4_pieces[2] is not None and \
+                k4_pieces.rows_form:
+            acts['flat16'] = split_gemm.ColScaled(rnn_flat)
+            dense4 = split_gemm.mm_rows16(rnn_flat, k4_pieces[2], split_gemm.W_SCALE,
+                                          stacked=True)
+            arithmetic['dense4'] = 'fp16x3 (row / column scales)'
+            hip.bias_act_fwd(dense4, p['dense4/bias'], cfg.relu_cutoff,
+                             cfg.dense_dropout_rate if training else 0.0, self._next_seed())
+        elif flat_scale is not None:
             # bounded input (the recurrent stack's output): fp16 pieces, three products
             if y16_of is not None and y16_of[0] is x and y16_of[2] == flat_scale:
                 flat16 = y16_of[1]
@@ -1310,7 +1338,8 @@ class CTCModel:
 
             side_tensors = [dxw] + [t.buf for t in (ds, drs, acts['in_split'][i],
                                                     acts['flat_split']) if t is not None] + \
-                [t[0].buf for t in (x16, y16) if t is not None]
+                [t[0].buf for t in (x16, y16)
+                 if t is not None and not isinstance(t, split_gemm.ColScaled)]
 
             def split_steps(lo, hi, ds=ds, drs=drs, dxw2d=dxw2d, drec=drec):
                 # pieces of dxw (GRU: and drec) for steps [lo, hi) of both directions
@@ -1331,7 +1360,8 @@ class CTCModel:
                     d16, inv = split_gemm.wgrad16_operand(
                         dxw2d[a * batch:b * batch, cols],
                         None if colmax is None else colmax[d * gh:(d + 1) * gh])
-                    split_gemm.wgrad16(g[name + '/w_ih'][d], d16, inv, x16[0], x16[1], a * batch)
+                    split_gemm.wgrad16(g[name + '/w_ih'][d], d16, inv, x16[0], x16[1], a * batch,
+                                       x_col_inv=getattr(x16, 'col_inv', None))
                     if d == 0:
                         a2, b2, shift, hcols = max(a, 1), b, -1, slice(0, hidden)
                     else:
@@ -1343,7 +1373,8 @@ class CTCModel:
                             drec.view(rows, 2 * gh)[a * batch:b * batch, cols])
                     split_gemm.wgrad16(g[name + '/w_hh'][d], d16, inv, y16[0], y16[1],
                                        (a2 + shift) * batch, x_cols=hcols,
-                                       d_rows=slice((a2 - a) * batch, (b2 - a) * batch))
+                                       d_rows=slice((a2 - a) * batch, (b2 - a) * batch),
+                                       x_col_inv=getattr(y16, 'col_inv', None))
 
             def partial_weight_grads(lo, hi, name=name, x=x, y=y, dxw=dxw, drec=drec,
                                      ds=ds if self.split_wgrad else None, drs=drs,

@@ -206,7 +206,40 @@ def wgrad16_operand(d2d, colmax=None):
     return hip.split_f16_cols(d2d, scale, 1.0, H_B), inv
 
 
-def wgrad16(out, d16, inv, x16, x_scale, x_lo, x_cols=slice(None), d_rows=slice(None)):
+class ColScaled:
+    """fp16 pieces of an UNBOUNDED matrix x [rows, cols] (the output of a ReLU-cell layer) for the
+    weight-gradient products over its ROW axis: a power of two per COLUMN - x's column is the
+    product's output column, the scale comes back out of it - found on the device and applied on
+    first use, on whatever stream is current then (the weight gradients' side stream).  Quacks like
+    the (pieces, scale) pair of a bounded input: [0] the pieces, [1] their common scale (1),
+    `col_inv` the inverse column scales."""
+
+    def __init__(self, x2d):
+        self.x2d, self._pieces, self.col_inv = x2d, None, None
+
+    def __getitem__(self, index):
+        if index == 1:
+            return 1.0
+        if self._pieces is None:
+            scale, self.col_inv = hip.colmax_scale(self.x2d)
+            self._pieces = Split(hip.split_f16_cols(self.x2d, scale, 1.0, H_A), H_A)
+        return self._pieces
+
+
+def mm_rows16(x2d, w16, w_scale, stacked=False):
+    """x [R, K] . W^T for an UNBOUNDED x: x split with one scale per ROW found on the fly
+    (`hip.split_f16_rows`, like a layer's dxw), one fp16 GEMM over 3 K against the fixed-scale
+    pieces of W ([N, 3, K] `split16(.., H_B)`, or ``stacked`` [3 K, N] for a product x K), the row
+    scales and 1 / w_scale taken back out in place."""
+    d16, inv = hip.split_f16_rows(x2d, H_A)
+    rows, _, k = d16.shape
+    rhs = w16 if stacked else w16.concat().t()
+    tmp = torch.mm(d16.view(rows, 3 * k), rhs, out_dtype=F32)
+    return hip.rescale_rows(tmp, inv, 1.0 / w_scale, tmp, accumulate=False)
+
+
+def wgrad16(out, d16, inv, x16, x_scale, x_lo, x_cols=slice(None), d_rows=slice(None),
+            x_col_inv=None):
     """out[M, N] += D^T X for D = the rows ``d_rows`` of the block whose pieces are ``d16`` (from
     `wgrad16_operand`) and X = rows [x_lo, x_lo + len) x ``x_cols`` of the operand whose forward
     pieces are ``x16`` (split16(..., x_scale, H_A)): one fp16 GEMM over 3 x rows, then the
@@ -216,6 +249,8 @@ def wgrad16(out, d16, inv, x16, x_scale, x_lo, x_cols=slice(None), d_rows=slice(
     lhs = d16.reshape(rows * 3, m).t()
     rhs = x16.buf.view(x16.rows * 3, x16.cols)[3 * x_lo:3 * (x_lo + rows), x_cols]
     tmp = torch.mm(lhs, rhs, out_dtype=F32)
+    if x_col_inv is not None:           # (x scaled per column: `ColScaled`)
+        tmp.mul_(x_col_inv[x_cols].view(1, -1))
     return hip.rescale_rows(tmp, inv, 1.0 / x_scale, out, accumulate=True)
 
 

@@ -329,3 +329,50 @@ def test_scaled_fp16_splits_and_the_gradient_products(hip):
     # gate units the rows come out at ~2.4 x the fp32 GEMM's (tiny) error
     assert float(s_err.max()) < 2e-5 and float(s_err.mean()) <= 3.0 * float(p_err.mean()) + 1e-8
     assert float(dx[17].abs().max()) == 0.0
+
+
+def test_fp16_forms_of_an_unbounded_operand(hip):
+    """Layers behind a ReLU cell (the reference's default model, asr/params.py:43-50) have inputs
+    without a bound: the projection x W^T takes x with a scale per ROW found on the device
+    (`split_gemm.mm_rows16`), the weight gradients d^T x take x with a scale per COLUMN
+    (`split_gemm.ColScaled`) - both against float64 next to the library's fp32 GEMM, on an x whose
+    rows span six decades and whose columns span four, with outliers in the thousands."""
+    from ctc_asr_amd import split_gemm
+    g = torch.Generator(device='cuda').manual_seed(9)
+    rows, k, n = 4096, 2048, 1536
+    x = torch.randn(rows, k, device='cuda', generator=g).abs()
+    x *= torch.logspace(-3, 3, rows, device='cuda').view(-1, 1)
+    x *= torch.logspace(-2, 2, k, device='cuda')[torch.randperm(k, device='cuda', generator=g)]
+    x[7, 5], x[100, 2000] = 9000.0, 3.0e4
+    w = torch.randn(n, k, device='cuda', generator=g) / np.sqrt(k)
+    w16 = split_gemm.split16(w, split_gemm.W_SCALE, split_gemm.H_B)
+    got = split_gemm.mm_rows16(x, w16, split_gemm.W_SCALE)
+    ref = x.double() @ w.double().t()
+    lib = torch.mm(x, w.t())
+    err = lambda a: float(((a.double() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max())
+    assert torch.isfinite(got).all() and err(got) < 3.0 * err(lib) + 1e-7, (err(got), err(lib))
+    # the same product with W's pieces stacked along its rows (dense4: x K)
+    stacked = split_gemm.split16_rows_stacked(w.t().contiguous(), split_gemm.W_SCALE,
+                                              split_gemm.H_B)
+    got_s = split_gemm.mm_rows16(x, stacked, split_gemm.W_SCALE, stacked=True)
+    assert err(got_s) < 3.0 * err(lib) + 1e-7
+    # weight gradient: d [rows, m] (scaled per column like a layer's dxw) against the unbounded x
+    m = 1024
+    d = torch.randn(rows, m, device='cuda', generator=g) * \
+        torch.logspace(-9, -3, m, device='cuda').view(1, -1)
+    d16, inv = split_gemm.wgrad16_operand(d)
+    cols = split_gemm.ColScaled(x)
+    out = torch.zeros(m, k, device='cuda')
+    split_gemm.wgrad16(out, d16, inv, cols[0], cols[1], 0, x_col_inv=cols.col_inv)
+    ref_w = d.double().t() @ x.double()
+    lib_w = torch.mm(d.t(), x)
+    rel = lambda a: float((a.double() - ref_w).norm() / ref_w.norm())
+    col = lambda a: float(((a.double() - ref_w).abs().amax(dim=0) / ref_w.abs().amax(dim=0)).max())
+    assert rel(out) < 2.0 * rel(lib_w) + 1e-7 and col(out) < 3.0 * col(lib_w) + 1e-7, \
+        (rel(out), rel(lib_w), col(out), col(lib_w))
+    # a shifted row range and a column slice (W_hh's product reads the layer output one step off)
+    out2 = torch.zeros(m, 512, device='cuda')
+    split_gemm.wgrad16(out2, d16, inv, cols[0], cols[1], 64, x_cols=slice(256, 768),
+                       d_rows=slice(0, rows - 64), x_col_inv=cols.col_inv)
+    ref2 = d[:rows - 64].double().t() @ x[64:, 256:768].double()
+    assert float((out2.double() - ref2).norm() / ref2.norm()) < 3e-6

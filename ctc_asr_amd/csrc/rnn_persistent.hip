@@ -2184,6 +2184,316 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
         for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same backward recurrence on the fp16 matrix pipe for the LSTM at H = 2048 (round 5; the
+// reference's best published models are 4 - 5 x BiLSTM-2048, testruns.md): ONE direction per launch
+// on 256 workgroups of 8 units - 8 x 8192 weights as two fp16 pieces = 256 KB per workgroup, half
+// in LDS (unpadded: a fragment's lanes l and l + 8 read the same 16 bytes), half in 256 registers
+// per lane.  A producer = one workgroup = 8 units x 4 gates = 32 gate columns = ONE K = 32 MFMA
+// step: its 16 rows are scaled by the power of two that puts the row's largest of those 32
+// values into [2^13, 2^14).  Exchange [step][dir][producer P][piece][k group q][b][8 halves],
+// k group q = units 2 q, 2 q + 1 of P, element e = 4 (unit & 1) + gate; inverse scales
+// [step][dir][producer][32 rows].  Only 8 of an MFMA tile's 16 output columns are real (the other
+// 8 repeat them and are never read).  One 16-row tile per launch (B <= 32: the tiles, like the
+// directions, run one after the other).
+#define PRNN_W16_H 2048
+#ifndef PRNN_W16_D
+#define PRNN_W16_D 12                  // ring depth: producers whose A granules are in flight
+#endif
+__host__ __device__ inline size_t prnn_w16_scale_bytes(int T) {
+    return (size_t)(T + 1) * 2 * (PRNN_W16_H / 8) * PRNN_B16_SCALE_ROWS * sizeof(float);
+}
+template <int D>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
+    constexpr int H = PRNN_W16_H, GH = 4 * H, NW = 4, NTH = PRNN_THREADS;
+    constexpr int NP = H / 8;               // producers per direction = workgroups
+    constexpr int NPW = NP / NW;            // producers per wave: 64
+    constexpr int QS = NPW * 2;             // B-fragment slots per wave: (producer, piece)
+    constexpr int QL = QS / 2, REGW = QS - QL;      // 64 slots in LDS (512 B each), 64 in registers
+    constexpr int RED_FLOATS = NW * 16 * 17;
+    constexpr int IVL = NPW * 4;            // float4 slots of a wave's inverse scales
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
+    u32x4 *frag = reinterpret_cast<u32x4 *>(smem);          // [wave][QL][32 granules]
+    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 32 * sizeof(u32x4));
+    float4 *invs = reinterpret_cast<float4 *>(red + RED_FLOATS);        // [wave][IVL]
+    float *wave_top = reinterpret_cast<float *>(invs + NW * IVL);
+
+    const int chain = p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
+    const int row0 = chain * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int B = p.B, T = p.T, BS = p.BS;
+    const int u0 = slice * 8;
+
+    // ---- this workgroup's 8 columns of R^T as scaled fp16 pieces -------------------------------
+    float w_scale;
+    {
+        float m = 0.f;
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 7)) * GH;
+        for (int n = (tid >> 3) * 4; n < GH; n += NTH / 8 * 4) {
+            const float4 v = ldg4(wrow + n);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        if (lane == 0) wave_top[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wave_top[0], wave_top[1]), fmaxf(wave_top[2], wave_top[3]));
+        const unsigned bits = __float_as_uint(m);
+        const int e = (int)((bits >> 23) & 0xFF) - 127;
+        const int se = bits == 0u ? 0 : min(max(14 - e, -60), 60);
+        w_scale = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+    const float out_scale = 1.0f / w_scale;
+    u32x4 wreg[REGW];
+    {
+        // fragment of producer P (of this wave): lane (k group q = lane >> 4, column lane & 7)
+        auto pieces = [&](int pw, u32x4 &first, u32x4 &second) {
+            const float *wcol = p.w + ((size_t)dir * H + u0 + (lane & 7)) * GH +
+                                8 * (wave * NPW + pw) + 2 * (lane >> 4);
+            unsigned q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                q[e] = f16_pieces(wcol[(size_t)(e & 3) * H + (e >> 2)] * w_scale);
+            first = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                            (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+            second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                             (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+        };
+        for (int pw = 0; pw < QL / 2; ++pw) {
+            u32x4 first, second;
+            pieces(pw, first, second);
+            if ((lane & 15) < 8) {
+                const int cell16 = (lane >> 4) * 8 + (lane & 7);
+                frag[(wave * QL + 2 * pw) * 32 + cell16] = first;
+                frag[(wave * QL + 2 * pw + 1) * 32 + cell16] = second;
+            }
+        }
+#pragma unroll
+        for (int pw = 0; pw < REGW / 2; ++pw) pieces(QL / 2 + pw, wreg[2 * pw], wreg[2 * pw + 1]);
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * GH;
+    const size_t x_base = x_step;
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.rs, 0, (int)prnn_w16_scale_bytes(T), 0x00020000);
+    constexpr unsigned S_STEP = 2u * NP * PRNN_B16_SCALE_ROWS * sizeof(float);
+    const int rnum = 0x7FFFFFFF;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.dy), 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cells, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dxw, 0, rnum, 0x00020000);
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    };
+
+    // ---- the item of this thread (threads 0 .. 127): row tid >> 3 of the tile, unit tid & 7 -----
+    const bool has_item = tid < 128;
+    const int ib = (tid >> 3) & 15, iu = tid & 7, unit = u0 + iu;
+    const int brow = row0 + ib;
+    const int steps = has_item && brow < B ? row_steps(p.seq_len, brow, T) : 0;
+    float dc_state = 0.f, dbs[4] = {0.f, 0.f, 0.f, 0.f}, cmx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.s_hi < T && steps > 0) dc_state = p.carry[((size_t)dir * B + brow) * H + unit];
+    const int arow = row0 + (lane & 15);
+    const int a_steps = arow < B ? row_steps(p.seq_len, arow, T) : 0;
+
+    unsigned long long pt[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0 && threadIdx.x == 0;
+    for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
+        float dyv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cv = 0.f, cpv = 0.f;
+        int it_t = -1;
+        if (s < steps) {
+            const int t = row_time(dir, s, steps);
+            it_t = t;
+            const unsigned e0 = (unsigned)(((t * BS + brow) * 2 + dir) * H + unit);
+            dyv = ldf(dy_rsrc, e0 * 4u);
+            gi = ldf(g_rsrc, (e0 * 4u - 3u * unit) * 4u);
+            gf = ldf(g_rsrc, (e0 * 4u - 3u * unit + H) * 4u);
+            gg = ldf(g_rsrc, (e0 * 4u - 3u * unit + 2 * H) * 4u);
+            go = ldf(g_rsrc, (e0 * 4u - 3u * unit + 3 * H) * 4u);
+            cv = ldf(c_rsrc, e0 * 4u);
+            if (s > 0)
+                cpv = ldf(c_rsrc, (unsigned)(((row_time(dir, s - 1, steps) * BS + brow) * 2 + dir) *
+                                             H + unit) * 4u);
+        }
+        f32x4 total = {0.f, 0.f, 0.f, 0.f};
+        if (s < T - 1) {
+            if (s < p.s_hi - 1) {
+                dir_wait<1>(p.sync, nullptr, dir, chain, group_size, (unsigned)(p.s_hi - 2 - s),
+                            tid);
+                if (s == p.s_lo && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
+            // inverse scales of the wave's 64 producers x 16 rows: four 1 KB loads
+            float4 iv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                iv[j] = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
+                                               (unsigned)(((dir * NP + wave * NPW + 16 * j + (lane >> 2)) *
+                                                           PRNN_B16_SCALE_ROWS + row0 + 4 * (lane & 3)) *
+                                                          sizeof(float)));
+            const bool ok = s + 1 < a_steps;        // otherwise: the all-zero block
+            const unsigned aoff = (unsigned)(((ok ? x_base + (size_t)(s + 1) * x_step : 0) +
+                                              (size_t)dir * B * GH + (size_t)(lane >> 4) * B * 4 +
+                                              (size_t)(ok ? arow : 0) * 4) * sizeof(float));
+            u32x4 a[D][2];
+            // (the 128 wave-uniform offsets of a step are products with the runtime batch: opaque
+            // to the optimiser here, or it computes them all ahead of the step loop and spills
+            // a hundred scalar registers)
+            unsigned gstride = (unsigned)(B * 16 * sizeof(float));
+            asm volatile("" : "+s"(gstride));
+            const unsigned wbase = (unsigned)(wave * NPW * 2) * gstride;
+            auto issue = [&](int P, u32x4 (&dst)[2]) {
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+                    dst[pc] = load16u(x_rsrc, aoff, wbase + (unsigned)(P * 2 + pc) * gstride);
+            };
+#pragma unroll
+            for (int P = 0; P < D; ++P) issue(P, a[P]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) invs[wave * IVL + 64 * j + lane] = iv[j];
+            auto bfrag = [&](int sl) -> u32x4 {      // compile-time slot after unrolling
+                return sl < QL ? frag[(wave * QL + sl) * 32 + (lane >> 4) * 8 + (lane & 7)]
+                               : wreg[sl - QL];
+            };
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < NPW; ++P) {
+                Frag16 w1, w2, d1, d2;
+                w1.u = bfrag(2 * P);
+                w2.u = bfrag(2 * P + 1);
+                d1.u = a[P % D][0];
+                d2.u = a[P % D][1];
+                f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w1.h, zero, 0, 0, 0);
+                f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w2.h, zero, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2.h, w1.h, acc1, 0, 0, 0);
+                if (P + D < NPW) issue(P + D, a[P % D]);
+                const float4 ivp = invs[wave * IVL + 4 * P + (lane >> 4)];
+                const f32x4 sum = acc0 + acc1;
+                total[0] += sum[0] * ivp.x;
+                total[1] += sum[1] * ivp.y;
+                total[2] += sum[2] * ivp.z;
+                total[3] += sum[3] * ivp.w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (prof) {
+            asm volatile("" ::"v"(total[0]));
+            unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            red[(wave * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = total[r] * out_scale;
+        __syncthreads();
+
+        if (has_item) {
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (it_t >= 0) {
+                float dh = dyv;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) dh += red[(w * 16 + ib) * 17 + iu];
+                const float tc = tanhf_(cv);
+                const float dc = dc_state + dh * go * (1.f - tc * tc);
+                dg[0] = dc * gg * gi * (1.f - gi);
+                dg[1] = dc * cpv * gf * (1.f - gf);
+                dg[2] = dc * gi * (1.f - gg * gg);
+                dg[3] = dh * tc * go * (1.f - go);
+                dc_state = dc * gf;
+            }
+            // the row's scale over this workgroup's 32 values (8 lanes of a DPP row)
+            float mx = fmaxf(fmaxf(fabsf(dg[0]), fabsf(dg[1])), fmaxf(fabsf(dg[2]), fabsf(dg[3])));
+            mx = fmaxf(mx, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(mx))));
+            mx = fmaxf(mx, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(mx))));
+            mx = fmaxf(mx, __uint_as_float(dpp_u32<0x141>(__float_as_uint(mx))));
+            const unsigned mbits = __float_as_uint(mx);
+            const int me = (int)((mbits >> 23) & 0xFF) - 127;
+            const int mse = mbits == 0u ? 0 : min(max(13 - me, -100), 100);
+            const float rscale = __uint_as_float((unsigned)(mse + 127) << 23);
+            const float rinv = __uint_as_float((unsigned)(127 - mse) << 23);
+            unsigned q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) q[g] = f16_pieces(dg[g] * rscale);
+            const bool odd = (tid & 1) != 0;
+            const unsigned f01 = (q[0] & 0xFFFFu) | (q[1] << 16), f23 = (q[2] & 0xFFFFu) | (q[3] << 16);
+            const unsigned s01 = (q[0] >> 16) | (q[1] & 0xFFFF0000u),
+                           s23 = (q[2] >> 16) | (q[3] & 0xFFFF0000u);
+            const unsigned give01 = odd ? f01 : s01, give23 = odd ? f23 : s23;
+            const unsigned got01 = dpp_u32<0xB1>(give01), got23 = dpp_u32<0xB1>(give23);   // lane ^ 1
+            const u32x4 v = odd ? (u32x4){got01, got23, s01, s23} : (u32x4){f01, f23, got01, got23};
+            if (it_t >= 0) {
+                const unsigned off = (unsigned)(
+                    (x_base + (size_t)s * x_step + (size_t)dir * B * GH +
+                     (size_t)(slice * 2 + (odd ? 1 : 0)) * B * 16 +
+                     (size_t)((iu >> 1) & 3) * B * 4 + (size_t)brow * 4) * sizeof(float));
+                __builtin_amdgcn_raw_buffer_store_b128(v, x_rsrc, (int)off, 0, 16);
+            }
+            // the eight rows of this wave: two 16-byte stores of their inverse scales
+            float rr[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                rr[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 8 * k));
+            if (lane == 0) {
+                const unsigned so = (unsigned)s * S_STEP +
+                                    (unsigned)(((dir * NP + slice) * PRNN_B16_SCALE_ROWS + row0 +
+                                                (tid >> 3)) * sizeof(float));
+                store16_sc1(s_rsrc, so, rr[0], rr[1], rr[2], rr[3]);
+                store16_sc1(s_rsrc, so + 16u, rr[4], rr[5], rr[6], rr[7]);
+            }
+            if (it_t >= 0) {
+                const unsigned dx0 = (unsigned)(((it_t * BS + brow) * 2 + dir) * GH + unit) * 4u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg[g]), dx_rsrc,
+                                                          (int)(dx0 + (unsigned)g * H * 4u), 0, 0);
+                    dbs[g] += dg[g];
+                    cmx[g] = fmaxf(cmx[g], fabsf(dg[g]));
+                }
+            }
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
+        if (s > p.s_lo) {
+            unsigned unused = 0;
+            dir_arrive<1>(p.sync, nullptr, dir, chain, grp, tid, unused);
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if (prof)
+        for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+    if (p.s_lo > 0 && steps > 0) p.carry[((size_t)dir * B + brow) * H + unit] = dc_state;
+    if (p.dbias || p.colmax) {
+        float *sums = red, *tops = reinterpret_cast<float *>(frag);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __syncthreads();
+            if (has_item) {
+                sums[tid] = dbs[g];
+                tops[tid] = cmx[g];
+            }
+            __syncthreads();
+            if (tid < 8) {
+                float sum = 0.f, top = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    sum += sums[r * 8 + tid];
+                    top = fmaxf(top, tops[r * 8 + tid]);
+                }
+                if (p.dbias) atomicAdd(p.dbias + ((size_t)dir * 4 + g) * H + u0 + tid, sum);
+                if (p.colmax)
+                    atomicMax(p.colmax + ((size_t)dir * 4 + g) * H + u0 + tid, __float_as_uint(top));
+            }
+        }
+    }
+}
+
 int device_cu_count() {
     static int cus = -1;
     if (cus < 0) {
@@ -2295,7 +2605,8 @@ static size_t prnn_step_exchange_bytes(int T, int B, int H, int G) {
 // ... and the inverse scales of the fp16 backward kernel
 size_t prnn_exchange_bytes(int T, int B, int H, int G) {
     return prnn_step_exchange_bytes(T, B, H, G) +
-           (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() + prnn_b16_scale_bytes(T) : 0);
+           (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() + prnn_b16_scale_bytes(T) : 0) +
+           (G == 4 && H == PRNN_W16_H ? prnn_w16_scale_bytes(T) : 0);
 }
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
@@ -2474,6 +2785,23 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
         if (mt == 1) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 16, 16, 16, 1, 1); }
         if (chains) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 8, 16, 16, 2, 1); }
         PRNN_BWD(CTCASR_CELL_GRU, 48, 2, 8, 16, 16, 1, 1);
+    }
+    if (cell == CTCASR_CELL_LSTM && H == PRNN_W16_H && (flags & CTCASR_RNN_F16)) {
+        // fp16 matrix pipe (round 5): the same geometry as the fp32 kernel below - 256 workgroups
+        // of 8 units, one direction and one 16-row tile per launch
+        p.nwg = 256; p.ndir = 1;
+        p.colmax = colmax;
+        p.rs = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xchg) +
+                                         prnn_step_exchange_bytes(T, B, H, 4));
+        const size_t lds = (size_t)4 * 64 * 32 * 16 + (size_t)4 * 16 * 17 * 4 +
+                           (size_t)4 * 256 * 16 + 64;
+        for (int tile = 0; tile < mt; ++tile)
+            for (int dir = 0; dir < 2; ++dir) {
+                p.chain0 = tile; p.dir0 = dir;
+                const int rc = launch_persistent(prnn_bwd16w_kernel<PRNN_W16_D>, p, lds, s);
+                if (rc != CTCASR_OK) return rc;
+            }
+        return CTCASR_OK;
     }
     if (cell == CTCASR_CELL_LSTM && H == 2048) {
         // 8 units per workgroup (half MFMA tiles: 16 units would be 512 KB of weights), 256

@@ -433,7 +433,7 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, c
 
 // Whether a backward call with these flags runs the fp16-pipe kernel (and so can fill `colmax`).
 extern "C" int ctcasr_rnn_bwd_f16_supported(int cell, int T, int B, int H, int flags) {
-    return (flags & CTCASR_RNN_F16) && cell == CTCASR_CELL_LSTM && H == 1024 &&
+    return (flags & CTCASR_RNN_F16) && cell == CTCASR_CELL_LSTM && (H == 1024 || H == 2048) &&
            ctcasr_rnn_persistent_supported(cell, T, B, H) ? 1 : 0;
 }
 

@@ -342,7 +342,8 @@ def test_rnn_fwd_on_the_fp16_matrix_pipe(hip, cell, use_len, dims):
 
 @pytest.mark.parametrize('use_len', [False, True])
 @pytest.mark.parametrize('dims', [(12, 16, 1024), (30, 7, 1024), (9, 19, 1024), (11, 32, 1024),
-                                  (5, 35, 1024), (6, 64, 1024)])
+                                  (5, 35, 1024), (6, 64, 1024),
+                                  (12, 16, 2048), (9, 5, 2048), (7, 27, 2048), (5, 40, 2048)])
 def test_rnn_bwd_on_the_fp16_matrix_pipe(hip, use_len, dims):
     """CTCASR_RNN_F16 on the backward LSTM-1024 kernel: dgates as two fp16 pieces scaled per
     (producer workgroup, row), W_hh per workgroup, three products.  dxw against autograd through

@@ -1093,6 +1093,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-workloads', action='store_true',
                     help='skip the secondary C2 measurement of the default N = 1 run')
+    ap.add_argument('--no-reference-models', action='store_true',
+                    help='skip ref_default / ref_best (the reference\'s own configurations) among '
+                         'the other workloads of the default N = 1 run')
     ap.add_argument('--dropout', type=float, default=0.1,
                     help='dense_dropout_rate (reference default 0.1)')
     ap.add_argument('--rnn-bwd-whole-chip', action='store_true',
@@ -1223,6 +1226,36 @@ def main():
             other['c5_from_disk'] = measure_c5_from_disk(args, local_rank)
         except Exception as err:        # noqa: BLE001
             other['c5_from_disk'] = {'error': '{}: {}'.format(type(err).__name__, err)}
+    if world == 1 and args.workload == 'c3' and not args.no_other_workloads and \
+            not args.no_reference_models:
+        # the reference's own configurations: its flag defaults (asr/params.py:43-50: 3 conv + 4 x
+        # ReLU-RNN-2048, batch 16) and its best published model (testruns.md: 3 conv + 4 x
+        # BiLSTM-2048) - a few steps each, with the loss / logits deltas of that architecture
+        # against the float64 oracle at the small probe shape (batch 4, T' = 100)
+        ref_args = argparse.Namespace(**vars(args))
+        ref_args.steps, ref_args.warmup = min(args.steps, 6), min(args.warmup, 2)
+        for ref_name in ('ref_default', 'ref_best'):
+            try:
+                line, _ = measure(ref_name, ref_args, rank, local_rank, world)
+                entry = {k: line[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'config',
+                                              'dtype', 'kernel_ms_per_step', 'roofline')}
+                if not args.no_parity_probe:
+                    small = parity_probe(workload_cfg_kwargs(ref_name), 'cuda:{}'.format(local_rank))
+                    entry['ctc_loss_delta'] = small['ctc_loss_delta']
+                    entry['logits_max_abs_delta'] = small['logits_max_abs_delta']
+                    entry['parity_probe'] = {k: small.get(k) for k in (
+                        'loss_gpu', 'loss_oracle', 'batch', 'frames', 'ctc_steps', 'tolerance',
+                        'note')}
+                    entry['parity_probe']['arithmetic'] = \
+                        (small.get('variants') or {}).get('default', {}).get('arithmetic')
+                    if small['ctc_loss_delta'] is not None and (
+                            small['ctc_loss_delta'] > 1e-3 * max(1.0, abs(small.get('loss_oracle')
+                                                                       or 1.0)) or
+                            small['logits_max_abs_delta'] > 1e-3):
+                        exit_code = 3
+                other[ref_name] = entry
+            except Exception as err:        # noqa: BLE001
+                other[ref_name] = {'error': '{}: {}'.format(type(err).__name__, err)}
     if world == 1 and args.collective_stand_in and args.workload != 'c5':
         # one GPU cannot run RCCL beside itself; its CU footprint can be stood in for
         report = {'stand_in': '24 workgroups x 256 threads per bucket, resident for bytes / '

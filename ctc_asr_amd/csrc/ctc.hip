@@ -145,9 +145,15 @@ ctc_sweep_kernel(const float *__restrict__ logits, const int *__restrict__ label
         float sum = 0.f;
         for (int c = 0; c < C; ++c) sum += expf(row[c] - mx);
         float lz = mx + logf(sum);
+        // a NaN / inf logit anywhere in the utterance makes its loss NaN, as tf.nn.ctc_loss's
+        // log-softmax would (asr/model.py:259 -> NanTensorHook, :368): the lattice's max-based
+        // log-sum-exp below would otherwise drop NaN paths and report a finite loss while the
+        // gradient carries the NaN into the parameters
+        if (!(fabsf(lz) <= 3.0e38f)) atomicOr(&flags[2], 1);
         for (int c = 0; c < C; ++c) logp[t * C + c] = row[c] - lz;
     }
     __syncthreads();
+    const bool poisoned = flags[2] != 0;
 
     int my_ext[CTC_MAX_PER_THREAD];
     bool skip_ok[CTC_MAX_PER_THREAD];   // may take the u-2 -> u (alpha) transition
@@ -195,7 +201,11 @@ ctc_sweep_kernel(const float *__restrict__ logits, const int *__restrict__ label
         }
         const double *fin = ((len - 1) & 1) ? lat1 : lat0;
         const double log_pzx = lse3(fin[S - 1], S > 1 ? fin[S - 2] : -INFINITY, -INFINITY);
-        if (tid == 0) { status[b] = 0; loss[b] = (float)(-log_pzx); logpzx_ws[b] = log_pzx; }
+        if (tid == 0) {
+            status[b] = 0;
+            loss[b] = poisoned ? __uint_as_float(0x7FC00000u) : (float)(-log_pzx);
+            logpzx_ws[b] = log_pzx;
+        }
         return;
     }
 

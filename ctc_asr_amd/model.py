@@ -706,6 +706,13 @@ class CTCModel:
         sequences = sequences.to(self.device, torch.float32).contiguous()
         batch, frames, _ = sequences.shape
         acts = {'training': training, 'batch': batch, 'conv_f16': {}}
+        # A NaN / inf in an utterance's features makes that utterance's loss NaN in the reference
+        # (TensorFlow's relu / minimum / matmul propagate it; NanTensorHook stops the run,
+        # asr/model.py:368).  Here the clipped-ReLU epilogues and the saturating fp16 splits would
+        # swallow it - finite loss, NaN weight gradients -, so the utterance is marked at the door
+        # and `loss_fn` reports what TensorFlow would (three tiny kernels per step).
+        acts['input_poison'] = torch.where(
+            torch.isfinite(sequences).view(batch, -1).all(dim=1), 0.0, float('nan')).to(torch.float32)
         self._prepare_weight_splits(cfg.output_time(frames) * batch, training, batch)
         if cfg.used_model == 'ds2':
             # conv dropout: the reference never forwards `training` to conv_layers, so a
@@ -1127,6 +1134,9 @@ class CTCModel:
                                                      grad_scale=1.0 / batch)
         if self._acts is not None:
             self._acts['dlogits'] = grad
+            if self._acts.get('input_poison') is not None and \
+                    self._acts['input_poison'].shape == per_utt.shape:
+                per_utt = per_utt + self._acts['input_poison']
         self.last_status, self.last_per_utterance_loss = status, per_utt
         if check:
             self.check_status(status)

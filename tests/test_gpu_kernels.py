@@ -83,6 +83,29 @@ def test_ctc_infeasible_and_bad_label(hip):
     assert float(grad[:, 0].abs().max()) == 0.0 and float(grad[:, 2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('poison', [float('nan'), float('inf')])
+def test_ctc_loss_of_non_finite_logits_is_nan(hip, poison):
+    """A NaN / inf logit inside an utterance's frames makes THAT utterance's loss NaN - what
+    tf.nn.ctc_loss's log-softmax yields and the reference's NanTensorHook stops on
+    (asr/model.py:259, :368); the max-based log-sum-exp of the lattice alone would drop the NaN
+    paths, report a finite loss and let the NaN gradient through (found by the Trainer test of
+    round 5).  The other utterances and frames beyond the length are unaffected."""
+    rng = np.random.default_rng(13)
+    logits = rng.normal(size=(40, 3, 29)).astype(np.float32)
+    labels = [[1, 2, 3], [4, 5], [6, 7, 8, 9]]
+    flat, offsets = pack_labels(labels)
+    lens = np.array([40, 25, 40], dtype=np.int32)
+    args = (_t(flat, torch.int32), _t(offsets, torch.int32), _t(lens, torch.int32), 4)
+    clean, _, _ = hip.ctc_loss_fwd_bwd(_t(logits), *args)
+    bad = logits.copy()
+    bad[17, 0, 5] = poison          # inside utterance 0
+    bad[30, 1, 2] = poison          # beyond utterance 1's 25 frames: not looked at
+    loss, grad, status = hip.ctc_loss_fwd_bwd(_t(bad), *args)
+    assert status.cpu().tolist() == [0, 0, 0]
+    assert torch.isnan(loss[0])
+    assert torch.equal(loss[1:], clean[1:]) and torch.isfinite(grad[:, 1:]).all()
+
+
 @pytest.mark.parametrize('shape', [(7, 3, 6), (300, 5, 29), (777, 2, 29)])
 def test_greedy_decode(hip, shape):
     num_steps, batch, classes = shape

@@ -2494,6 +2494,282 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The plain ReLU recurrence at H = 2048 - the reference's DEFAULT model, asr/params.py:43-50 - on the
+// fp16 matrix pipe (round 5), forward (BWD = false: h_t = relu(xw_t + b + h_(t-1) W_hh^T)) and
+// backward (BWD = true: dpre_t = (dy_t + dpre_(t+1) W_hh) [y_t > 0]) from one kernel: both are "a
+// row vector of 2048 values times a 2048 x 2048 matrix, then something elementwise".  Neither h
+// (no bound behind a ReLU) nor dpre has a range, so BOTH take the block scaling of the LSTM
+// backward kernel (section 4.1e): a producer = one workgroup = 32 units = ONE K = 32 MFMA step
+// scales each of its 16 rows by the power of two of the row's largest of those 32 values,
+// publishes two fp16 pieces per value [step][dir][producer][piece][k group of 8 units][b][8 halves]
+// + 16 inverse scales; the consumer multiplies a producer's block into fresh accumulators and
+// adds them times the inverse scale.  64 workgroups per direction (128 CUs: weight-gradient GEMMs
+// fit beside it), 32 units = two N tiles each, 32 x 2048 weights as two fp16 pieces = 256 KB = 128
+// KB LDS + 128 registers per lane, scaled per workgroup.  One 16-row tile (B <= 16), every row
+// running all T steps; everything else takes the fp32 kernels.
+#define PRNN_R16_H 2048
+__host__ __device__ inline size_t prnn_r16_scale_bytes(int T) {
+    return (size_t)(T + 1) * 2 * (PRNN_R16_H / 32) * PRNN_B16_SCALE_ROWS * sizeof(float);
+}
+template <bool BWD>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_relu16_kernel(PArgs p) {
+    constexpr int H = PRNN_R16_H, NW = 4, NTH = PRNN_THREADS;
+    constexpr int NP = H / 32;              // producers per direction = workgroups: 64
+    constexpr int NPW = NP / NW;            // producers per wave: 16
+    constexpr int QS = NPW * 4;             // B-fragment slots per wave: (producer, N tile, piece)
+    constexpr int QL = QS / 2, REGW = QS - QL;
+    constexpr int RED_FLOATS = NW * 2 * 16 * 17;
+    constexpr int IVL = NPW * 4;            // float4 slots of a wave's inverse scales
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
+    u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 64 * sizeof(u32x4));
+    float4 *invs = reinterpret_cast<float4 *>(red + RED_FLOATS);
+    float *wave_top = reinterpret_cast<float *>(invs + NW * IVL);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const int dir = p.dir0 + wg / p.nwg, slice = wg % p.nwg;
+    const int chain = 0;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int B = p.B, T = p.T, BS = p.BS;
+    const int u0 = slice * 32;
+
+    // ---- this workgroup's 32 rows of the matrix (forward: w_hh [dir][unit][k]; backward: w_hh_t
+    // [dir][unit][k] - the contraction index is the contiguous one either way) as scaled pieces
+    float w_scale;
+    {
+        float m = 0.f;
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 31)) * H;
+        for (int n = (tid >> 5) * 4; n < H; n += NTH / 32 * 4) {
+            const float4 v = ldg4(wrow + n);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        if (lane == 0) wave_top[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wave_top[0], wave_top[1]), fmaxf(wave_top[2], wave_top[3]));
+        const unsigned bits = __float_as_uint(m);
+        const int e = (int)((bits >> 23) & 0xFF) - 127;
+        const int se = bits == 0u ? 0 : min(max(14 - e, -60), 60);
+        w_scale = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+    const float out_scale = 1.0f / w_scale;
+    u32x4 wreg[REGW];
+    {
+        // slot (producer pw of this wave, N tile nt): lane (k group q = lane >> 4, column lane & 15)
+        // holds the 8 contraction indices 32 P + 8 q .. + 7 of unit u0 + 16 nt + column
+        auto pieces = [&](int sl2, u32x4 &first, u32x4 &second) {
+            const int pw = sl2 >> 1, nt = sl2 & 1;
+            const float *wcol = p.w + ((size_t)dir * H + u0 + 16 * nt + (lane & 15)) * H +
+                                32 * (wave * NPW + pw) + 8 * (lane >> 4);
+            const float4 lo = ldg4(wcol), hi = ldg4(wcol + 4);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            unsigned q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = f16_pieces(v[e] * w_scale);
+            first = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                            (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+            second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                             (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+        };
+        for (int sl2 = 0; sl2 < QL / 2; ++sl2) {
+            u32x4 first, second;
+            pieces(sl2, first, second);
+            frag[(wave * QL + 2 * sl2) * 64 + lane] = first;
+            frag[(wave * QL + 2 * sl2 + 1) * 64 + lane] = second;
+        }
+#pragma unroll
+        for (int sl2 = 0; sl2 < REGW / 2; ++sl2)
+            pieces(QL / 2 + sl2, wreg[2 * sl2], wreg[2 * sl2 + 1]);
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * H * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * H;
+    const size_t x_base = x_step;
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.rs, 0, (int)prnn_r16_scale_bytes(T), 0x00020000);
+    constexpr unsigned S_STEP = 2u * NP * PRNN_B16_SCALE_ROWS * sizeof(float);
+
+    // ---- the two items of this thread: row (item >> 5), unit item & 31; item = tid + 256 it -----
+    const int iu = tid & 31, unit = u0 + iu;
+    int brow[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) brow[it] = (tid >> 5) + 8 * it;
+    const float bias = (!BWD && p.bias) ? p.bias[(size_t)dir * H + unit] : 0.f;
+    const int arow = lane & 15;
+    float dbs = 0.f, cmx = 0.f;
+
+    const int s_first = BWD ? p.s_hi - 1 : p.s_lo, s_last = BWD ? p.s_lo : p.s_hi - 1;
+    const int s_inc = BWD ? -1 : 1;
+    unsigned long long pt[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0 && threadIdx.x == 0;
+    for (int s = s_first; BWD ? s >= s_last : s <= s_last; s += s_inc) {
+        unsigned long long c0 = prof ? wall_clock64() : 0;
+        const int t = row_time(dir, s, T);
+        // the step's own inputs, requested before the barrier
+        float in0[2], in1[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            in0[it] = in1[it] = 0.f;
+            if (brow[it] < B) {
+                if constexpr (BWD) {
+                    const size_t e = ((size_t)t * BS + brow[it]) * 2 * H + dir * H + unit;
+                    in0[it] = p.dy[e];
+                    in1[it] = p.y[e];
+                } else {
+                    in0[it] = p.xw[(((size_t)t * BS + brow[it]) * 2 + dir) * H + unit] + bias;
+                }
+            }
+        }
+        f32x4 total[2];
+        total[0] = total[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int src = BWD ? s + 1 : s - 1;            // the step whose published block is read
+        if (BWD ? s < T - 1 : s > 0) {
+            if (s != s_first) {
+                dir_wait<1>(p.sync, nullptr, dir, chain, group_size,
+                            (unsigned)(BWD ? p.s_hi - 2 - s : s - 1 - p.s_lo), tid);
+                if (s == s_last && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
+            }
+            if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
+            const float4 iv = load16_sc1(
+                s_rsrc, (unsigned)src * S_STEP +
+                            (unsigned)(((dir * NP + wave * NPW + (lane >> 2)) * PRNN_B16_SCALE_ROWS +
+                                        4 * (lane & 3)) * sizeof(float)));
+            const bool ok = arow < B;
+            const unsigned aoff = (unsigned)(((ok ? x_base + (size_t)src * x_step : 0) +
+                                              (size_t)dir * B * H + (size_t)(lane >> 4) * B * 4 +
+                                              (size_t)(ok ? arow : 0) * 4) * sizeof(float));
+            unsigned gstride = (unsigned)(B * 16 * sizeof(float));
+            asm volatile("" : "+s"(gstride));
+            const unsigned wbase = (unsigned)(wave * NPW * 2) * gstride;
+            u32x4 a[NPW][2];
+#pragma unroll
+            for (int P = 0; P < NPW; ++P)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+                    a[P][pc] = load16u(x_rsrc, aoff, wbase + (unsigned)(P * 2 + pc) * gstride);
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane < IVL) invs[wave * IVL + lane] = iv;
+            auto bfrag = [&](int sl) -> u32x4 {
+                return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+            };
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < NPW; ++P) {
+                Frag16 d1, d2;
+                d1.u = a[P][0];
+                d2.u = a[P][1];
+                const float4 ivp = invs[wave * IVL + 4 * P + (lane >> 4)];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    Frag16 w1, w2;
+                    w1.u = bfrag((P * 2 + nt) * 2);
+                    w2.u = bfrag((P * 2 + nt) * 2 + 1);
+                    f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w1.h, zero, 0, 0, 0);
+                    f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w2.h, zero, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2.h, w1.h, acc1, 0, 0, 0);
+                    const f32x4 sum = acc0 + acc1;
+                    total[nt][0] += sum[0] * ivp.x;
+                    total[nt][1] += sum[1] * ivp.y;
+                    total[nt][2] += sum[2] * ivp.z;
+                    total[nt][3] += sum[3] * ivp.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (prof) {
+            asm volatile("" ::"v"(total[0][0]));
+            unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((wave * 2 + nt) * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] =
+                    total[nt][r] * out_scale;
+        __syncthreads();
+
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool has = brow[it] < B;
+            float acc = in0[it];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                acc += red[((w * 2 + (iu >> 4)) * 16 + brow[it]) * 17 + (iu & 15)];
+            float val;                               // what the next step multiplies
+            if constexpr (BWD) val = in1[it] > 0.f ? acc : 0.f;
+            else val = fmaxf(acc, 0.f);
+            if (!has) val = 0.f;
+            // the row's scale over this workgroup's 32 values (two DPP rows of 16 lanes)
+            float mx = row16_max(fabsf(val));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            const unsigned mbits = __float_as_uint(mx);
+            const int me = (int)((mbits >> 23) & 0xFF) - 127;
+            const int mse = mbits == 0u ? 0 : min(max(13 - me, -100), 100);
+            const float rscale = __uint_as_float((unsigned)(mse + 127) << 23);
+            const float rinv = __uint_as_float((unsigned)(127 - mse) << 23);
+            u32x4 first, second;
+            gather8_pieces(f16_pieces(val * rscale), first, second);
+            if (has && (tid & 7) == 0) {
+                const unsigned off = (unsigned)(
+                    (x_base + (size_t)s * x_step + (size_t)dir * B * H + (size_t)slice * B * 32 +
+                     (size_t)(iu >> 3) * B * 4 + (size_t)brow[it] * 4) * sizeof(float));
+                __builtin_amdgcn_raw_buffer_store_b128(first, x_rsrc, (int)off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    second, x_rsrc, (int)(off + (unsigned)(B * 16 * sizeof(float))), 0, 16);
+            }
+            if (has && (tid & 31) == 0)
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __float_as_uint(rinv), s_rsrc,
+                    (int)((unsigned)s * S_STEP +
+                          (unsigned)(((dir * NP + slice) * PRNN_B16_SCALE_ROWS + brow[it]) *
+                                     sizeof(float))), 0, 16);
+            if (has) {
+                if constexpr (BWD) {
+                    p.dxw[(((size_t)t * BS + brow[it]) * 2 + dir) * H + unit] = val;
+                    dbs += val;
+                    cmx = fmaxf(cmx, fabsf(val));
+                } else {
+                    p.y[((size_t)t * BS + brow[it]) * 2 * H + dir * H + unit] = val;
+                }
+            }
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[2] += c - c0; c0 = c; }
+        if (s != s_last) {
+            unsigned unused = 0;
+            dir_arrive<1>(p.sync, nullptr, dir, chain, grp, tid, unused);
+        } else {
+            __syncthreads();            // (the partial sums in LDS are reused by nobody after this)
+        }
+        if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
+    }
+    if (prof)
+        for (int i = 0; i < 4; ++i) p.sync->prof[(BWD ? 4 : 0) + i] = pt[i];
+    if (BWD && (p.dbias || p.colmax)) {
+        // sums / maxima over the 8 rows a thread column holds, then one atomic per unit
+        float *sums = red, *tops = red + 256;
+        __syncthreads();
+        sums[tid] = dbs;
+        tops[tid] = cmx;
+        __syncthreads();
+        if (tid < 32) {
+            float sum = 0.f, top = 0.f;
+            for (int r = 0; r < 8; ++r) {
+                sum += sums[r * 32 + tid];
+                top = fmaxf(top, tops[r * 32 + tid]);
+            }
+            if (p.dbias) atomicAdd(p.dbias + (size_t)dir * H + u0 + tid, sum);
+            if (p.colmax) atomicMax(p.colmax + (size_t)dir * H + u0 + tid, __float_as_uint(top));
+        }
+    }
+}
+
 int device_cu_count() {
     static int cus = -1;
     if (cus < 0) {
@@ -2606,7 +2882,8 @@ static size_t prnn_step_exchange_bytes(int T, int B, int H, int G) {
 size_t prnn_exchange_bytes(int T, int B, int H, int G) {
     return prnn_step_exchange_bytes(T, B, H, G) +
            (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() + prnn_b16_scale_bytes(T) : 0) +
-           (G == 4 && H == PRNN_W16_H ? prnn_w16_scale_bytes(T) : 0);
+           (G == 4 && H == PRNN_W16_H ? prnn_w16_scale_bytes(T) : 0) +
+           (G == 1 && H == PRNN_R16_H ? prnn_r16_scale_bytes(T) : 0);
 }
 
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
@@ -2661,6 +2938,16 @@ int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
         const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 + 32;
         return lstm ? launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_LSTM, 2, 8, 0>, p, lds, s)
                     : launch_persistent(prnn_fwd16_kernel<CTCASR_CELL_GRU, 2, 8, 0>, p, lds, s);
+    }
+    if ((flags & CTCASR_RNN_F16) && cell == CTCASR_CELL_RNN_RELU && H == PRNN_R16_H && mt == 1 &&
+        !seq_len) {
+        // the reference's default cell on the fp16 pipe: 64 workgroups per direction, 32 units each
+        p.nwg = PRNN_R16_H / 32;
+        p.rs = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xchg) +
+                                         prnn_step_exchange_bytes(T, B, H, 1));
+        const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 +
+                           (size_t)4 * 64 * 16 + 64;
+        return launch_persistent(prnn_relu16_kernel<false>, p, lds, s);
     }
     // 128 workgroups per direction, 16 * NT gate columns each, QW = H / 64 K chunks per wave
 #define PRNN_FWD(CELL_, NT_, QW_, MT_)                                                        \
@@ -2785,6 +3072,16 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
         if (mt == 1) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 16, 16, 16, 1, 1); }
         if (chains) { PRNN_BWD(CTCASR_CELL_GRU, 48, 1, 8, 16, 16, 2, 1); }
         PRNN_BWD(CTCASR_CELL_GRU, 48, 2, 8, 16, 16, 1, 1);
+    }
+    if ((flags & CTCASR_RNN_F16) && cell == CTCASR_CELL_RNN_RELU && H == PRNN_R16_H && mt == 1 &&
+        !seq_len) {
+        p.nwg = PRNN_R16_H / 32;
+        p.colmax = colmax;
+        p.rs = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xchg) +
+                                         prnn_step_exchange_bytes(T, B, H, 1));
+        const size_t lds = (size_t)4 * 32 * 64 * 16 + (size_t)4 * 2 * 16 * 17 * 4 +
+                           (size_t)4 * 64 * 16 + 64;
+        return launch_persistent(prnn_relu16_kernel<true>, p, lds, s);
     }
     if (cell == CTCASR_CELL_LSTM && H == PRNN_W16_H && (flags & CTCASR_RNN_F16)) {
         // fp16 matrix pipe (round 5): the same geometry as the fp32 kernel below - 256 workgroups

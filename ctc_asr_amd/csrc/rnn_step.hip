@@ -433,8 +433,22 @@ extern "C" int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, c
 
 // Whether a backward call with these flags runs the fp16-pipe kernel (and so can fill `colmax`).
 extern "C" int ctcasr_rnn_bwd_f16_supported(int cell, int T, int B, int H, int flags) {
-    return (flags & CTCASR_RNN_F16) && cell == CTCASR_CELL_LSTM && (H == 1024 || H == 2048) &&
+    const int rows = B < PRNN_BLOCK_ROWS ? B : PRNN_BLOCK_ROWS;
+    return (flags & CTCASR_RNN_F16) &&
+           ((cell == CTCASR_CELL_LSTM && (H == 1024 || H == 2048)) ||
+            (cell == CTCASR_CELL_RNN_RELU && H == 2048 && rows <= 16 && B <= 16)) &&
            ctcasr_rnn_persistent_supported(cell, T, B, H) ? 1 : 0;
+}
+
+// Whether a recurrence call runs an fp16-pipe kernel at all (ABI v6; for labels and flags: the
+// forward ReLU-2048 kernel writes no `y_pieces`, so ctcasr_rnn_fwd_f16_supported stays false for
+// it).  ``ragged``: the call passes per-row lengths.
+extern "C" int ctcasr_rnn_f16_recurrence(int cell, int T, int B, int H, int flags, int backward,
+                                         int ragged) {
+    if (cell == CTCASR_CELL_RNN_RELU)
+        return !ragged && ctcasr_rnn_bwd_f16_supported(cell, T, B, H, flags);
+    return backward ? ctcasr_rnn_bwd_f16_supported(cell, T, B, H, flags)
+                    : ctcasr_rnn_fwd_f16_supported(cell, T, B, H, flags);
 }
 
 // Steps [step_begin, step_end) of the backward recurrence, walked downwards.  A whole pass is
@@ -450,7 +464,9 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
                                     int step_begin, int step_end, int flags,
                                     ctcasr_stream_t stream) {
     (void)b_hh_n;
-    if (colmax && !ctcasr_rnn_bwd_f16_supported(cell, T, B, H, flags)) return CTCASR_ERR_UNSUPPORTED;
+    if (colmax && (!ctcasr_rnn_bwd_f16_supported(cell, T, B, H, flags) ||
+                   (cell == CTCASR_CELL_RNN_RELU && seq_len)))
+        return CTCASR_ERR_UNSUPPORTED;
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |

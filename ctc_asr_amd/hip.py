@@ -102,6 +102,7 @@ SIGNATURES = {
                                       _c_int, _c_p]),
     'ctcasr_gemm_split_tn': (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_int,
                                       _c_int, _c_p]),
+    'ctcasr_rnn_f16_recurrence': (_c_int, [_c_int] * 7),
     'ctcasr_collective_traffic': (_c_int, [_c_int, _c_int, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     'ctcasr_dgrad16_packed_bytes': (_c_sz, [_c_int]),
     'ctcasr_dgrad16_pack_weights': (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_f, _c_p, _c_p]),
@@ -460,6 +461,14 @@ def rnn_fwd_f16_supported(cell, num_steps, batch, hidden, flags=RNN_F16):
     [T*B, 3, 2H], the pieces of y * 2^15 in the layout of `split_f16(order (0, 0, 1))`)."""
     return bool(load().ctcasr_rnn_fwd_f16_supported(CELL_IDS[cell], int(num_steps), int(batch),
                                                     int(hidden), int(flags)))
+
+
+def rnn_f16_recurrence(cell, num_steps, batch, hidden, flags=RNN_F16, backward=False,
+                       ragged=False):
+    """Whether a recurrence call with these flags runs an fp16-pipe kernel (include/ctcasr.h)."""
+    return bool(load().ctcasr_rnn_f16_recurrence(CELL_IDS[cell], int(num_steps), int(batch),
+                                                 int(hidden), int(flags), int(backward),
+                                                 int(ragged)))
 
 
 def rnn_bwd_f16_supported(cell, num_steps, batch, hidden, flags=RNN_F16):

@@ -1433,7 +1433,8 @@ class CTCModel:
             # leaves the column maxima of each launch's rows of dxw for the fp16 weight gradients
             bwd_flags = self.rnn_bwd_flags | ((hip.RNN_F16 | self.rnn_xcd_flag)
                                               if self.rnn_bwd_f16 else 0)
-            f16_rec = hip.rnn_bwd_f16_supported(cell, t_out, batch, hidden, bwd_flags)
+            f16_rec = hip.rnn_f16_recurrence(cell, t_out, batch, hidden, bwd_flags, backward=True,
+                                             ragged=acts['rnn_len'] is not None)
             arith['rnn{}/recurrence_bwd'.format(i)] = 'fp16x3' if f16_rec else 'fp32'
             colmax = torch.zeros((chunks, 2 * gh), dtype=torch.int32, device=dy.device) \
                 if f16_rec and g16 else None

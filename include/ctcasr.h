@@ -249,6 +249,11 @@ int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y, const float 
  * largest |dxw| of that column over the steps of the call - what ctcasr_colmax_scale's pass over
  * the finished rows of dxw would find (same values, no pass). */
 int ctcasr_rnn_bwd_f16_supported(int cell, int T, int B, int H, int flags);
+/* ABI v6: whether a recurrence call with these flags runs an fp16-pipe kernel at all (`backward`:
+ * the backward pass; `ragged`: the call passes per-row lengths).  Differs from the two functions
+ * above for the ReLU cell at H = 2048 (B <= 16, no lengths: round 5), whose forward kernel writes
+ * no y_pieces. */
+int ctcasr_rnn_f16_recurrence(int cell, int T, int B, int H, int flags, int backward, int ragged);
 
 /* ---- fused dense / conv epilogues (tf.layers.dense + ReLU + tf.minimum(., relu_cutoff) +
  * tf.layers.dropout: asr/util/tf_contrib.py:50-61,122-135, asr/model.py:219-225) --------------

@@ -267,7 +267,9 @@ def _recurrence_float64(cell, xw, w_hh, b_hh, seq_len):
                             torch.zeros_like(steps))
             x = x64[t, rows, d]
             rec = h @ w64[d].t()
-            if cell == 'lstm':
+            if cell == 'rnn_relu':
+                h_new = torch.relu(x + rec)
+            elif cell == 'lstm':
                 i, f, g, o = (x + rec).split(hidden, dim=1)
                 c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
                 h_new = torch.sigmoid(o) * torch.tanh(c_new)
@@ -1084,3 +1086,75 @@ def test_a_set_time_out_word_ends_every_later_launch_at_once(hip, flags):
     y3, _, _ = hip.rnn_fwd('lstm', xw, w_hh, workspace=ws, flags=flags)
     hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
     assert torch.equal(y3, y)
+
+
+@pytest.mark.parametrize('dims', [(12, 16, 2048), (40, 5, 2048), (9, 11, 2048)])
+def test_relu_recurrence_on_the_fp16_matrix_pipe(hip, dims):
+    """CTCASR_RNN_F16 for the ReLU cell at H = 2048 - the reference's default model
+    (asr/params.py:43-50) - forward and backward (`prnn_relu16_kernel`): h and dpre have no bound, so
+    both are published as two fp16 pieces under a power of two per (producer workgroup, row).
+    Against the float64 recurrence / autograd next to the fp32 kernels' errors, with a recurrent
+    matrix that lets h grow over the steps and gradients over five decades of rows; bias in the
+    kernel; bias gradient; column maxima exact; step ranges bit-identical; per-row lengths and
+    bigger batches fall back to the fp32 kernels."""
+    num_steps, batch, hidden = dims
+    g = torch.Generator(device=DEV).manual_seed(51)
+    xw = torch.randn(num_steps, batch, 2, hidden, device=DEV, generator=g)
+    w_hh = torch.randn(2, hidden, hidden, device=DEV, generator=g) * (1.3 / np.sqrt(hidden))
+    bias = torch.randn(2 * hidden, device=DEV, generator=g) * 0.3
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g) * \
+        torch.logspace(-5, 0, batch, device=DEV).view(1, batch, 1)
+    assert hip.rnn_f16_recurrence('rnn_relu', num_steps, batch, hidden, hip.RNN_F16)
+    assert not hip.rnn_f16_recurrence('rnn_relu', num_steps, batch, hidden, hip.RNN_F16, ragged=True)
+    assert not hip.rnn_f16_recurrence('rnn_relu', num_steps, 20, hidden, hip.RNN_F16)
+    assert not hip.rnn_fwd_f16_supported('rnn_relu', num_steps, batch, hidden)     # (no y_pieces)
+    xb = (xw + bias.view(1, 1, 2, hidden)).double().requires_grad_(True)
+    ref_y = _recurrence_float64('rnn_relu', xb, w_hh, None, None)
+    (ref_y * dy.double()).sum().backward()
+    ref_dxw = xb.grad
+    y16, reserve, ws = hip.rnn_fwd('rnn_relu', xw, w_hh, xw_bias=bias, flags=hip.RNN_F16)
+    y32, reserve32, _ = hip.rnn_fwd('rnn_relu', xw, w_hh, xw_bias=bias, workspace=ws)
+    hip.rnn_poll_error('rnn_relu', ws, num_steps, batch, hidden)
+    assert not torch.equal(y16, y32)
+    scale = float(ref_y.abs().max())
+    e16, e32 = float((y16.double() - ref_y).abs().max()), float((y32.double() - ref_y).abs().max())
+    assert e16 < 3 * e32 + 1e-6 * scale, (e16, e32, scale)
+    # backward from the SAME y (the fp32 kernel's) so that the masks y > 0 agree
+    w_hh_t = hip.transpose_batched(w_hh)
+    db16, db32 = torch.zeros(2 * hidden, device=DEV), torch.zeros(2 * hidden, device=DEV)
+    colmax = torch.zeros(2 * hidden, dtype=torch.int32, device=DEV)
+    dxw32 = hip.rnn_bwd('rnn_relu', dy, y32, w_hh_t, reserve32, dbias=db32, workspace=ws)
+    dxw16 = hip.rnn_bwd('rnn_relu', dy, y32, w_hh_t, reserve32, dbias=db16, workspace=ws,
+                        flags=hip.RNN_F16, colmax=colmax)
+    hip.rnn_poll_error('rnn_relu', ws, num_steps, batch, hidden)
+    assert not torch.equal(dxw16, dxw32)
+    # (the float64 reference's mask comes from its own y: compare where the masks agree)
+    same = ((ref_y > 0) == (y32.double() > 0)).view(num_steps, batch, 2, hidden)
+
+    def row_err(got):
+        err = ((got.double() - ref_dxw).abs() * same).amax(dim=(0, 2, 3))
+        return float((err / ref_dxw.abs().amax(dim=(0, 2, 3)).clamp_min(1e-30)).max())
+    assert row_err(dxw16) < 3 * row_err(dxw32) + 1e-6, (row_err(dxw16), row_err(dxw32))
+    assert float((db16 - db32).abs().max()) < 1e-4 * max(1.0, float(db32.abs().max()))
+    assert torch.equal(colmax.view(torch.float32), dxw16.abs().amax(dim=(0, 1)).reshape(-1))
+    if num_steps >= 9:
+        cuts = [0, 3, num_steps // 2, num_steps]
+        y_cut = torch.full_like(y16, float('nan'))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            hip.rnn_fwd('rnn_relu', xw, w_hh, y=y_cut, reserve=reserve, workspace=ws,
+                        steps=(lo, hi), xw_bias=bias, flags=hip.RNN_F16)
+        assert torch.equal(y_cut, y16)
+        dxw_cut = torch.full_like(dxw16, float('nan'))
+        db_cut, colmax_cut = torch.zeros_like(db16), torch.zeros_like(colmax)
+        for hi, lo in zip(cuts[::-1][:-1], cuts[::-1][1:]):
+            hip.rnn_bwd('rnn_relu', dy, y32, w_hh_t, reserve32, dxw=dxw_cut, dbias=db_cut,
+                        workspace=ws, steps=(lo, hi), flags=hip.RNN_F16, colmax=colmax_cut)
+        hip.rnn_poll_error('rnn_relu', ws, num_steps, batch, hidden)
+        assert torch.equal(dxw_cut, dxw16) and torch.equal(colmax_cut, colmax)
+    # per-row lengths: the fp32 kernel runs, whatever the flag says
+    sl = torch.full((batch,), num_steps, dtype=torch.int32, device=DEV)
+    sl[-1] = max(1, num_steps - 2)
+    y_len, _, _ = hip.rnn_fwd('rnn_relu', xw, w_hh, sl, xw_bias=bias, workspace=ws,
+                               flags=hip.RNN_F16)
+    y_len32, _, _ = hip.rnn_fwd('rnn_relu', xw, w_hh, sl, xw_bias=bias, workspace=ws)
+    assert torch.equal(y_len, y_len32)

@@ -1252,8 +1252,28 @@ class CTCModel:
         # backlog, so the collective hides behind the layers below (engine.Trainer)
         early = self.early_hooks
 
+        # dense4's kernel gradient flat^T dz in the fp16 form (round 5; it was the last big bf16 x 6
+        # product of the step, 1.46 ms on the side stream at C3): the forward pass's fp16 pieces of
+        # the recurrent stack's output (fixed scale, or per-column scales behind a ReLU cell)
+        # against dz scaled per column like a layer's dxw
+        flat16 = acts.get('flat16')
+        k4_f16 = (self.bwd_f16 and k4_split is not None and flat16 is not None and
+                  self.split_wgrad and os.environ.get('CTCASR_DENSE4_WGRAD_F16', '1') == '1')
+        acts['arithmetic']['dense4/kernel_gradient'] = \
+            'fp16x3' if k4_f16 else ('bf16x6' if k4_split is not None else 'fp32')
+
         def dense4_weight_grad(dz_split=dz_split):
-            if k4_split is not None:
+            if k4_f16:
+                dz16, dz_inv = split_gemm.wgrad16_operand(dz)
+                pieces, scale = flat16[0], flat16[1]
+                inv = getattr(flat16, 'col_inv', None)
+                if inv is None:
+                    inv = torch.ones(pieces.cols, dtype=torch.float32, device=dz.device)
+                g['dense4/kernel'].zero_()
+                split_gemm.wgrad16(g['dense4/kernel'], pieces.buf, inv,
+                                   split_gemm.Split(dz16, split_gemm.H_B), scale, 0,
+                                   x_col_inv=dz_inv)
+            elif k4_split is not None:
                 if dz_split is None:
                     dz_split = split_gemm.split(dz, split_gemm.B_ORDER)
                 if acts['flat_split'] is None:      # (the forward pass used fp16 pieces)

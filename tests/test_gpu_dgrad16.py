@@ -167,3 +167,45 @@ def test_weight_pieces_saturate_and_cover_ragged_column_counts(hip):
     assert packed.numel() == 2 * 128 * 19 * 2048
     assert torch.isfinite(packed.view(torch.float16).float()).all()
     assert float(packed.view(torch.float16).float().abs().max()) <= 60000.0
+
+
+@pytest.mark.parametrize('batch,frames', [(32, 399), (16, 329)])
+def test_the_model_takes_the_kernel_and_its_schedules_agree(hip, batch, frames):
+    """`CTCModel.backward` with the own data-gradient kernel (the default for LSTM-1024) against
+    the library form (CTCASR_OWN_DGRAD=0) on the same weights and batch - every gradient slice -
+    and the kernel's optional schedules (`dgrad_early`: a finished direction's share of a step
+    range multiplied beside the next recurrence launch, on the side stream / a stream of its own)
+    against the plain one; T' odd in the second case (the two directions' ranges overlap by a row)."""
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=2, num_units_rnn=H, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0, conv_dropout_rate=0.0)
+    rng = np.random.default_rng(3)
+    feats = torch.tensor(rng.normal(size=(batch, frames, 80)).astype(np.float32), device=DEV)
+    flen = torch.full((batch,), frames, dtype=torch.int32)
+    labels = [list(rng.integers(1, 28, size=20)) for _ in range(batch)]
+
+    def grads(own, early):
+        model = CTCModel(cfg, DEV, seed=5)
+        model.own_dgrad, model.dgrad_early = own, early
+        loss = model.forward_backward(feats, flen, labels)
+        torch.cuda.synchronize()
+        model.check_rnn_error()
+        return float(loss), model.arena.grad.clone(), model
+
+    loss_lib, grad_lib, _ = grads(False, '0')
+    loss_own, grad_own, model = grads(True, '0')
+    arith = model.arithmetic()
+    assert arith['rnn1/data_gradient'].startswith('fp16x3 block-scaled')
+    assert arith['rnn0/data_gradient'].startswith('fp16x3 block-scaled')
+    assert loss_lib == loss_own                      # (the forward pass is the same)
+    for name, a, b in model.arena.layer_slices:
+        ref = grad_lib[a:b].double()
+        rel = float((ref - grad_own[a:b].double()).norm() / ref.norm().clamp_min(1e-30))
+        assert rel < 2e-5, (name, rel)               # both are fp32-grade forms of one product
+    for early in ('side', 'own'):
+        _, grad_e, _ = grads(True, early)
+        for name, a, b in model.arena.layer_slices:
+            ref = grad_own[a:b].double()
+            rel = float((ref - grad_e[a:b].double()).norm() / ref.norm().clamp_min(1e-30))
+            assert rel < 2e-6, (early, name, rel)    # the same products, summed in another order

@@ -255,6 +255,9 @@ def _cpu_baseline_worker(spec):
                       'sweep': {str(k): round(v, 3) for k, v in sweep.items()}}))
 
 
+T_PROCESS_START = time.time()
+
+
 def host_cores():
     """(usable logical CPUs, physical cores among them)."""
     try:
@@ -1064,7 +1067,14 @@ def merge_release_modes(legs, stub):
     # (a mode in which any rank reported an error - e.g. a recurrence time-out under the early
     # release - is never the chosen one while another mode ran clean)
     result['allreduce']['choice_rule'] = 'fastest mode without a failed rank'
-    return result
+    # the number an N > 1 reader looks for first, right behind `value` in the printed line
+    front = {}
+    for key, val in result.items():
+        front[key] = val
+        if key == 'value':
+            front['exposed_allreduce_frac_of_step'] = \
+                result['allreduce']['exposed_allreduce_frac_of_step']
+    return front
 
 
 def free_port():
@@ -1097,6 +1107,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-workloads', action='store_true',
                     help='skip the secondary C2 measurement of the default N = 1 run')
+    ap.add_argument('--leg-budget', type=float, default=900.0,
+                    help='N > 1: seconds of wall clock after which no further release-mode leg is '
+                         'started (the stubbed leg always runs)')
     ap.add_argument('--no-reference-models', action='store_true',
                     help='skip ref_default / ref_best (the reference\'s own configurations) among '
                          'the other workloads of the default N = 1 run')
@@ -1186,14 +1199,26 @@ def main():
         # the contract's protocol), then the same step with the collectives stubbed out.  `value`
         # is the better mode's; everything measured is in `allreduce.modes`.
         forced = os.environ.get('CTCASR_ALLREDUCE_EARLY')
-        legs = {}
+        legs, skipped = {}, []
         for mode in (('early',) if forced == '1' else ('held',) if forced == '0'
                      else ('held', 'early')):
+            # (the run bounds itself: a leg that would start after --leg-budget seconds of wall
+            # clock is skipped and named - every rank decides on rank 0's clock)
+            late = torch.tensor([1.0 if legs and time.time() - T_PROCESS_START > args.leg_budget
+                                 else 0.0], device='cuda:{}'.format(local_rank))
+            dist.broadcast(late, src=0)
+            if late.item():
+                skipped.append(mode)
+                continue
             legs[mode], shape = measure(args.workload, args, rank, local_rank, world,
                                         allreduce_early=(mode == 'early'))
         stub, _ = measure(args.workload, args, rank, local_rank, world, reduce=False)
         cfg, frames, batch, seconds = shape
         result = merge_release_modes(legs, stub) if rank == 0 else None
+        if rank == 0 and skipped:
+            result['allreduce']['skipped_modes'] = {
+                m: 'not started: {:.0f} s of wall clock were spent (--leg-budget)'.format(
+                    args.leg_budget) for m in skipped}
         if rank == 0 and 'failed' in result['allreduce']:
             exit_code = 4                # every measured mode failed: the line says why
     if world == 1 and args.workload == 'c3' and not args.no_other_workloads:

@@ -223,6 +223,9 @@ def test_bench_two_ranks_on_one_gpu_report_both_release_modes():
         assert info['mode'] == mode and info['launches_per_step'] >= 1
         assert len(info['rank_ms_per_step']['all']) == 2
         assert 'exposed_allreduce_ms' in info
+    assert line['exposed_allreduce_frac_of_step'] == \
+        line['allreduce']['exposed_allreduce_frac_of_step']     # (up front, behind `value`)
+    assert list(line).index('exposed_allreduce_frac_of_step') == list(line).index('value') + 1
     assert line['allreduce']['chosen'] in modes
     assert line['allreduce']['stubbed_ms_per_step'] > 0
 

@@ -104,6 +104,11 @@ SIGNATURES = {
                                       _c_int, _c_p]),
     'ctcasr_rnn_f16_recurrence': (_c_int, [_c_int] * 7),
     'ctcasr_collective_traffic': (_c_int, [_c_int, _c_int, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
+    'ctcasr_wgrad16_packed_bytes': (_c_sz, [_c_int, _c_int]),
+    'ctcasr_wgrad16_pack': (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_int, _c_p, _c_f, _c_p,
+                                     _c_p]),
+    'ctcasr_wgrad16_gemm': (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p,
+                                     _c_i64, _c_p, _c_int, _c_int, _c_f, _c_p, _c_i64, _c_p]),
     'ctcasr_dgrad16_packed_bytes': (_c_sz, [_c_int]),
     'ctcasr_dgrad16_pack_weights': (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_f, _c_p, _c_p]),
     'ctcasr_dgrad16_supported': (_c_int, [_c_int] * 4),
@@ -694,6 +699,47 @@ def dgrad16_supported(cell, num_steps, batch, hidden):
     what the fp16-pipe LSTM-1024 backward recurrence published; include/ctcasr.h, ABI v6)."""
     return bool(load().ctcasr_dgrad16_supported(CELL_IDS[cell], int(num_steps), int(batch),
                                                 int(hidden)))
+
+
+@_on_tensor_device
+def wgrad16_pack(x, rows_total, row0, stages, scale, col_scale=None, out=None):
+    """Rows [row0, row0 + 32 * stages) of ``x`` (an f32 matrix view [>= rows_total, cols] with unit
+    column stride; rows outside [0, rows_total) read as zeros), every column times col_scale[c]
+    times scale, as fp16 pieces transposed into MFMA fragment order (include/ctcasr.h:
+    ctcasr_wgrad16_pack) - an operand of `wgrad16_gemm`.  uint8 buffer."""
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1:
+        raise CtcAsrError('wgrad16_pack: x must be an f32 matrix in HBM with unit column stride.')
+    cols = x.shape[1]
+    need = load().ctcasr_wgrad16_packed_bytes(int(stages), cols)
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=x.device)
+    elif out.dtype != torch.uint8 or out.numel() < need or not out.is_contiguous():
+        raise CtcAsrError('wgrad16_pack: out must be a contiguous uint8 buffer of {} bytes.'
+                          .format(need))
+    _check(load().ctcasr_wgrad16_pack(
+        x.data_ptr(), x.stride(0), int(rows_total), cols, int(row0), int(stages),
+        _dev(col_scale, name='col_scale'), float(scale), out.data_ptr(), _stream()),
+        'wgrad16_pack')
+    return out
+
+
+@_on_tensor_device
+def wgrad16_gemm(d_packed, m, stages, inv_scale, x_packed, x_stage0, x_scale, dw_x,
+                 y_packed=None, y_stage0=0, y_scale=1.0, dw_y=None):
+    """dw_x [m, nx] += D^T X and (optional) dw_y [m, ny] += D^T Y over `stages` stages of 32 rows,
+    from operands packed by `wgrad16_pack` (include/ctcasr.h: ctcasr_wgrad16_gemm)."""
+    for name, t in (('dw_x', dw_x), ('dw_y', dw_y)):
+        if t is not None and (t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or
+                              t.stride(1) != 1 or t.shape[0] != m):
+            raise CtcAsrError('wgrad16_gemm: {} must be an f32 [m, n] view in HBM with unit '
+                              'column stride.'.format(name))
+    _check(load().ctcasr_wgrad16_gemm(
+        d_packed.data_ptr(), int(m), int(stages), _dev(inv_scale, name='inv_scale'),
+        x_packed.data_ptr(), int(x_stage0), dw_x.shape[1], float(x_scale), dw_x.data_ptr(),
+        dw_x.stride(0), None if y_packed is None else y_packed.data_ptr(), int(y_stage0),
+        0 if dw_y is None else dw_y.shape[1], float(y_scale),
+        None if dw_y is None else dw_y.data_ptr(), 0 if dw_y is None else dw_y.stride(0),
+        _stream()), 'wgrad16_gemm')
 
 
 def dgrad16_packed_bytes(n):

@@ -486,6 +486,27 @@ int ctcasr_dgrad16_blockscaled(void *workspace, int T, int B, int hidden, const 
                                float scale, int n, float *dx, int64_t ld_dx, int t_lo, int t_hi,
                                int dir_lo, int dir_hi, int accumulate, ctcasr_stream_t stream);
 
+/* ABI v6: the weight gradients of a recurrent layer's two matrices for one direction and step range
+ * as one own kernel (csrc/wgrad16.hip; TensorFlow: cuDNN's RNN backward-weights, asr/model.py:194-215):
+ *   dW_x[m, nx] += D^T X,  dW_y[m, ny] += D^T Y      (sums over the ROWS of D / X / Y)
+ * from operands packed transposed - K = the row axis - as fp16 pieces in MFMA fragment order:
+ * ctcasr_wgrad16_pack writes rows [row0, row0 + 32 * stages) of x [rows_total, cols] (leading
+ * dimension ld_x; rows outside [0, rows_total) read as zeros - a negative / positive row0 shifts
+ * an operand by time steps), each column times col_scale[c] (NULL: 1) times scale, saturating at
+ * +-60000, into ctcasr_wgrad16_packed_bytes(stages, cols) bytes.  ctcasr_wgrad16_gemm multiplies
+ * `stages` stages of the packed D (m columns, inverse column scales inv_scale[m]) into stages
+ * [x_stage0, x_stage0 + stages) of the packed X (nx columns, fixed scale x_scale) and - optional -
+ * of the packed Y, and ACCUMULATES into dW_x / dW_y (row-major, leading dimensions ld_*): two fp16
+ * pieces per operand, three products, fp32 accumulation, no library GEMM. */
+size_t ctcasr_wgrad16_packed_bytes(int stages, int cols);
+int ctcasr_wgrad16_pack(const float *x, int64_t ld_x, int64_t rows_total, int cols, int64_t row0,
+                        int stages, const float *col_scale, float scale, void *packed,
+                        ctcasr_stream_t stream);
+int ctcasr_wgrad16_gemm(const void *d_packed, int m, int stages, const float *inv_scale,
+                        const void *x_packed, int x_stage0, int nx, float x_scale, float *dw_x,
+                        int64_t ld_x, const void *y_packed, int y_stage0, int ny, float y_scale,
+                        float *dw_y, int64_t ld_y, ctcasr_stream_t stream);
+
 /* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
  * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):
  *   lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step);  m, v updated in place;

@@ -1,0 +1,94 @@
+"""The own weight-gradient kernel (csrc/wgrad16.hip, ABI v6): dW_x += D^T X, dW_y += D^T Y over
+the rows of a step range - the gradients of a cuDNN layer's two matrices (asr/model.py:194-215) -
+from operands packed transposed as fp16 pieces.  Against float64 next to the library's fp32 GEMM."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    from ctc_asr_amd import hip as hip_mod
+    hip_mod.load()
+    return hip_mod
+
+
+def own_wgrad(hip, d, x, x_scale, y=None, y_shift=0, y_scale=1.0, row_lo=0, row_hi=None):
+    """dW_x, dW_y of rows [row_lo, row_hi) of d against the same rows of x and rows shifted by
+    ``y_shift`` of y (zeros outside), through ctcasr_wgrad16_pack / _gemm."""
+    row_hi = d.shape[0] if row_hi is None else row_hi
+    n_rows = row_hi - row_lo
+    stages = (n_rows + 31) // 32
+    scale, inv = hip.colmax_scale(d[row_lo:row_hi])
+    d_pk = hip.wgrad16_pack(d[row_lo:row_hi], n_rows, 0, stages, 1.0, col_scale=scale)
+    x_pk = hip.wgrad16_pack(x[row_lo:], min(n_rows, x.shape[0] - row_lo), 0, stages, x_scale)
+    dw_x = torch.zeros(d.shape[1], x.shape[1], device=DEV)
+    dw_y = y_pk = None
+    if y is not None:
+        # rows [row_lo + shift, ...) of y; rows outside [0, len(y)) read as zeros
+        y_pk = hip.wgrad16_pack(y, y.shape[0], row_lo + y_shift, stages, y_scale)
+        dw_y = torch.zeros(d.shape[1], y.shape[1], device=DEV)
+    hip.wgrad16_gemm(d_pk, d.shape[1], stages, inv, x_pk, 0, x_scale, dw_x,
+                     y_packed=y_pk, y_stage0=0, y_scale=y_scale, dw_y=dw_y)
+    return dw_x, dw_y
+
+
+def errors(got, ref):
+    err = got.double() - ref
+    return float(err.norm() / ref.norm()), \
+        float((err.abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-300)).max())
+
+
+@pytest.mark.parametrize('rows,m,nx,ny,shift', [(8000, 4096, 2048, 1024, -32), (1456, 512, 640, 256, 16),
+                                                (100, 300, 48, 272, -16), (32, 16, 16, 16, 16)])
+def test_against_float64_next_to_the_fp32_gemm(hip, rows, m, nx, ny, shift):
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    d = torch.randn(rows, m, device=DEV, generator=g)
+    d *= torch.logspace(-9, -3, m, device=DEV)[torch.randperm(m, device=DEV, generator=g)]
+    d *= torch.logspace(-3, 0, rows, device=DEV).view(-1, 1)
+    x = torch.rand(rows, nx, device=DEV, generator=g) * 2 - 1          # |x| <= 1: scale 2^15
+    y = torch.rand(rows, ny, device=DEV, generator=g) * 2 - 1
+    dw_x, dw_y = own_wgrad(hip, d, x, 32768.0, y, shift, 32768.0)
+    ref_x = d.double().t() @ x.double()
+    y_sh = torch.zeros_like(y)
+    if shift < 0:
+        y_sh[-shift:] = y[:shift]
+    else:
+        y_sh[:rows - shift] = y[shift:]
+    ref_y = d.double().t() @ y_sh.double()
+    for got, ref, lib in ((dw_x, ref_x, torch.mm(d.t(), x)), (dw_y, ref_y, torch.mm(d.t(), y_sh))):
+        rms, row = errors(got, ref)
+        rms32, row32 = errors(lib, ref)
+        assert torch.isfinite(got).all()
+        assert rms < 2.0 * rms32 + 1e-7 and row < 3.0 * row32 + 1e-7, (rms, rms32, row, row32)
+
+
+def test_ranges_accumulate_and_only_one_operand(hip):
+    g = torch.Generator(device=DEV).manual_seed(4)
+    rows, m, nx = 640, 256, 512
+    d = torch.randn(rows, m, device=DEV, generator=g) * 1e-4
+    x = torch.rand(rows, nx, device=DEV, generator=g) * 40 - 20        # clipped-ReLU range: 2^11
+    whole, none = own_wgrad(hip, d, x, 2048.0)
+    assert none is None
+    a, _ = own_wgrad(hip, d, x, 2048.0, row_lo=0, row_hi=352)
+    b, _ = own_wgrad(hip, d, x, 2048.0, row_lo=352, row_hi=640)
+    ref = d.double().t() @ x.double()
+    assert errors(a + b, ref)[0] < 2e-6 and errors(whole, ref)[0] < 2e-6
+    # the kernel accumulates into what is there
+    scale, inv = hip.colmax_scale(d)
+    d_pk = hip.wgrad16_pack(d, rows, 0, 20, 1.0, col_scale=scale)
+    x_pk = hip.wgrad16_pack(x, rows, 0, 20, 2048.0)
+    out = torch.full((m, nx), 3.0, device=DEV)
+    hip.wgrad16_gemm(d_pk, m, 20, inv, x_pk, 0, 2048.0, out)
+    assert errors(out - 3.0, ref)[0] < 1e-5
+    # a stage offset into a second operand packed for all rows
+    part = torch.zeros(m, nx, device=DEV)
+    d2_pk = hip.wgrad16_pack(d[320:], 320, 0, 10, 1.0, col_scale=scale)
+    hip.wgrad16_gemm(d2_pk, m, 10, inv, x_pk, 10, 2048.0, part)
+    assert errors(part, d[320:].double().t() @ x[320:].double())[0] < 2e-6

@@ -44,6 +44,8 @@ struct WgArgs {
     float alpha[2];         // 1 / scale of the second operands
     int m, n[2], stage0[2]; // first stage of the range inside b[k]
     int stages, m_tiles, n_tiles[2], tiles_n[2], tiles_m;
+    int parts;              // row ranges one tile's sum is cut into (one workgroup each)
+    int *sync;              // [1 + tiles]: time-out word, then the part whose turn it is to add
 };
 
 __device__ __forceinline__ void wg_dma16(const char *base, unsigned lane_off, unsigned lds_base) {
@@ -62,7 +64,11 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
     const int wr = wave >> 2, wc = wave & 3;
     // tile list: operand 0's tiles_m x tiles_n[0], then operand 1's; within an operand the tiles
     // of one row of tiles are neighbours (they share the A panel in L2)
-    int v = blockIdx.x, which = 0;
+    const int tiles_all = p.tiles_m * (p.tiles_n[0] + p.tiles_n[1]);
+    const int part = blockIdx.x / tiles_all, tile_id = blockIdx.x % tiles_all;
+    const int s_lo = (int)((int64_t)p.stages * part / p.parts);
+    const int s_hi = (int)((int64_t)p.stages * (part + 1) / p.parts);
+    int v = tile_id, which = 0;
     if (v >= p.tiles_m * p.tiles_n[0]) {
         v -= p.tiles_m * p.tiles_n[0];
         which = 1;
@@ -102,13 +108,13 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) total[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(0, lds0);
-    for (int s = 0; s < p.stages; ++s) {
-        const int par = s & 1;
+    issue(s_lo, lds0);
+    for (int s = s_lo; s < s_hi; ++s) {
+        const int par = (s - s_lo) & 1;
         const char *cur = smem + par * WG_STAGE_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < p.stages) issue(s + 1, lds0 + (par ^ 1) * WG_STAGE_BYTES);
+        if (s + 1 < s_hi) issue(s + 1, lds0 + (par ^ 1) * WG_STAGE_BYTES);
         const char *a_rd = cur + wr * (8 * 2048) + lane * 16;
         const char *b_rd = cur + WG_A_BYTES + wc * (4 * 2048) + lane * 16;
         WgFrag x1[4], x2[4];
@@ -140,8 +146,56 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
     const int64_t ld = p.ld[which];
     const float alpha = p.alpha[which];
     const int n_cols = p.n[which];
+    if (p.parts == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (mt0 + 8 * wr + i) * 16 + 4 * (lane >> 4) + r;
+                if (m >= p.m) continue;
+                const float scale = p.inv[m] * alpha;
+                float *row = out + (int64_t)m * ld;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = (nt0 + 4 * wc + j) * 16 + (lane & 15);
+                    if (n < n_cols) row[n] += total[i][j][r] * scale;
+                }
+            }
+        }
+        return;
+    }
+    // The parts of a tile add in order (the same sums on every run): part q waits for the tile's
+    // word to read q.  Part q - 1 has a lower workgroup id, was dispatched before and waits only
+    // on lower ids itself.  dW and the word are read and written at agent scope access by access
+    // (sc1 loads / write-through stores): another XCD's L2 never holds a stale or a dirty line of
+    // them, and no workgroup has to write back or invalidate a whole L2 - which would cost every
+    // other workgroup of its XCD the operand panels they share there.
+    int *turn = p.sync + 1 + tile_id;
+    if (tid == 0 && part > 0) {
+        long spins = 0;
+        while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != part) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1L << 24)) {
+                __hip_atomic_store(p.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        float have[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = (mt0 + 8 * wr + i) * 16 + 4 * (lane >> 4) + r;
+            float *row = out + (int64_t)m * ld;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (nt0 + 4 * wc + j) * 16 + (lane & 15);
+                have[r][j] = (m < p.m && n < n_cols)
+                    ? __hip_atomic_load(row + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = (mt0 + 8 * wr + i) * 16 + 4 * (lane >> 4) + r;
@@ -151,10 +205,18 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = (nt0 + 4 * wc + j) * 16 + (lane & 15);
-                if (n < n_cols) row[n] += total[i][j][r] * scale;
+                if (n < n_cols)
+                    __hip_atomic_store(row + n, have[r][j] + total[i][j][r] * scale,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
+    // every store of this workgroup acknowledged at agent scope, then the word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(turn, part + 1 == p.parts ? 0 : part + 1, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // rows [row0, row0 + 32 * stages) of x [rows_total, ld] (zeros outside [0, rows_total)), columns
@@ -195,6 +257,11 @@ extern "C" size_t ctcasr_wgrad16_packed_bytes(int stages, int cols) {
     return stages > 0 && cols > 0 ? (size_t)stages * ((cols + 15) / 16) * 2048 : 0;
 }
 
+extern "C" size_t ctcasr_wgrad16_sync_ints(int m, int nx, int ny) {
+    const int tm = (m + WG_TILE - 1) / WG_TILE;
+    return 1 + (size_t)tm * ((nx + WG_TILE - 1) / WG_TILE + (ny > 0 ? (ny + WG_TILE - 1) / WG_TILE : 0));
+}
+
 extern "C" int ctcasr_wgrad16_pack(const float *x, int64_t ld_x, int64_t rows_total, int cols,
                                    int64_t row0, int stages, const float *col_scale, float scale,
                                    void *packed, ctcasr_stream_t stream) {
@@ -212,9 +279,10 @@ extern "C" int ctcasr_wgrad16_gemm(const void *d_packed, int m, int stages, cons
                                    const void *x_packed, int x_stage0, int nx, float x_scale,
                                    float *dw_x, int64_t ld_x, const void *y_packed, int y_stage0,
                                    int ny, float y_scale, float *dw_y, int64_t ld_y,
-                                   ctcasr_stream_t stream) {
+                                   int parts, int32_t *sync, ctcasr_stream_t stream) {
     if (!d_packed || !inv_scale || !x_packed || !dw_x || m <= 0 || stages <= 0 || nx <= 0 ||
         ld_x < nx || x_stage0 < 0 || !(x_scale > 0.f) ||
+        parts < 1 || parts > stages || (parts > 1 && !sync) ||
         (y_packed && (!dw_y || ny <= 0 || ld_y < ny || y_stage0 < 0 || !(y_scale > 0.f))))
         return CTCASR_ERR_BAD_ARGUMENT;
     static bool attr_set = false;
@@ -238,7 +306,8 @@ extern "C" int ctcasr_wgrad16_gemm(const void *d_packed, int m, int stages, cons
         a.alpha[1] = 1.0f / y_scale; a.out[1] = dw_y; a.ld[1] = ld_y;
         a.n_tiles[1] = (ny + 15) / 16; a.tiles_n[1] = (ny + WG_TILE - 1) / WG_TILE;
     }
-    const int tiles = a.tiles_m * (a.tiles_n[0] + a.tiles_n[1]);
+    a.parts = parts; a.sync = sync;
+    const int tiles = a.tiles_m * (a.tiles_n[0] + a.tiles_n[1]) * parts;
     wgrad16_kernel<<<tiles, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(a);
     return ctcasr_launch_status();
 }

@@ -108,7 +108,9 @@ SIGNATURES = {
     'ctcasr_wgrad16_pack': (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_int, _c_p, _c_f, _c_p,
                                      _c_p]),
     'ctcasr_wgrad16_gemm': (_c_int, [_c_p, _c_int, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p,
-                                     _c_i64, _c_p, _c_int, _c_int, _c_f, _c_p, _c_i64, _c_p]),
+                                     _c_i64, _c_p, _c_int, _c_int, _c_f, _c_p, _c_i64, _c_int, _c_p,
+                                     _c_p]),
+    'ctcasr_wgrad16_sync_ints': (_c_sz, [_c_int, _c_int, _c_int]),
     'ctcasr_dgrad16_packed_bytes': (_c_sz, [_c_int]),
     'ctcasr_dgrad16_pack_weights': (_c_int, [_c_p, _c_i64, _c_int, _c_int, _c_f, _c_p, _c_p]),
     'ctcasr_dgrad16_supported': (_c_int, [_c_int] * 4),
@@ -725,9 +727,18 @@ def wgrad16_pack(x, rows_total, row0, stages, scale, col_scale=None, out=None):
 
 @_on_tensor_device
 def wgrad16_gemm(d_packed, m, stages, inv_scale, x_packed, x_stage0, x_scale, dw_x,
-                 y_packed=None, y_stage0=0, y_scale=1.0, dw_y=None):
+                 y_packed=None, y_stage0=0, y_scale=1.0, dw_y=None, parts=1):
     """dw_x [m, nx] += D^T X and (optional) dw_y [m, ny] += D^T Y over `stages` stages of 32 rows,
-    from operands packed by `wgrad16_pack` (include/ctcasr.h: ctcasr_wgrad16_gemm)."""
+    from operands packed by `wgrad16_pack` (include/ctcasr.h: ctcasr_wgrad16_gemm).  `parts`
+    workgroups per tile add in order through the device's zeroed sync words."""
+    parts = max(1, min(int(parts), int(stages)))
+    sync = None
+    if parts > 1:
+        need = load().ctcasr_wgrad16_sync_ints(int(m), dw_x.shape[1], 0 if dw_y is None else dw_y.shape[1])
+        sync = _WGRAD16_SYNC.get(dw_x.device.index)
+        if sync is None or sync.numel() < need:
+            sync = _WGRAD16_SYNC[dw_x.device.index] = torch.zeros(max(need, 4096), dtype=torch.int32,
+                                                            device=dw_x.device)
     for name, t in (('dw_x', dw_x), ('dw_y', dw_y)):
         if t is not None and (t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or
                               t.stride(1) != 1 or t.shape[0] != m):
@@ -739,7 +750,18 @@ def wgrad16_gemm(d_packed, m, stages, inv_scale, x_packed, x_stage0, x_scale, dw
         dw_x.stride(0), None if y_packed is None else y_packed.data_ptr(), int(y_stage0),
         0 if dw_y is None else dw_y.shape[1], float(y_scale),
         None if dw_y is None else dw_y.data_ptr(), 0 if dw_y is None else dw_y.stride(0),
-        _stream()), 'wgrad16_gemm')
+        parts, None if sync is None else sync.data_ptr(), _stream()), 'wgrad16_gemm')
+
+
+_WGRAD16_SYNC = {}
+
+
+def wgrad16_gave_up_waiting(device):
+    """True if a part of a `wgrad16_gemm` launch on `device` ever stopped waiting for its turn
+    (the sticky word 0 of the sync words; synchronises)."""
+    device = torch.device(device)
+    sync = _WGRAD16_SYNC.get(torch.cuda.current_device() if device.index is None else device.index)
+    return bool(sync is not None and int(sync[0].item()) != 0)
 
 
 def dgrad16_packed_bytes(n):

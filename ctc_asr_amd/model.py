@@ -440,6 +440,13 @@ class CTCModel:
         # split of dxw, no library GEMM on the main stream - and so no "one library GEMM at a
         # time" wait for the side stream in front of it
         self.own_dgrad = os.environ.get('CTCASR_OWN_DGRAD', '1') == '1'
+        # the weight gradients of a recurrent layer (LSTM / plain cells, fixed-scale fp16 operands)
+        # through the own kernel (csrc/wgrad16.hip) instead of the library's TN GEMMs
+        self.own_wgrad = os.environ.get('CTCASR_OWN_WGRAD', '1') == '1'
+        # workgroups a tile's row sum is cut into (192 tiles of a direction's W_ih + W_hh at
+        # H = 1024 leave a quarter of the chip idle, or make 1.5 rounds on the half beside a
+        # recurrence launch)
+        self.own_wgrad_parts = int(os.environ.get('CTCASR_WGRAD_PARTS', '1'))
         # layers whose input has no bound (behind a ReLU-cell layer: the reference's default model)
         # in an fp16 form as well - the input split with a scale per ROW for the projection (as a
         # layer's dxw is for the data gradient), per COLUMN for the weight gradients
@@ -1381,12 +1388,33 @@ class CTCModel:
                                        out=drs.buf[rng, :, cols])
 
             def partial_weight_grads_f16(lo, hi, name=name, dxw2d=dxw2d, drec=drec, x16=x16,
-                                         y16=y16, colmax=None):
+                                         y16=y16, x=x, y=y, colmax=None):
                 # steps [lo, hi) in the fp16 form: per direction one column-scaled split of the
                 # finished rows of dxw (GRU: and of drec) feeds both W_ih's and W_hh's product
                 # (``colmax``: the column maxima of these rows, left by the recurrence launch)
+                own = (self.own_wgrad and cell != 'gru' and
+                       not isinstance(x16, split_gemm.ColScaled) and
+                       not isinstance(y16, split_gemm.ColScaled))
                 for d, (a, b) in enumerate(((lo, hi), (t_out - hi, t_out - lo))):
                     cols = slice(d * gh, (d + 1) * gh)
+                    if own:
+                        # one launch for both matrices: dxw's rows packed transposed with column
+                        # scales, the input's rows and the output's rows one step back / ahead
+                        # (zeros outside the sequence: h(-1) = h(T) = 0) with their fixed scales
+                        n_rows = (b - a) * batch
+                        stages = (n_rows + 31) // 32
+                        d_rows = dxw2d[a * batch:b * batch, cols]
+                        scale, inv = hip.colmax_scale(d_rows) if colmax is None else \
+                            hip.colscale_from_max(colmax[d * gh:(d + 1) * gh])
+                        d_pk = hip.wgrad16_pack(d_rows, n_rows, 0, stages, 1.0, col_scale=scale)
+                        x_pk = hip.wgrad16_pack(x.view(rows, -1), rows, a * batch, stages, x16[1])
+                        y_pk = hip.wgrad16_pack(
+                            y.view(rows, 2 * hidden)[:, d * hidden:(d + 1) * hidden], rows,
+                            (a + (1 if d else -1)) * batch, stages, y16[1])
+                        hip.wgrad16_gemm(d_pk, gh, stages, inv, x_pk, 0, x16[1],
+                                         g[name + '/w_ih'][d], y_packed=y_pk, y_scale=y16[1],
+                                         dw_y=g[name + '/w_hh'][d], parts=self.own_wgrad_parts)
+                        continue
                     d16, inv = split_gemm.wgrad16_operand(
                         dxw2d[a * batch:b * batch, cols],
                         None if colmax is None else colmax[d * gh:(d + 1) * gh])

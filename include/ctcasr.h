@@ -497,15 +497,21 @@ int ctcasr_dgrad16_blockscaled(void *workspace, int T, int B, int hidden, const 
  * `stages` stages of the packed D (m columns, inverse column scales inv_scale[m]) into stages
  * [x_stage0, x_stage0 + stages) of the packed X (nx columns, fixed scale x_scale) and - optional -
  * of the packed Y, and ACCUMULATES into dW_x / dW_y (row-major, leading dimensions ld_*): two fp16
- * pieces per operand, three products, fp32 accumulation, no library GEMM. */
+ * pieces per operand, three products, fp32 accumulation, no library GEMM.  Tiles of 256 x 256
+ * outputs; `parts` >= 1 cuts every tile's row sum into that many workgroups (for launches whose
+ * tiles alone do not fill the chip), which add to dW in part order through the words of `sync`
+ * (ctcasr_wgrad16_sync_ints(m, nx, ny) int32, ZERO before the first launch that uses them; every
+ * launch leaves them zero; word 0 turns 1 should a part give up waiting - sticky, never seen).
+ * sync may be NULL for parts == 1. */
 size_t ctcasr_wgrad16_packed_bytes(int stages, int cols);
+size_t ctcasr_wgrad16_sync_ints(int m, int nx, int ny);
 int ctcasr_wgrad16_pack(const float *x, int64_t ld_x, int64_t rows_total, int cols, int64_t row0,
                         int stages, const float *col_scale, float scale, void *packed,
                         ctcasr_stream_t stream);
 int ctcasr_wgrad16_gemm(const void *d_packed, int m, int stages, const float *inv_scale,
                         const void *x_packed, int x_stage0, int nx, float x_scale, float *dw_x,
                         int64_t ld_x, const void *y_packed, int y_stage0, int ny, float y_scale,
-                        float *dw_y, int64_t ld_y, ctcasr_stream_t stream);
+                        float *dw_y, int64_t ld_y, int parts, int32_t *sync, ctcasr_stream_t stream);
 
 /* ---- K12: TensorFlow-form Adam over a flat parameter arena ------------------------------------
  * Replaces tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).minimize (asr/model.py:80-83):

@@ -19,7 +19,7 @@ def hip():
     return hip_mod
 
 
-def own_wgrad(hip, d, x, x_scale, y=None, y_shift=0, y_scale=1.0, row_lo=0, row_hi=None):
+def own_wgrad(hip, d, x, x_scale, y=None, y_shift=0, y_scale=1.0, row_lo=0, row_hi=None, parts=1):
     """dW_x, dW_y of rows [row_lo, row_hi) of d against the same rows of x and rows shifted by
     ``y_shift`` of y (zeros outside), through ctcasr_wgrad16_pack / _gemm."""
     row_hi = d.shape[0] if row_hi is None else row_hi
@@ -35,7 +35,7 @@ def own_wgrad(hip, d, x, x_scale, y=None, y_shift=0, y_scale=1.0, row_lo=0, row_
         y_pk = hip.wgrad16_pack(y, y.shape[0], row_lo + y_shift, stages, y_scale)
         dw_y = torch.zeros(d.shape[1], y.shape[1], device=DEV)
     hip.wgrad16_gemm(d_pk, d.shape[1], stages, inv, x_pk, 0, x_scale, dw_x,
-                     y_packed=y_pk, y_stage0=0, y_scale=y_scale, dw_y=dw_y)
+                     y_packed=y_pk, y_stage0=0, y_scale=y_scale, dw_y=dw_y, parts=parts)
     return dw_x, dw_y
 
 
@@ -92,3 +92,56 @@ def test_ranges_accumulate_and_only_one_operand(hip):
     d2_pk = hip.wgrad16_pack(d[320:], 320, 0, 10, 1.0, col_scale=scale)
     hip.wgrad16_gemm(d2_pk, m, 10, inv, x_pk, 10, 2048.0, part)
     assert errors(part, d[320:].double().t() @ x[320:].double())[0] < 2e-6
+
+
+def test_parts_add_in_order(hip):
+    """A tile's row sum cut into workgroups: the same bits on every run, the float64 answer, and
+    the sync words back at zero."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    rows, m, nx, ny = 4000, 1024, 768, 512
+    d = torch.randn(rows, m, device=DEV, generator=g) * 1e-3
+    x = torch.rand(rows, nx, device=DEV, generator=g) * 2 - 1
+    y = torch.rand(rows, ny, device=DEV, generator=g) * 2 - 1
+    ref = d.double().t() @ x.double()
+    one = own_wgrad(hip, d, x, 32768.0, y, 0, 32768.0)
+    for parts in (2, 5, 8, 1000):
+        runs = [own_wgrad(hip, d, x, 32768.0, y, 0, 32768.0, parts=parts) for _ in range(3)]
+        for dw_x, dw_y in runs[1:]:
+            assert torch.equal(dw_x, runs[0][0]) and torch.equal(dw_y, runs[0][1])
+        assert errors(runs[0][0], ref)[0] < 2e-6
+        assert errors(runs[0][1], one[1].double())[0] < 1e-6
+    assert not hip.wgrad16_gave_up_waiting(DEV)
+    from ctc_asr_amd.hip import _WGRAD16_SYNC
+    assert int(_WGRAD16_SYNC[torch.cuda.current_device()].abs().sum()) == 0
+
+
+@pytest.mark.parametrize('batch,frames', [(32, 399), (16, 329), (20, 261)])
+def test_the_model_with_the_own_kernel_agrees_with_the_library_form(hip, batch, frames):
+    """`CTCModel.backward` with `own_wgrad` against the library's TN GEMMs on the same weights and
+    batch, every gradient slice; T' odd / rows of a range not a multiple of 32 in the later cases
+    (the last stage of a range is zero-filled, the shifted output rows cross the sequence ends)."""
+    from ctc_asr_amd.model import CTCModel, ModelConfig
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                      num_layers_rnn=2, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                      dense_dropout_rate=0.0, conv_dropout_rate=0.0)
+    rng = np.random.default_rng(3)
+    feats = torch.tensor(rng.normal(size=(batch, frames, 80)).astype(np.float32), device=DEV)
+    flen = torch.full((batch,), frames, dtype=torch.int32)
+    labels = [list(rng.integers(1, 28, size=20)) for _ in range(batch)]
+
+    def grads(own):
+        model = CTCModel(cfg, DEV, seed=5)
+        model.own_wgrad = own
+        loss = model.forward_backward(feats, flen, labels)
+        torch.cuda.synchronize()
+        model.check_rnn_error()
+        return float(loss), model.arena.grad.clone(), model
+
+    loss_lib, grad_lib, _ = grads(False)
+    loss_own, grad_own, model = grads(True)
+    assert loss_lib == loss_own
+    assert not hip.wgrad16_gave_up_waiting(DEV)
+    for name, a, b in model.arena.layer_slices:
+        ref = grad_lib[a:b].double()
+        rel = float((ref - grad_own[a:b].double()).norm() / ref.norm().clamp_min(1e-30))
+        assert rel < 2e-5, (name, rel)

@@ -41,13 +41,16 @@ def library():
     split_gemm.wgrad16(g_hh, d16, inv, y16, 32768.0, 8000 - B, x_cols=slice(0, H))
 
 
+PARTS = int(os.environ.get('PARTS', '4'))
+
+
 def own():
     scale, inv = hip.colscale_from_max(colmax)
     d_pk = hip.wgrad16_pack(dxw[8000:, :GH], ROWS, 0, stages, 1.0, col_scale=scale, out=bufs[0])
     x_pk = hip.wgrad16_pack(x[8000:], ROWS, 0, stages, 32768.0, out=bufs[1])
     y_pk = hip.wgrad16_pack(y[:, :H], 16000, 8000 - B, stages, 32768.0, out=bufs[2])
     hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih, y_packed=y_pk, y_scale=32768.0,
-                     dw_y=g_hh)
+                     dw_y=g_hh, parts=PARTS)
 
 
 def timed(fn, reps=8):
@@ -78,4 +81,33 @@ for name, fn in (('library form (column split, 2 TN GEMMs, rescales)', library),
     ref = dxw[8000:, :GH].double().t() @ x[8000:].double()
     err = float((g_ih.double() - ref).norm() / ref.norm())
     print('{}: {:.3f} ms{}  (dW_ih rms error {:.2e})'.format(
-        name, ms, ' beside a half-chip backward recurrence' if beside else '', err))
+        name + (' parts {}'.format(PARTS) if fn is own else ''), ms, ' beside a half-chip backward recurrence' if beside else '', err))
+
+if not beside:
+    scale, inv = hip.colscale_from_max(colmax)
+    d_pk = hip.wgrad16_pack(dxw[8000:, :GH], ROWS, 0, stages, 1.0, col_scale=scale, out=bufs[0])
+    x_pk = hip.wgrad16_pack(x[8000:], ROWS, 0, stages, 32768.0, out=bufs[1])
+    y_pk = hip.wgrad16_pack(y[:, :H], 16000, 8000 - B, stages, 32768.0, out=bufs[2])
+    parts = {
+        'pack d (column scales)': lambda: hip.wgrad16_pack(dxw[8000:, :GH], ROWS, 0, stages, 1.0, col_scale=scale, out=bufs[0]),
+        'pack x': lambda: hip.wgrad16_pack(x[8000:], ROWS, 0, stages, 32768.0, out=bufs[1]),
+        'pack y': lambda: hip.wgrad16_pack(y[:, :H], 16000, 8000 - B, stages, 32768.0, out=bufs[2]),
+        'kernel W_ih + W_hh': lambda: hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih, y_packed=y_pk,
+                                                        y_scale=32768.0, dw_y=g_hh),
+        'kernel W_ih + W_hh, 2 parts': lambda: hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih, y_packed=y_pk,
+                                                        y_scale=32768.0, dw_y=g_hh, parts=2),
+        'kernel W_ih + W_hh, 4 parts': lambda: hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih, y_packed=y_pk,
+                                                        y_scale=32768.0, dw_y=g_hh, parts=4),
+        'kernel W_ih + W_hh, 8 parts': lambda: hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih, y_packed=y_pk,
+                                                        y_scale=32768.0, dw_y=g_hh, parts=8),
+        'kernel W_ih + W_hh, 16 parts': lambda: hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih, y_packed=y_pk,
+                                                        y_scale=32768.0, dw_y=g_hh, parts=16),
+        'kernel W_ih only': lambda: hip.wgrad16_gemm(d_pk, GH, stages, inv, x_pk, 0, 32768.0, g_ih),
+        'library: column split of d': lambda: split_gemm.wgrad16_operand(dxw[8000:, :GH], colmax),
+    }
+    d16, inv16 = split_gemm.wgrad16_operand(dxw[8000:, :GH], colmax)
+    parts['library: W_ih GEMM + rescale'] = lambda: split_gemm.wgrad16(g_ih, d16, inv16, x16, 32768.0, 8000)
+    parts['library: W_hh GEMM + rescale'] = lambda: split_gemm.wgrad16(g_hh, d16, inv16, y16, 32768.0, 8000 - B,
+                                                                      x_cols=slice(0, H))
+    for name, fn in parts.items():
+        print('  {}: {:.3f} ms'.format(name, timed(fn, 16)))

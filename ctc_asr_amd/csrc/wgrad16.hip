@@ -73,7 +73,23 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
         v -= p.tiles_m * p.tiles_n[0];
         which = 1;
     }
-    const int tm = v / p.tiles_n[which], tn = v % p.tiles_n[which];
+    // Workgroup b runs on XCD b % 8, which has its own L2: an XCD takes a compact block of the
+    // operand's tiles (4 x 4 where the tile counts allow: 8 operand panels per stage for 16 tiles
+    // instead of 17), not every eighth tile of the row-major list.
+    int tm, tn;
+    {
+        const int tiles_n = p.tiles_n[which], count = p.tiles_m * tiles_n;
+        if (p.tiles_m % 4 == 0 && tiles_n % 4 == 0 && count % 8 == 0 &&
+            (p.tiles_m * p.tiles_n[0]) % 8 == 0) {
+            const int pos = (v % 8) * (count / 8) + v / 8;     // position in block-major order
+            const int block = pos / 16, in_block = pos % 16, blocks_n = tiles_n / 4;
+            tm = (block / blocks_n) * 4 + in_block / 4;
+            tn = (block % blocks_n) * 4 + in_block % 4;
+        } else {
+            tm = v / tiles_n;
+            tn = v % tiles_n;
+        }
+    }
     const int nt_total = p.n_tiles[which];
     const int mt0 = tm * (WG_TILE / 16), nt0 = tn * (WG_TILE / 16);
     const char *b_all = p.b[which] + (size_t)p.stage0[which] * nt_total * 2048;

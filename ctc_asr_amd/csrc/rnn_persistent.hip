@@ -25,6 +25,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #define PRNN_THREADS 256
@@ -53,6 +54,9 @@
 #endif
 #ifndef PRNN_CHAIN0_PRIO
 #define PRNN_CHAIN0_PRIO 1
+#endif
+#ifndef PRNN_XCD_TILE_PAIRS
+#define PRNN_XCD_TILE_PAIRS 0
 #endif
 #ifndef PRNN_POLL_SLEEP
 #define PRNN_POLL_SLEEP 1
@@ -814,16 +818,22 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_fwd16_kernel(PArgs p) {
     float *red = reinterpret_cast<float *>(smem + (size_t)4 * QL * 64 * sizeof(u32x4));
     float *wave_top = red + 4 * NT * 16 * 17;
 
-    const int chain = p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
-    const int row0 = chain * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x % (p.ndir * p.nwg);
     // Workgroup b runs on XCD b % 8.  `xcd_split` (two directions in the launch): direction 0 on
     // XCDs 0 - 3, direction 1 on XCDs 4 - 7 - an exchange block is then pulled across the fabric
     // by four L2s instead of eight, and an XCD's L2 holds one direction's blocks instead of two.
+    // Two batch tiles in the launch (each its own group of workgroups): every (direction, tile)
+    // on its own PAIR of XCDs - two L2s per exchange block.
     const bool split = p.xcd_split && p.ndir == 2;
+    const bool pairs = PRNN_XCD_TILE_PAIRS && split && (int)gridDim.x == 2 * p.ndir * p.nwg &&
+                       p.nwg % 2 == 0;
+    const int chain = p.chain0 + (pairs ? ((int)blockIdx.x >> 1) & 1
+                                        : (int)blockIdx.x / (p.ndir * p.nwg));
+    const int row0 = chain * 16;
     const int dir = p.dir0 + (split ? (wg & 7) >> 2 : wg / p.nwg);
-    const int slice = split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
+    const int slice = pairs ? ((int)blockIdx.x >> 3) * 2 + ((int)blockIdx.x & 1)
+                            : split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int H = p.H, B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * UPB;
@@ -1788,6 +1798,32 @@ __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, __uint_as_float(dpp_u32<0x140>(__float_as_uint(v))));
     return v;
 }
+// The LSTM cell derivative of the fp16-pipe backward kernels, every operation rounded on its own
+// (no contraction, whatever the optimiser makes of the code around it - packed math for two items
+// in one kernel, scalar math for one item in the other): prnn_bwd16_kernel and prnn_bwd16s_kernel
+// then agree bit for bit, which is how the staggered kernel's exchange is tested.
+__device__ __forceinline__ float tanh_pinned(float x) {
+#pragma clang fp contract(off)
+    const float ax = fabsf(x);
+    const float e = __expf(-2.0f * ax);
+    const float big = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float x2 = ax * ax;
+    const float small =
+        ax * __fmaf_rn(x2, __fmaf_rn(x2, __fmaf_rn(-x2, 0.053968254f, 0.13333334f), -0.33333334f), 1.0f);
+    return copysignf(ax < 0.05f ? small : big, x);
+}
+__device__ __forceinline__ void lstm_cell_bwd_pinned(float dh, float &dc_state, float gi, float gf,
+                                                     float gg, float go, float cv, float cpv,
+                                                     float (&dg)[4]) {
+#pragma clang fp contract(off)
+    const float tc = tanh_pinned(cv);
+    const float dc = dc_state + ((dh * go) * (1.f - tc * tc));
+    dg[0] = ((dc * gg) * gi) * (1.f - gi);
+    dg[1] = ((dc * cpv) * gf) * (1.f - gf);
+    dg[2] = (dc * gi) * (1.f - gg * gg);
+    dg[3] = ((dh * tc) * go) * (1.f - go);
+    dc_state = dc * gf;
+}
 #define PRNN_B16_SCALE_ROWS 32          // rows per producer in the inverse-scale blocks
 #ifndef PRNN_B16_D1
 #define PRNN_B16_D1 14                  // ring depth, one tile on 4 waves
@@ -2075,13 +2111,8 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
                 float dh = dyv[it];
 #pragma unroll
                 for (int w = 0; w < NW; ++w) dh += red[((w * MT + tile) * 16 + ib) * 17 + iu];
-                const float tc = tanhf_(cv[it]);
-                const float dc = dc_state[it] + dh * go[it] * (1.f - tc * tc);
-                dg[0] = dc * gg[it] * gi[it] * (1.f - gi[it]);
-                dg[1] = dc * cpv[it] * gf[it] * (1.f - gf[it]);
-                dg[2] = dc * gi[it] * (1.f - gg[it] * gg[it]);
-                dg[3] = dh * tc * go[it] * (1.f - go[it]);
-                dc_state[it] = dc * gf[it];
+                lstm_cell_bwd_pinned(dh, dc_state[it], gi[it], gf[it], gg[it], go[it], cv[it],
+                                     cpv[it], dg);
             }
             if (ITEMS * NTH > MT * 256 && item >= MT * 256) continue;     // (wave-uniform)
             // the row's scale over this workgroup's 64 values; two fp16 pieces of every value
@@ -2182,6 +2213,491 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
     }
     if (prof)
         for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// prnn_bwd16s_kernel (round 5): the same recurrence for batches of 17..32 rows on half of the
+// chip with the two 16-row tiles STAGGERED by half a step instead of behind one barrier.
+//
+// prnn_bwd16_kernel<2, 4, 5> pays per step: barrier round trip (1.2 us), first byte of freshly
+// published cross-XCD data (~1.5 us), 512 KB through the CU's load path, gate math + publish (1.0),
+// store drain (0.5) - one after the other, 8.3 us.  The tiles are independent recurrences, so one
+// tile's exchange round trip (publish -> drain -> arrive -> everybody's arrival visible -> first
+// byte) can run under the other tile's 256 KB of loads.  One instruction stream per wave (4 waves,
+// 512 registers: the weights' register half is held once), software-pipelined by hand:
+//
+//   phase (s, X):  main loop over the wave's 16 producers of tile X (their A granules were
+//                  requested during the phase before), pairs of producers alternate on the matrix
+//                  pipe; as ring slots come free they are refilled with tile X's remaining
+//                  producers, then - from pair JW on - with the FIRST producers of the next phase
+//                  (tile X ^ 1: the same step for X = 0, the next step for X = 1);
+//                  reduce + cell derivative + publish of (s, X) while those loads are in flight.
+//   arrival of (s, X): vmcnt counts loads and stores in ONE in-order queue on gfx950, so the
+//                  publish stores cannot be waited for alone - a 4-byte marker load is issued right
+//                  behind them and the arrival is posted where the next phase's main loop first
+//                  waits for that marker (pair JA): by then the stores in front of it are complete,
+//                  and nothing younger had to drain.  Every wave counts itself in on an LDS word,
+//                  the fourth posts the workgroup's arrival (no workgroup barrier).
+//   wait for (s', X'): every wave polls for itself, asynchronously - the counter loads are issued
+//                  at pair JP and looked at at pair JW; only a wave that finds them short spins.
+//
+// Each tile has its own arrival counters (SyncWords.group_cnt[dir][tile]).  Arithmetic, exchange
+// layout, scales, column maxima: prnn_bwd16_kernel's, and the per-tile order of every sum is that of
+// <2, 4, 5> - results are bit-identical to it (tests/test_gpu_kernels.py).
+// ---------------------------------------------------------------------------------------------
+#ifndef PRNN_B16S_D
+#define PRNN_B16S_D 8                   // ring slots = producers of a tile in flight per wave (8 / 16)
+#endif
+#ifndef PRNN_B16S_JW
+#define PRNN_B16S_JW 7                  // pair at which the next phase's loads may start (>= (16 - D) / 2)
+#endif
+#ifndef PRNN_B16S_JP
+#define PRNN_B16S_JP 5                  // pair at which the poll loads for them are issued
+#endif
+#ifndef PRNN_B16S_JA
+#define PRNN_B16S_JA 1                  // pair at which the phase before posts its arrival
+#endif
+template <int DD, int JW, int JP, int JA, bool PROF = false>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16s_kernel(PArgs p) {
+    constexpr int H = PRNN_RS_H, GH = 4 * H;
+    constexpr int NW = 4, NTH = 256, NPW = 16, QS = NPW * 4, QL = QS / 2, REGW = QS - QL;
+    constexpr int RED_FLOATS = NW * 16 * 17, IVL = 4 * NPW;
+    static_assert(DD % 2 == 0 && DD <= NPW && (NPW % DD == 0 || JW == NPW / 2 - 1),
+                  "ring slots: even; not a divisor of 16 only when the next phase is requested at the end");
+    static_assert(2 * JW >= NPW - DD && JW < NPW / 2 && JP <= JW && JA <= JP, "pipeline points");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
+    u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 64 * sizeof(u32x4));   // [2 tiles]
+    float4 *invs = reinterpret_cast<float4 *>(red + 2 * RED_FLOATS);       // [2 tiles][NW][IVL]
+    float *wave_top = reinterpret_cast<float *>(invs + 2 * NW * IVL);
+    unsigned *arrived = reinterpret_cast<unsigned *>(wave_top + 4);        // [2 tiles]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const bool split = p.xcd_split && p.ndir == 2;
+    const int dir = p.dir0 + (split ? (wg & 7) >> 2 : wg / p.nwg);
+    const int slice = split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int B = p.B, T = p.T, BS = p.BS;
+    const int u0 = slice * 16;
+    if (tid < 2) arrived[tid] = 0u;
+
+    // ---- this workgroup's 16 columns of R^T as scaled fp16 pieces (prnn_bwd16_kernel's layout) --
+    float w_scale;
+    {
+        float m = 0.f;
+        const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 15)) * GH;
+        for (int n = (tid >> 4) * 4; n < GH; n += NTH / 16 * 4) {
+            const float4 v = ldg4(wrow + n);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_max(m);
+        if (lane == 0) wave_top[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wave_top[0], wave_top[1]), fmaxf(wave_top[2], wave_top[3]));
+        const unsigned bits = __float_as_uint(m);
+        const int e = (int)((bits >> 23) & 0xFF) - 127;
+        const int se = bits == 0u ? 0 : min(max(14 - e, -60), 60);
+        w_scale = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+    const float out_scale = 1.0f / w_scale;
+    u32x4 wreg[REGW];
+    {
+        auto pieces = [&](int pm, u32x4 &first, u32x4 &second) {
+            const float *wcol = p.w + ((size_t)dir * H + u0 + (lane & 15)) * GH +
+                                16 * (wave * NPW + (pm >> 1)) + 8 * (pm & 1) + 2 * (lane >> 4);
+            unsigned q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                q[e] = f16_pieces(wcol[(size_t)(e & 3) * H + (e >> 2)] * w_scale);
+            first = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                            (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+            second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                             (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+        };
+        for (int pm = 0; pm < QL / 2; ++pm) {
+            u32x4 first, second;
+            pieces(pm, first, second);
+            frag[(wave * QL + 2 * pm) * 64 + lane] = first;
+            frag[(wave * QL + 2 * pm + 1) * 64 + lane] = second;
+        }
+#pragma unroll
+        for (int pm = 0; pm < REGW / 2; ++pm) pieces(QL / 2 + pm, wreg[2 * pm], wreg[2 * pm + 1]);
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * GH;
+    const size_t x_base = x_step;
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.rs, 0, (int)prnn_b16_scale_bytes(T), 0x00020000);
+    constexpr unsigned S_STEP = 2u * (H / 16) * PRNN_B16_SCALE_ROWS * sizeof(float);
+    const int rnum = 0x7FFFFFFF;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.dy), 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cells, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dxw, 0, rnum, 0x00020000);
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    };
+
+    // ---- one item per thread and tile: row x * 16 + (tid >> 4), unit tid & 15.  No per-row lengths
+    // (cuDNN semantics: the caller takes prnn_bwd16_kernel for those), so the time of step s is
+    // wave-uniform and every per-item address is a scalar part + a per-lane constant ---------------
+    const int iu = tid & 15, unit = u0 + iu;
+    float dc_state[2], dbs[2][4], cmx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int brow = x * 16 + (tid >> 4);
+        dc_state[x] = 0.f;
+        if (p.s_hi < T && brow < B) dc_state[x] = p.carry[((size_t)dir * B + brow) * H + unit];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbs[x][g] = 0.f;
+    }
+    // element index of (row, dir, unit) in a [BS, 2, H] slab; the [T] part goes into the scalar offset
+    auto item_elem = [&](int x) -> unsigned {
+        return (unsigned)(((x * 16 + (tid >> 4)) * 2 + dir) * H + unit);
+    };
+    auto ldf2 = [](__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) -> float {
+        return __uint_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)uni_off, 0));
+    };
+
+    // what the cell derivative of (step, tile) needs besides dh_rec, requested half a phase ahead
+    // (behind the first loads of the tile's A operand).  Unconditional - rows past the batch read
+    // the batch's last row - so that the vector-memory queue has no data-dependent entries and
+    // every wait below is a counted one.
+    float c_dy[2], c_gi[2], c_gf[2], c_gg[2], c_go[2], c_cv[2], c_cp[2];
+    auto cell_prefetch = [&](int s, int x) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        s = max(s, 0);                    // (behind the launch's last phase: any valid address)
+        const unsigned t = (unsigned)(dir == 0 ? s : T - 1 - s);
+        const unsigned tp = s > 0 ? (unsigned)(dir == 0 ? s - 1 : T - s) : t;
+        const unsigned unit = (unsigned)(u0 + (tq & 15));
+        const unsigned e = (unsigned)((min(x * 16 + (tq >> 4), B - 1) * 2 + dir) * H) + unit;
+        const unsigned slab = t * (unsigned)BS * 2u * H * 4u;               // bytes of [BS, 2, H] rows
+        c_dy[x] = ldf2(dy_rsrc, e * 4u, slab);
+        const unsigned ge = (e * 4u - 3u * unit) * 4u;
+        c_gi[x] = ldf2(g_rsrc, ge, slab * 4u);
+        c_gf[x] = ldf2(g_rsrc, ge + H * 4u, slab * 4u);
+        c_gg[x] = ldf2(g_rsrc, ge + 2 * H * 4u, slab * 4u);
+        c_go[x] = ldf2(g_rsrc, ge + 3 * H * 4u, slab * 4u);
+        c_cv[x] = ldf2(c_rsrc, e * 4u, slab);
+        c_cp[x] = ldf2(c_rsrc, e * 4u, tp * (unsigned)BS * 2u * H * 4u);
+        if (s == 0) c_cp[x] = 0.f;        // (no cell state before the first step)
+    };
+
+    // A operand of (step s, tile x): block of step s + 1 (the all-zero block for s = T - 1, where
+    // nothing has been published) - a scalar; rows past the batch read the batch's last row (their
+    // results are never used); inverse scales
+    unsigned ablock[2];                   // scalar: byte offset of (step, dir) in the exchange buffer
+    float4 iv_next;
+    auto lane_aoff = [&](int x) -> unsigned {
+        const int row = min(x * 16 + (lane & 15), B - 1);
+        return (unsigned)(((size_t)(lane >> 4) * B * 4 + (size_t)row * 4) * sizeof(float));
+    };
+    auto tile_addresses = [&](int s, int x) {
+        ablock[x] = (unsigned)(((s + 1 < T ? x_base + (size_t)(s + 1) * x_step : 0) +
+                                (size_t)dir * B * GH) * sizeof(float));
+        iv_next = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
+                                         (unsigned)(((dir * (H / 16) + wave * NPW + (lane >> 2)) *
+                                                     PRNN_B16_SCALE_ROWS + x * 16 + 4 * (lane & 3)) *
+                                                    sizeof(float)));
+    };
+    u32x4 a[DD][4];                       // ring: producer P of the tile in flight sits in slot P % DD
+    // (the 64 wave-uniform offsets are products with the runtime batch: made opaque per use, or
+    // the optimiser hoists them all and spills scalar registers - see prnn_bwd16w_kernel)
+    const unsigned wave_off = (unsigned)(wave * NPW * 4) * (unsigned)B * 64u;
+    auto issue = [&](int x, int P) {
+        unsigned bstride = (unsigned)B * 64u;
+        asm volatile("" : "+s"(bstride));
+        const unsigned lo = lane_aoff(x);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)       // g = half * 2 + piece
+            a[P % DD][g] = load16u(x_rsrc, lo, ablock[x] + wave_off + (unsigned)(P * 4 + g) * bstride);
+    };
+    auto poll = [&](int x) -> unsigned {  // lanes 0 .. 7: the arrival counter of group `lane`
+        unsigned v = 0xFFFFFFFFu;
+        if (lane < PRNN_GROUPS)
+            v = __hip_atomic_load(&p.sync->group_cnt[dir][x][lane][0], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto bfrag = [&](int sl) -> u32x4 {   // compile-time slot after unrolling
+        return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+    };
+
+    // phase timers (CTCASR_RNN_PROF: a second instantiation - the timed stream needs registers the
+    // plain one does not have to spare): wave 0 of workgroup 0, wave-uniform -> scalar registers.
+    // [0] waiting for the marker (publish stores of the phase before), [1] waiting for the polled
+    // counters (+ spinning), [2] the rest of the main loops, [3] reduce + cell derivative + publish
+    unsigned long long pt[4] = {0, 0, 0, 0}, spins_total = 0;
+    const bool profw = PROF && p.prof && blockIdx.x == 0 && wave == 0;
+    unsigned marker = 0u;                 // the load behind a phase's publish stores
+
+    // one phase: `xc` = tile (compile-time), s = its step.  prev_arrives: the phase before
+    // published something that others wait for; has_next / next_waits: see above
+    auto phase = [&](auto xc, int s, bool prev_arrives, bool has_next, bool next_waits) {
+        constexpr int X = decltype(xc)::value, XN = X ^ 1;
+        const int sn = X == 0 ? s : s - 1;                  // the next phase's step
+        f32x4 total = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        unsigned pv = 0xFFFFFFFFu;
+        unsigned long long c0 = 0, waited = 0;
+        if constexpr (PROF) c0 = profw ? wall_clock64() : 0;
+#pragma unroll
+        for (int j = 0; j < NPW / 2; ++j) {
+            if (j == JA && prev_arrives) {
+                // the marker is back -> the publish stores issued in front of it are complete
+                unsigned long long w0 = 0;
+                if constexpr (PROF) w0 = profw ? wall_clock64() : 0;
+                asm volatile("" ::"v"(marker) : "memory");
+                if constexpr (PROF) {
+                    if (profw) { const unsigned long long d = wall_clock64() - w0; pt[0] += d; waited += d; }
+                }
+                if (lane == 0) {
+                    const unsigned before = __hip_atomic_fetch_add(
+                        &arrived[XN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((before & 3u) == 3u)
+                        __hip_atomic_fetch_add(&p.sync->group_cnt[dir][XN][grp][0], 1u,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (j == JP && has_next && next_waits) pv = poll(XN);
+            const int P0 = 2 * j, P1 = 2 * j + 1;
+            f32x4 acc0, acc1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Frag16 w10, w20, w11, w21, d10, d20, d11, d21;
+                w10.u = bfrag((P0 * 2 + m) * 2);
+                w20.u = bfrag((P0 * 2 + m) * 2 + 1);
+                w11.u = bfrag((P1 * 2 + m) * 2);
+                w21.u = bfrag((P1 * 2 + m) * 2 + 1);
+                d10.u = a[P0 % DD][2 * m];
+                d20.u = a[P0 % DD][2 * m + 1];
+                d11.u = a[P1 % DD][2 * m];
+                d21.u = a[P1 % DD][2 * m + 1];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d10.h, w10.h, m == 0 ? zero : acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d11.h, w11.h, m == 0 ? zero : acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d10.h, w20.h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d11.h, w21.h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d20.h, w10.h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d21.h, w11.h, acc1, 0, 0, 0);
+            }
+            // refill the two slots: the tile's own remaining producers ...
+            if (P0 + DD < NPW) issue(X, P0 + DD);
+            if (P1 + DD < NPW) issue(X, P1 + DD);
+            // ... then the next phase's first ones, as soon as everybody has published them
+            // (unconditional - after the launch's last phase they read blocks nobody needs: the
+            // instruction stream stays straight-line)
+            if (j >= JW) {
+                if (j == JW) {
+                    // the counters polled at pair JP: looked at in straight-line code (a counted
+                    // vmcnt - the ring stays in flight); only a wave that finds them short spins
+                    const unsigned target = (unsigned)group_size * (unsigned)(p.s_hi - 1 - sn);
+                    unsigned long long w1 = 0;
+                    if constexpr (PROF) {
+                        w1 = profw ? wall_clock64() : 0;
+                        asm volatile("" ::"v"(pv) : "memory");
+                        if (profw) { const unsigned long long d = wall_clock64() - w1; pt[1] += d; waited += d; }
+                        w1 = profw ? wall_clock64() : 0;
+                    }
+                    if (__builtin_expect(has_next && next_waits && !__all(pv >= target), 0)) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            __builtin_amdgcn_s_sleep(PRNN_POLL_SLEEP);
+                            const unsigned again = poll(XN);
+                            if constexpr (PROF) spins_total += 1;
+                            if (__all(again >= target)) break;
+                            if (++spins > PRNN_SPIN_LIMIT ||
+                                ((spins & 1023u) == 0 &&
+                                 __hip_atomic_load(&p.sync->error, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT))) {
+                                if (lane == 0)
+                                    __hip_atomic_store(&p.sync->error, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        if constexpr (PROF) {
+                            if (profw) { const unsigned long long d = wall_clock64() - w1; pt[1] += d; waited += d; }
+                        }
+                    }
+                    tile_addresses(sn, XN);
+#pragma unroll
+                    for (int q = 0; q <= P1 + DD - NPW; ++q) issue(XN, q);
+                    cell_prefetch(sn, XN);
+                } else {
+                    issue(XN, P0 + DD - NPW);
+                    issue(XN, P1 + DD - NPW);
+                }
+            }
+            {
+                const float4 iv0 = invs[(X * NW + wave) * IVL + 4 * P0 + (lane >> 4)];
+                const float4 iv1 = invs[(X * NW + wave) * IVL + 4 * P1 + (lane >> 4)];
+                total[0] += acc0[0] * iv0.x;
+                total[1] += acc0[1] * iv0.y;
+                total[2] += acc0[2] * iv0.z;
+                total[3] += acc0[3] * iv0.w;
+                total[0] += acc1[0] * iv1.x;
+                total[1] += acc1[1] * iv1.y;
+                total[2] += acc1[2] * iv1.z;
+                total[3] += acc1[3] * iv1.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- reduce over the waves' K shares, cell derivative, publish ---------------------------
+        if constexpr (PROF) {
+            asm volatile("" ::"v"(total[0]));
+            if (profw) { const unsigned long long c = wall_clock64(); pt[2] += c - c0 - waited; c0 = c; }
+        }
+        // (per-lane address constants of this part are recomputed from an opaque copy of the thread
+        // index every phase: hoisted out of the step loop they are spilled, and a scratch reload is
+        // a vector-memory load - waiting for it drains the ring)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lq = tq & 63, iu = tq & 15, unit = u0 + iu;
+        float *redx = red + X * RED_FLOATS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            redx[(wave * 16 + 4 * (lq >> 4) + r) * 17 + (lq & 15)] = total[r] * out_scale;
+        __syncthreads();
+        {
+            const int ib = tq >> 4;
+            const bool has = X * 16 + ib < B;
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has) {
+                float dh = c_dy[X];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) dh += redx[(w * 16 + ib) * 17 + iu];
+                lstm_cell_bwd_pinned(dh, dc_state[X], c_gi[X], c_gf[X], c_gg[X], c_go[X], c_cv[X],
+                                     c_cp[X], dg);
+            }
+            float mx = fmaxf(fmaxf(fabsf(dg[0]), fabsf(dg[1])), fmaxf(fabsf(dg[2]), fabsf(dg[3])));
+            mx = row16_max(mx);
+            const unsigned mbits = __float_as_uint(mx);
+            const int me = (int)((mbits >> 23) & 0xFF) - 127;
+            const int mse = mbits == 0u ? 0 : min(max(13 - me, -100), 100);
+            const float rscale = __uint_as_float((unsigned)(mse + 127) << 23);
+            const float rinv = __uint_as_float((unsigned)(127 - mse) << 23);
+            unsigned q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) q[g] = f16_pieces(dg[g] * rscale);
+            const bool odd = (tq & 1) != 0;
+            const unsigned f01 = (q[0] & 0xFFFFu) | (q[1] << 16), f23 = (q[2] & 0xFFFFu) | (q[3] << 16);
+            const unsigned s01 = (q[0] >> 16) | (q[1] & 0xFFFF0000u),
+                           s23 = (q[2] >> 16) | (q[3] & 0xFFFF0000u);
+            const unsigned give01 = odd ? f01 : s01, give23 = odd ? f23 : s23;
+            const unsigned got01 = dpp_u32<0xB1>(give01), got23 = dpp_u32<0xB1>(give23);
+            const u32x4 v = odd ? (u32x4){got01, got23, s01, s23} : (u32x4){f01, f23, got01, got23};
+            if (has) {
+                // block (producer, half = unit >> 3, piece), k group (unit >> 1) & 3
+                const unsigned lo = (unsigned)(
+                    ((size_t)((slice * 2 + (iu >> 3)) * 2 + (odd ? 1 : 0)) * B * 16 +
+                     (size_t)((iu >> 1) & 3) * B * 4 + (size_t)(X * 16 + ib) * 4) * sizeof(float));
+                const unsigned uo = (unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * GH) *
+                                               sizeof(float));
+                __builtin_amdgcn_raw_buffer_store_b128(v, x_rsrc, (int)lo, (int)uo, 16);
+            }
+            const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 0));
+            const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 16));
+            const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 32));
+            const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 48));
+            if (lq == 0)
+                store16_sc1(s_rsrc,
+                            (unsigned)s * S_STEP +
+                                (unsigned)(((dir * (H / 16) + slice) * PRNN_B16_SCALE_ROWS + X * 16 +
+                                            ib) * sizeof(float)),
+                            r0, r1, r2, r3);
+            if (has) {      // dxw in its GEMM layout: read after the launch only
+                const unsigned t = (unsigned)(dir == 0 ? s : T - 1 - s);
+                const unsigned lo = (unsigned)(((X * 16 + ib) * 2 + dir) * GH + unit) * 4u;
+                const unsigned uo = t * (unsigned)BS * 2u * GH * 4u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg[g]), dx_rsrc,
+                                                          (int)(lo + (unsigned)g * H * 4u), (int)uo, 0);
+                    dbs[X][g] += dg[g];
+                    cmx[g] = fmaxf(cmx[g], fabsf(dg[g]));
+                }
+            }
+        }
+        // the marker behind the stores (any address that is always valid: the all-zero block)
+        asm volatile("" ::: "memory");
+        marker = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, 0, 0, 0);
+        // the next phase's inverse scales -> this wave's LDS rows (requested at pair JW)
+        invs[(XN * NW + wave) * IVL + lane] = iv_next;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PROF) {
+            if (profw) pt[3] += wall_clock64() - c0;
+        }
+    };
+
+    // ---- prologue: the first phase's operands (no wait: what it reads was published by the launch
+    // before, or it is the all-zero block) ---------------------------------------------------------
+    {
+        const int s = p.s_hi - 1;
+        tile_addresses(s, 0);
+#pragma unroll
+        for (int q = 0; q < DD; ++q) issue(0, q);
+        cell_prefetch(s, 0);
+        invs[(0 * NW + wave) * IVL + lane] = iv_next;
+    }
+    for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
+        // (s, 0): the phase before, (s + 1, 1), arrives if it exists; next = (s, 1), which waits
+        // for arrivals unless this is the launch's first step
+        phase(std::integral_constant<int, 0>{}, s, s < p.s_hi - 1, true, s < p.s_hi - 1);
+        // (s, 1): the phase before, (s, 0), arrives unless this is the launch's last step;
+        // next = (s - 1, 0)
+        phase(std::integral_constant<int, 1>{}, s, s > p.s_lo, s > p.s_lo, true);
+    }
+    __syncthreads();        // every wave is through its last poll
+    if (tid == 0 && p.s_hi - p.s_lo >= 2) {
+        counters_done(p.sync, dir, 0, p.nwg);
+        counters_done(p.sync, dir, 1, p.nwg);
+    }
+    if constexpr (PROF) {
+        if (profw && lane == 0) {
+            for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+            p.sync->prof[8] = spins_total;
+        }
+    }
+    if (p.s_lo > 0) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int brow = x * 16 + (tid >> 4);
+            if (brow < B) p.carry[((size_t)dir * B + brow) * H + unit] = dc_state[x];
+        }
+    }
+    if (p.dbias || p.colmax) {
+        float *sums = red, *tops = reinterpret_cast<float *>(frag);     // (the weights are done with)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                sums[tid + x * NTH] = dbs[x][g];
+                tops[tid + x * NTH] = cmx[g];
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float sum = 0.f, top = 0.f;
+                for (int r = 0; r < 32; ++r) {
+                    sum += sums[r * 16 + tid];
+                    top = fmaxf(top, tops[r * 16 + tid]);
+                }
+                if (p.dbias) atomicAdd(p.dbias + ((size_t)dir * 4 + g) * H + u0 + tid, sum);
+                if (p.colmax)
+                    atomicMax(p.colmax + ((size_t)dir * 4 + g) * H + u0 + tid, __float_as_uint(top));
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3128,6 +3644,15 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
             return (size_t)128 * 1024 + (size_t)waves * tiles * 16 * 17 * 4 +
                    (size_t)tiles * 256 * 16 + 64;      // (inverse scales: 4 float4 per producer)
         };
+        if (mt == 2 && half_chip && (flags & CTCASR_RNN_STAGGER) && !seq_len) {
+            if (p.prof)
+                return launch_persistent(
+                    prnn_bwd16s_kernel<PRNN_B16S_D, PRNN_B16S_JW, PRNN_B16S_JP, PRNN_B16S_JA, true>,
+                    p, lds(2, 4), s);
+            return launch_persistent(
+                prnn_bwd16s_kernel<PRNN_B16S_D, PRNN_B16S_JW, PRNN_B16S_JP, PRNN_B16S_JA>, p,
+                lds(2, 4), s);
+        }
         if (mt == 2 && half_chip)
             return launch_persistent(prnn_bwd16_kernel<2, PRNN_B16_NW2, PRNN_B16_D2>, p, lds(2, PRNN_B16_NW2), s, PRNN_B16_NW2 / 4);
         return launch_persistent(prnn_bwd16_kernel<1, 4, PRNN_B16_D1>, p, lds(1, 4), s, 1, mt);

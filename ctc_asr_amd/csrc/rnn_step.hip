@@ -370,7 +370,8 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_b
     if (y_pieces && (seq_len || !ctcasr_rnn_fwd_f16_supported(cell, T, B, H, flags)))
         return CTCASR_ERR_UNSUPPORTED;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
-                         CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16 | CTCASR_RNN_XCD_SPLIT))
+                         CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16 | CTCASR_RNN_XCD_SPLIT |
+                         CTCASR_RNN_STAGGER))
         return CTCASR_ERR_BAD_ARGUMENT;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
@@ -470,7 +471,8 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     int rc = rnn_check(cell, T, B, H);
     if (rc != CTCASR_OK) return rc;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
-                         CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16 | CTCASR_RNN_XCD_SPLIT))
+                         CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16 | CTCASR_RNN_XCD_SPLIT |
+                         CTCASR_RNN_STAGGER))
         return CTCASR_ERR_BAD_ARGUMENT;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;

@@ -446,7 +446,10 @@ class CTCModel:
         # workgroups a tile's row sum is cut into (192 tiles of a direction's W_ih + W_hh at
         # H = 1024 leave a quarter of the chip idle, or make 1.5 rounds on the half beside a
         # recurrence launch)
-        self.own_wgrad_parts = int(os.environ.get('CTCASR_WGRAD_PARTS', '1'))
+        # (2 since the staggered backward recurrence: the recurrence launches got shorter, the
+        # weight gradients beside them are what the data-gradient kernel then shares the chip with -
+        # C3 48.0 -> 47.3 ms per step on one box, 47.6 -> 47.0 on another; 3: the same)
+        self.own_wgrad_parts = int(os.environ.get('CTCASR_WGRAD_PARTS', '2'))
         # layers whose input has no bound (behind a ReLU-cell layer: the reference's default model)
         # in an fp16 form as well - the input split with a scale per ROW for the projection (as a
         # layer's dxw is for the data gradient), per COLUMN for the weight gradients
@@ -457,7 +460,10 @@ class CTCModel:
         # of dx (half of the K axis) is multiplied beside the next launch ('side': on the side
         # stream ahead of the range's weight gradients, 'own': on a third stream), only the last
         # launch's share stays on the main stream ('0': the whole product behind the last launch)
-        self.dgrad_early = os.environ.get('CTCASR_DGRAD_EARLY', '0')
+        # ('side' since the staggered backward recurrence + 2-part weight-gradient tiles: another
+        # 0.2 - 0.3 ms of the C3 step in two A/Bs; it had measured no gain while the recurrence
+        # launches were the longer side of every layer)
+        self.dgrad_early = os.environ.get('CTCASR_DGRAD_EARLY', 'side')
         self._dgrad_stream = None
         # the forward recurrence's own product h_(t-1) W_hh^T as two fp16 pieces per operand and
         # three products on the fp16 matrix pipe (LSTM-1024 persistent kernel; |h| <= 1, W_hh
@@ -473,6 +479,10 @@ class CTCModel:
         # shorter in two alternating A/Bs: profiles/r04_ab.md)
         self.rnn_xcd_flag = hip.RNN_XCD_SPLIT \
             if os.environ.get('CTCASR_RNN_XCD_SPLIT', '1') == '1' else 0
+        # backward LSTM-1024 recurrence, 17..32 rows: the two 16-row tiles staggered by half a step
+        # (prnn_bwd16s_kernel; bit-identical results) instead of both behind one barrier
+        self.rnn_stagger_flag = hip.RNN_STAGGER \
+            if os.environ.get('CTCASR_RNN_STAGGER', '1') == '1' else 0
         # the fp16-pipe forward kernel writes the fp16 pieces of its output itself (no split pass)
         self.rnn_fwd_pieces = os.environ.get('CTCASR_RNN_FWD_PIECES', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
@@ -1479,7 +1489,8 @@ class CTCModel:
             split_done = []
             # dgates W_hh on the fp16 matrix pipe where the kernel exists (LSTM-1024); it then also
             # leaves the column maxima of each launch's rows of dxw for the fp16 weight gradients
-            bwd_flags = self.rnn_bwd_flags | ((hip.RNN_F16 | self.rnn_xcd_flag)
+            bwd_flags = self.rnn_bwd_flags | ((hip.RNN_F16 | self.rnn_xcd_flag |
+                                               self.rnn_stagger_flag)
                                               if self.rnn_bwd_f16 else 0)
             f16_rec = hip.rnn_f16_recurrence(cell, t_out, batch, hidden, bwd_flags, backward=True,
                                              ragged=acts['rnn_len'] is not None)

@@ -430,6 +430,77 @@ def test_rnn_bwd_on_the_fp16_matrix_pipe(hip, use_len, dims):
         hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, sl, workspace=ws, colmax=colmax)
 
 
+@pytest.mark.parametrize('xcd', [0, 1])
+@pytest.mark.parametrize('dims', [(12, 32), (9, 19), (7, 17), (61, 27), (200, 32)])
+def test_rnn_bwd_staggered_tiles_equal_one_barrier(hip, xcd, dims):
+    """CTCASR_RNN_STAGGER (prnn_bwd16s_kernel): the two 16-row tiles of a 17..32-row batch half
+    a step apart, each with its own arrival counters, next phase's operands requested under this
+    phase's matrix work.  Every sum keeps the order of the one-barrier kernel: dxw, the bias
+    gradients, the column maxima AND what the kernel publishes for the data-gradient kernel (the
+    exchange blocks and inverse scales of every step) are bit-identical - a stale or early read
+    of the exchange would show here; step ranges and repeated passes on one workspace (counters
+    handed back clean) too.  Calls with per-row lengths keep the one-barrier kernel."""
+    num_steps, batch = dims
+    hidden, gh = 1024, 4096
+    g = torch.Generator(device=DEV).manual_seed(43)
+    xw = torch.randn(num_steps, batch, 2, gh, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, gh, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g) * \
+        torch.logspace(-5, 0, batch, device=DEV).view(1, batch, 1)
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh)
+    w_hh_t = hip.transpose_batched(w_hh)
+    base = hip.RNN_F16 | (hip.RNN_XCD_SPLIT if xcd else 0)
+    x_off, s_off = hip.dgrad16_published_offsets(num_steps, batch, hidden)
+    x_bytes = (num_steps + 1) * 2 * batch * gh * 4
+    s_bytes = (num_steps + 1) * 2 * 64 * 32 * 4
+
+    def run(flags, cuts=None):
+        db = torch.zeros(2 * gh, device=DEV)
+        colmax = torch.zeros(2 * gh, dtype=torch.int32, device=DEV)
+        dxw = torch.full((num_steps, batch, 2, gh), float('nan'), device=DEV)
+        cuts = cuts or [num_steps, 0]
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, None, dxw=dxw, dbias=db, workspace=ws,
+                        steps=(lo, hi), flags=flags, colmax=colmax)
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+        published = (ws[x_off:x_off + x_bytes].clone(), ws[s_off:s_off + s_bytes].clone())
+        return dxw, db, colmax, published
+
+    want = run(base)
+    assert torch.isfinite(want[0]).all()
+    for attempt in range(3):           # (repeated: the counters of the pass before are clean again)
+        got = run(base | hip.RNN_STAGGER)
+        assert torch.equal(got[0], want[0]), attempt
+        assert torch.equal(got[1], want[1])
+        assert torch.equal(got[2], want[2])
+        assert torch.equal(got[3][0], want[3][0])
+        assert torch.equal(got[3][1], want[3][1])
+    if num_steps >= 7:
+        cuts = [num_steps, num_steps - 1, num_steps - 3, num_steps // 2, 1, 0]
+        got = run(base | hip.RNN_STAGGER, cuts)
+        assert torch.equal(got[0], want[0])
+        assert torch.equal(got[2], want[2])
+        assert torch.equal(got[3][0], want[3][0])
+        # (bias gradients: one atomic per launch and column - another order of the same sums)
+        assert float((got[1] - want[1]).abs().max()) <= 1e-5 * max(1.0, float(want[1].abs().max()))
+        # the two kernels may take turns inside one pass
+        db = torch.zeros(2 * gh, device=DEV)
+        dxw = torch.full_like(want[0], float('nan'))
+        for k, (hi, lo) in enumerate(zip(cuts[:-1], cuts[1:])):
+            hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, None, dxw=dxw, dbias=db, workspace=ws,
+                        steps=(lo, hi), flags=base | (hip.RNN_STAGGER if k % 2 else 0))
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+        assert torch.equal(dxw, want[0])
+    # per-row lengths: the flag is ignored (one-barrier kernel), same results as without it
+    sl = torch.randint(1, num_steps + 1, (batch,), device=DEV, generator=g).int()
+    y_l, reserve_l, ws_l = hip.rnn_fwd('lstm', xw, w_hh, sl)
+    a = hip.rnn_bwd('lstm', dy, y_l, w_hh_t, reserve_l, sl, workspace=ws_l, flags=base)
+    b = hip.rnn_bwd('lstm', dy, y_l, w_hh_t, reserve_l, sl, workspace=ws_l,
+                    flags=base | hip.RNN_STAGGER)
+    hip.rnn_poll_error('lstm', ws_l, num_steps, batch, hidden)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('magnitude', [1e-6, 3.0, 40.0, 3000.0])
 def test_rnn_fwd_f16_scales_its_weights_itself(hip, magnitude):
     """No assumption about the size of W_hh: every workgroup scales its slice by the power of

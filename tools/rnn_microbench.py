@@ -34,6 +34,8 @@ def main():
     if os.environ.get('CTCASR_XCD'):           # fp16 kernels: one direction per half of the XCDs
         fwd_flags |= hip.RNN_XCD_SPLIT
         bwd_flags |= hip.RNN_XCD_SPLIT
+    if os.environ.get('CTCASR_STAGGER'):       # fp16 LSTM-1024 backward, 17..32 rows: staggered tiles
+        bwd_flags |= hip.RNN_STAGGER
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
@@ -65,6 +67,10 @@ def main():
                 words = ws[base: base + 40].cpu().numpy().view(np.uint64)
                 labels = ['wait', 'partial loads+sum', 'gates+A operand', 'mfma+publish',
                           'drain+arrive+dxw']
+            if name == 'bwd' and os.environ.get('CTCASR_STAGGER'):
+                words = ws[base: base + 40].cpu().numpy().view(np.uint64)
+                labels = ['marker wait', 'poll wait', 'main loops (rest)', 'reduce+gates+publish',
+                          'spins x 100']
             print('  wg0 phases (us/step): ' + ', '.join(
                 '{} {:.2f}'.format(l, float(w_) / 100.0 / T) for l, w_ in zip(labels, words)))
             if name == 'fwd' and B > 16:

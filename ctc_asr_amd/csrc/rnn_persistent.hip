@@ -56,7 +56,7 @@
 #define PRNN_CHAIN0_PRIO 1
 #endif
 #ifndef PRNN_XCD_TILE_PAIRS
-#define PRNN_XCD_TILE_PAIRS 0
+#define PRNN_XCD_TILE_PAIRS 1
 #endif
 #ifndef PRNN_POLL_SLEEP
 #define PRNN_POLL_SLEEP 1
@@ -3738,7 +3738,9 @@ extern "C" unsigned ctcasr_build_flags(void) {
     unsigned flags = dgrad16_build_flags();
     if (PRNN_PROBE_HALF_LOADS || PRNN_PROBE_RS_Q != 4) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
-        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2)
+        PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2 ||
+        PRNN_XCD_TILE_PAIRS != 1 || PRNN_B16S_D != 8 || PRNN_B16S_JW != 7 || PRNN_B16S_JP != 5 ||
+        PRNN_B16S_JA != 1)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

@@ -491,11 +491,19 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                 f16_kernel = model.arithmetic().get(
                     'rnn0/recurrence_{}'.format(dom[4:])) == 'fp16x3'
                 peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if f16_kernel else FP32_MFMA_PEAK_TFLOPS
+                # 17..32 rows, LSTM-1024, cuDNN semantics, half of the chip: the staggered-tile
+                # kernel (prnn_bwd16s_kernel) unless CTCASR_RNN_STAGGER=0
+                staggered = (dom == 'rnn_bwd' and f16_kernel and rnn_cell == 'lstm' and
+                             hidden == 1024 and 16 < batch <= 32 and cfg.cudnn and
+                             not args.rnn_bwd_whole_chip and
+                             bool(getattr(model, 'rnn_stagger_flag', 0)))
                 roofline = {
                     'kernel': 'prnn_{}{}_kernel<{}> (persistent, LDS-resident recurrent weights; '
-                              'one launch = {:.0f} time steps x 2 directions, batch {})'.format(
-                                  dom[4:], '16' if f16_kernel else '', rnn_cell.upper(),
-                                  launch_steps, batch),
+                              'one launch = {:.0f} time steps x 2 directions, batch {}{})'.format(
+                                  dom[4:], ('16s' if staggered else '16') if f16_kernel else '',
+                                  rnn_cell.upper(), launch_steps, batch,
+                                  '; the two 16-row tiles staggered by half a step'
+                                  if staggered else ''),
                     'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': round(peak, 1), 'unit': 'TFLOP/s',
                     'frac': round(achieved / peak, 4),

@@ -448,7 +448,8 @@ class CTCModel:
         # recurrence launch)
         # (2 since the staggered backward recurrence: the recurrence launches got shorter, the
         # weight gradients beside them are what the data-gradient kernel then shares the chip with -
-        # C3 48.0 -> 47.3 ms per step on one box, 47.6 -> 47.0 on another; 3: the same)
+        # C3 48.0 -> 47.3 ms per step on one box, 47.6 -> 47.0 on another, 47.6 -> 46.7 with the
+        # layer input packed once for both directions; 3: the same; C2: no difference)
         self.own_wgrad_parts = int(os.environ.get('CTCASR_WGRAD_PARTS', '2'))
         # layers whose input has no bound (behind a ReLU-cell layer: the reference's default model)
         # in an fp16 form as well - the input split with a scale per ROW for the projection (as a
@@ -460,10 +461,10 @@ class CTCModel:
         # of dx (half of the K axis) is multiplied beside the next launch ('side': on the side
         # stream ahead of the range's weight gradients, 'own': on a third stream), only the last
         # launch's share stays on the main stream ('0': the whole product behind the last launch)
-        # ('side' since the staggered backward recurrence + 2-part weight-gradient tiles: another
-        # 0.2 - 0.3 ms of the C3 step in two A/Bs; it had measured no gain while the recurrence
-        # launches were the longer side of every layer)
-        self.dgrad_early = os.environ.get('CTCASR_DGRAD_EARLY', 'side')
+        # (measured again with the staggered backward recurrence and 2-part weight-gradient
+        # tiles: 'side' 46.58 / 46.79 ms against 46.56 / 46.78 for C3, 14.42 / 14.36 against
+        # 14.23 / 14.19 for C2 - the plain form stays the default)
+        self.dgrad_early = os.environ.get('CTCASR_DGRAD_EARLY', '0')
         self._dgrad_stream = None
         # the forward recurrence's own product h_(t-1) W_hh^T as two fp16 pieces per operand and
         # three products on the fp16 matrix pipe (LSTM-1024 persistent kernel; |h| <= 1, W_hh
@@ -1397,8 +1398,10 @@ class CTCModel:
                         hip.split_bf16(drec.view(rows, 2 * gh)[rng, cols], split_gemm.B_ORDER,
                                        out=drs.buf[rng, :, cols])
 
+            x_packs = {}       # (first row, rows) -> the layer input's rows packed for the own kernel
+
             def partial_weight_grads_f16(lo, hi, name=name, dxw2d=dxw2d, drec=drec, x16=x16,
-                                         y16=y16, x=x, y=y, colmax=None):
+                                         y16=y16, x=x, y=y, colmax=None, x_packs=x_packs):
                 # steps [lo, hi) in the fp16 form: per direction one column-scaled split of the
                 # finished rows of dxw (GRU: and of drec) feeds both W_ih's and W_hh's product
                 # (``colmax``: the column maxima of these rows, left by the recurrence launch)
@@ -1417,7 +1420,13 @@ class CTCModel:
                         scale, inv = hip.colmax_scale(d_rows) if colmax is None else \
                             hip.colscale_from_max(colmax[d * gh:(d + 1) * gh])
                         d_pk = hip.wgrad16_pack(d_rows, n_rows, 0, stages, 1.0, col_scale=scale)
-                        x_pk = hip.wgrad16_pack(x.view(rows, -1), rows, a * batch, stages, x16[1])
+                        # (the two directions meet the same rows of the layer's input in
+                        # different launches - times [lo, hi) here, mirrored there: packed once)
+                        x_pk = x_packs.pop((a, n_rows), None)
+                        if x_pk is None:
+                            x_pk = hip.wgrad16_pack(x.view(rows, -1), rows, a * batch, stages,
+                                                    x16[1])
+                            x_packs[(a, n_rows)] = x_pk
                         y_pk = hip.wgrad16_pack(
                             y.view(rows, 2 * hidden)[:, d * hidden:(d + 1) * hidden], rows,
                             (a + (1 if d else -1)) * batch, stages, y16[1])

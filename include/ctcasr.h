@@ -193,7 +193,7 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
  * tiles staggered by half a step (prnn_bwd16s_kernel: each tile with its own arrival counters, one
  * tile's exchange round trip under the other tile's loads) instead of both behind one barrier.
  * Same results bit for bit; every launch of a pass may choose freely.  Calls with per-row lengths
- * and other shapes ignore it. */
+ * and other shapes ignore it.  (ABI v6) */
 #define CTCASR_RNN_STAGGER 64
 /* Residency ticket (bits 8..31 of `flags`, 0 = none): a persistent launch that carries one posts
  * it in the workspace once ALL of its workgroups are running; ctcasr_rnn_resident_gate() makes

@@ -501,6 +501,37 @@ def test_rnn_bwd_staggered_tiles_equal_one_barrier(hip, xcd, dims):
     assert torch.equal(a, b)
 
 
+def test_staggered_launch_leaves_at_once_when_the_time_out_word_is_set(hip):
+    """The sticky time-out word ends a staggered-tile launch like every other persistent launch
+    (nothing written, no spinning), and the pass after the poll is whole again."""
+    import time
+    num_steps, batch, hidden = 300, 32, 1024
+    g = torch.Generator(device=DEV).manual_seed(6)
+    xw = torch.randn(num_steps, batch, 2, 4 * hidden, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, 4 * hidden, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g)
+    flags = hip.RNN_F16 | hip.RNN_XCD_SPLIT | hip.RNN_STAGGER
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh)
+    w_hh_t = hip.transpose_batched(w_hh)
+    want = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, workspace=ws, flags=flags)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    address = hip.rnn_timeout_words('lstm', ws, num_steps, batch, hidden)[0]
+    offset = address - ws.data_ptr()
+    ws[offset:offset + 4].view(torch.int32).fill_(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dxw = torch.full_like(want, 7.0)
+    hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, dxw=dxw, workspace=ws, flags=flags)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05
+    assert bool((dxw == 7.0).all())
+    with pytest.raises(hip.CtcAsrError, match='time'):
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    again = hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, workspace=ws, flags=flags)
+    hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+    assert torch.equal(again, want)
+
+
 @pytest.mark.parametrize('magnitude', [1e-6, 3.0, 40.0, 3000.0])
 def test_rnn_fwd_f16_scales_its_weights_itself(hip, magnitude):
     """No assumption about the size of W_hh: every workgroup scales its slice by the power of

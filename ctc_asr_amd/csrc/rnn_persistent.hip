@@ -2254,6 +2254,9 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
 #ifndef PRNN_B16S_JP
 #define PRNN_B16S_JP 5                  // pair at which the poll loads for them are issued
 #endif
+#ifndef PRNN_B16S_XCD_EXCL
+#define PRNN_B16S_XCD_EXCL 0            // probe: the launch on XCDs 0 - 3 only (see the kernel)
+#endif
 #ifndef PRNN_B16S_JA
 #define PRNN_B16S_JA 1                  // pair at which the phase before posts its arrival
 #endif
@@ -2276,10 +2279,18 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16s_kernel(PArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if PRNN_B16S_XCD_EXCL
+    // PROBE (timing of a placement): the launch has twice the workgroups; those that land on XCDs
+    // 4 - 7 leave at once, the others fill XCDs 0 - 3 - direction 0 on XCDs 0, 1, direction 1 on 2, 3
+    if (((int)blockIdx.x & 7) >= 4) return;
+    const int dir = p.dir0 + (((int)blockIdx.x & 7) >> 1);
+    const int slice = ((int)blockIdx.x >> 3) * 2 + ((int)blockIdx.x & 1);
+#else
     const int wg = blockIdx.x % (p.ndir * p.nwg);
     const bool split = p.xcd_split && p.ndir == 2;
     const int dir = p.dir0 + (split ? (wg & 7) >> 2 : wg / p.nwg);
     const int slice = split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
+#endif
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * 16;
@@ -3651,7 +3662,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                     p, lds(2, 4), s);
             return launch_persistent(
                 prnn_bwd16s_kernel<PRNN_B16S_D, PRNN_B16S_JW, PRNN_B16S_JP, PRNN_B16S_JA>, p,
-                lds(2, 4), s);
+                lds(2, 4), s, 1, PRNN_B16S_XCD_EXCL ? 2 : 1);
         }
         if (mt == 2 && half_chip)
             return launch_persistent(prnn_bwd16_kernel<2, PRNN_B16_NW2, PRNN_B16_D2>, p, lds(2, PRNN_B16_NW2), s, PRNN_B16_NW2 / 4);
@@ -3740,7 +3751,7 @@ extern "C" unsigned ctcasr_build_flags(void) {
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
         PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2 ||
         PRNN_XCD_TILE_PAIRS != 1 || PRNN_B16S_D != 8 || PRNN_B16S_JW != 7 || PRNN_B16S_JP != 5 ||
-        PRNN_B16S_JA != 1)
+        PRNN_B16S_JA != 1 || PRNN_B16S_XCD_EXCL != 0)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

@@ -2232,6 +2232,9 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
 //                  producers, then - from pair JW on - with the FIRST producers of the next phase
 //                  (tile X ^ 1: the same step for X = 0, the next step for X = 1);
 //                  reduce + cell derivative + publish of (s, X) while those loads are in flight.
+//                  (Measured: JW = the last pair - all of the next phase's first half requested at
+//                  once, just before the publish part - beats every earlier point: a poll that is
+//                  looked at before the arrivals are visible stalls the whole stream.)
 //   arrival of (s, X): vmcnt counts loads and stores in ONE in-order queue on gfx950, so the
 //                  publish stores cannot be waited for alone - a 4-byte marker load is issued right
 //                  behind them and the arrival is posted where the next phase's main loop first
@@ -2246,7 +2249,7 @@ __global__ void __launch_bounds__(64 * NW) prnn_bwd16_kernel(PArgs p) {
 // <2, 4, 5> - results are bit-identical to it (tests/test_gpu_kernels.py).
 // ---------------------------------------------------------------------------------------------
 #ifndef PRNN_B16S_D
-#define PRNN_B16S_D 8                   // ring slots = producers of a tile in flight per wave (8 / 16)
+#define PRNN_B16S_D 8                   // ring slots = producers of a tile in flight per wave
 #endif
 #ifndef PRNN_B16S_JW
 #define PRNN_B16S_JW 7                  // pair at which the next phase's loads may start (>= (16 - D) / 2)

@@ -114,6 +114,7 @@ struct PArgs {
     int prof;              // record phase timings of workgroup 0
     unsigned ticket;       // != 0: post it once every workgroup of this launch is running
     int xcd_split;         // fp16 kernels: direction 0 on XCDs 0 - 3, direction 1 on XCDs 4 - 7
+    unsigned *kp;          // backward, K-pair form: KPairWords + the hand-off slots (prnn_kp_bytes)
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) {
@@ -2715,6 +2716,582 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16s_kernel(PArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// prnn_bwd16k_kernel (round 6): the staggered kernel with the K axis split over
+// PAIRS of workgroups (a 2-D decomposition of dh = dgates x W_hh^T: 32 x 2 instead of 64 x 1).
+//
+// prnn_bwd16s_kernel is bound by what a CU pulls per phase: every workgroup needs the dgates of ALL
+// 4H gate columns of a tile's rows (256 KB per tile and step; its phase timers say 5.5 of 7.5 us
+// per step is waiting for those bytes, in two exposed round trips of 8 producers each).  Here the
+// workgroups {slice, slice ^ PBIT} - the two sit on ONE XCD - share 32 hidden units: each holds ONE
+// K half (32 producers) of the weights of all 32 units (the same 256 KB: 8 producers x 2 N tiles
+// per wave, half in LDS, half in registers), reads only that half's blocks (128 KB per tile and
+// step, ALL of a wave's 8 producers in flight at once: one round trip), multiplies them into TWO
+// partial tiles [16 rows x 16 units] and hands the partner the tile of the partner's units:
+// 1 KB per tile and step, through the XCD's L2.
+//
+// The hand-off is data-tagged - no flag, no drain: every 4-byte word carries the parity of the
+// slot's write count in its lowest significand bit (the word is a partial sum of products that
+// are good to 22 bits; the bit, cleared again by the receiver, costs < 2^-23 of the partner's half
+// of dh - and the result does not depend on the count).  The count at the start
+// of a launch is kept in the workspace (KPairWords.total, advanced by the launch's last workgroup
+// to leave), so a slot's current content never looks like the next one.  The receiver cannot use
+// vector loads: vmcnt is one in-order queue, and at that point the next phase's 39 loads are in
+// flight in front of anything it could issue - it polls with SCALAR loads (s_load_dwordx16 glc:
+// lgkmcnt; measured: coherent with another CU's stores through L2, tools/pair_handoff) and spreads
+// the 64 words over its lanes (v_writelane).  One hop: 0.6 - 0.7 us against 1.2 with a flag.
+//
+// Everything a workgroup PUBLISHES (exchange blocks, inverse scales, dxw, column maxima, bias
+// gradients) is the staggered kernel's: dgrad16 / wgrad16 read it unchanged.  The sums differ in
+// their order (own K half + partner's K half instead of four K quarters), so results agree with
+// prnn_bwd16s_kernel to rounding, not bit for bit; step ranges of THIS kernel are bit-identical to
+// one launch.
+// ---------------------------------------------------------------------------------------------
+#ifndef PRNN_B16K_JW
+#define PRNN_B16K_JW 3                  // pair (of 4) at which the next phase's loads start
+#endif
+#ifndef PRNN_B16K_JP
+#define PRNN_B16K_JP 2                  // pair at which the poll loads for them are issued
+#endif
+#ifndef PRNN_B16K_JA
+#define PRNN_B16K_JA 1                  // pair at which the phase before posts its arrival
+#endif
+#ifndef PRNN_B16K_SC1
+#define PRNN_B16K_SC1 0                 // hand-off stores write-through (1) or plain (0: one L2)
+#endif
+#ifndef PRNN_B16K_PROBE
+#define PRNN_B16K_PROBE 0               // timing probes (wrong results): 1 = nobody waits for the partner
+#endif
+#ifndef PRNN_B16K_SLEEP
+#define PRNN_B16K_SLEEP 1               // s_sleep between two looks at the partner's slot
+#endif
+struct KPairWords {
+    unsigned total;         // hand-offs every slot has seen before this launch (parity = tag base)
+    unsigned pad0[15];
+    unsigned done;          // workgroups of the launch that have left
+    unsigned pad1[47];
+};
+__host__ __device__ inline size_t prnn_kp_bytes() {
+    // header, then [dir][slice][tile][256] words written by the slice's partner
+    return sizeof(KPairWords) + (size_t)2 * PRNN_RS_NWG * 2 * 256 * sizeof(unsigned);
+}
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+template <int JW, int JP, int JA, bool PROF = false>
+__global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16k_kernel(PArgs p) {
+    constexpr int H = PRNN_RS_H, GH = 4 * H;
+    constexpr int NW = 4, NTH = 256, NPW = 8, DD = NPW;
+    constexpr int QS = NPW * 4 * 2, QL = QS / 2, REGW = QS - QL;    // slot = ((P 2 + m) 2 + piece) 2 + n
+    constexpr int RED_FLOATS = NW * 16 * 17, IVL = 4 * NPW;
+    static_assert(JW < NPW / 2 && JP <= JW && JA <= JP, "pipeline points");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    resident_signal(p.sync, p.ticket);
+    if (launch_poisoned(p.sync)) return;
+    u32x4 *frag = reinterpret_cast<u32x4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 64 * sizeof(u32x4));   // [2 tiles][2 n]
+    float4 *invs = reinterpret_cast<float4 *>(red + 4 * RED_FLOATS);       // [2 tiles][NW][IVL]
+    float *wave_top = reinterpret_cast<float *>(invs + 2 * NW * IVL);
+    unsigned *arrived = reinterpret_cast<unsigned *>(wave_top + 4);        // [2 tiles]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x % (p.ndir * p.nwg);
+    const bool split = p.xcd_split && p.ndir == 2;
+    const int dir = p.dir0 + (split ? (wg & 7) >> 2 : wg / p.nwg);
+    const int slice = split ? (wg >> 3) * 4 + (wg & 3) : wg % p.nwg;
+    // workgroup b runs on XCD b % 8: slices that differ in this bit share an XCD
+    const int pbit = split ? 4 : 8;
+    const int partner = slice ^ pbit, kh = (slice & pbit) ? 1 : 0;
+    const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
+    const int B = p.B, T = p.T, BS = p.BS;
+    const int u0 = slice * 16;
+    const int pb = 32 * kh + NPW * wave;       // this wave's first producer
+    if (tid < 2) arrived[tid] = 0u;
+    KPairWords *kpw = reinterpret_cast<KPairWords *>(p.kp);
+    unsigned *kp_slots = p.kp + sizeof(KPairWords) / sizeof(unsigned);
+    const unsigned kp_base = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+        &kpw->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+
+    // ---- weights: the K half `kh` of R^T for this workgroup's 16 units (n = 0) and the partner's
+    // (n = 1) as scaled fp16 pieces, fragments as in prnn_bwd16_kernel ---------------------------
+    float w_scale;
+    {
+        float m = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float *wrow = p.w + ((size_t)dir * H + (n ? partner : slice) * 16 + (tid & 15)) * GH +
+                                512 * kh;
+            for (int g = 0; g < 4; ++g)
+                for (int x = (tid >> 4) * 4; x < 512; x += NTH / 16 * 4) {
+                    const float4 v = ldg4(wrow + (size_t)g * H + x);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+        }
+        m = wave_max(m);
+        if (lane == 0) wave_top[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wave_top[0], wave_top[1]), fmaxf(wave_top[2], wave_top[3]));
+        const unsigned bits = __float_as_uint(m);
+        const int e = (int)((bits >> 23) & 0xFF) - 127;
+        const int se = bits == 0u ? 0 : min(max(14 - e, -60), 60);
+        w_scale = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+    const float out_scale = 1.0f / w_scale;
+    u32x4 wreg[REGW];
+    {
+        auto pieces = [&](int pm, int n, u32x4 &first, u32x4 &second) {
+            const float *wcol = p.w + ((size_t)dir * H + (n ? partner : slice) * 16 + (lane & 15)) * GH +
+                                16 * (pb + (pm >> 1)) + 8 * (pm & 1) + 2 * (lane >> 4);
+            unsigned q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                q[e] = f16_pieces(wcol[(size_t)(e & 3) * H + (e >> 2)] * w_scale);
+            first = (u32x4){(q[0] & 0xFFFFu) | (q[1] << 16), (q[2] & 0xFFFFu) | (q[3] << 16),
+                            (q[4] & 0xFFFFu) | (q[5] << 16), (q[6] & 0xFFFFu) | (q[7] << 16)};
+            second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
+                             (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
+        };
+        for (int pm = 0; pm < QL / 4; ++pm)
+            for (int n = 0; n < 2; ++n) {
+                u32x4 first, second;
+                pieces(pm, n, first, second);
+                frag[(wave * QL + (pm * 2 + 0) * 2 + n) * 64 + lane] = first;
+                frag[(wave * QL + (pm * 2 + 1) * 2 + n) * 64 + lane] = second;
+            }
+#pragma unroll
+        for (int pm = 0; pm < REGW / 4; ++pm)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                pieces(QL / 4 + pm, n, wreg[(pm * 2 + 0) * 2 + n], wreg[(pm * 2 + 1) * 2 + n]);
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.xchg, 0, (int)((size_t)(T + 1) * 2 * B * GH * sizeof(float)), 0x00020000);
+    const size_t x_step = (size_t)2 * B * GH;
+    const size_t x_base = x_step;
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.rs, 0, (int)prnn_b16_scale_bytes(T), 0x00020000);
+    constexpr unsigned S_STEP = 2u * (H / 16) * PRNN_B16_SCALE_ROWS * sizeof(float);
+    const int rnum = 0x7FFFFFFF;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.dy), 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cells, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dxw, 0, rnum, 0x00020000);
+    const __amdgpu_buffer_rsrc_t kp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        kp_slots, 0, (int)(prnn_kp_bytes() - sizeof(KPairWords)), 0x00020000);
+
+    // ---- one item per thread and tile (row x * 16 + (tid >> 4), unit tid & 15), no per-row
+    // lengths: as in prnn_bwd16s_kernel -------------------------------------------------------------
+    const int unit = u0 + (tid & 15);
+    float dc_state[2], dbs[2][4], cmx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int brow = x * 16 + (tid >> 4);
+        dc_state[x] = 0.f;
+        if (p.s_hi < T && brow < B) dc_state[x] = p.carry[((size_t)dir * B + brow) * H + unit];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbs[x][g] = 0.f;
+    }
+    auto ldf2 = [](__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) -> float {
+        return __uint_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)uni_off, 0));
+    };
+    float c_dy[2], c_gi[2], c_gf[2], c_gg[2], c_go[2], c_cv[2], c_cp[2];
+    auto cell_prefetch = [&](int s, int x) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        s = max(s, 0);                    // (behind the launch's last phase: any valid address)
+        const unsigned t = (unsigned)(dir == 0 ? s : T - 1 - s);
+        const unsigned tp = s > 0 ? (unsigned)(dir == 0 ? s - 1 : T - s) : t;
+        const unsigned unit = (unsigned)(u0 + (tq & 15));
+        const unsigned e = (unsigned)((min(x * 16 + (tq >> 4), B - 1) * 2 + dir) * H) + unit;
+        const unsigned slab = t * (unsigned)BS * 2u * H * 4u;               // bytes of [BS, 2, H] rows
+        c_dy[x] = ldf2(dy_rsrc, e * 4u, slab);
+        const unsigned ge = (e * 4u - 3u * unit) * 4u;
+        c_gi[x] = ldf2(g_rsrc, ge, slab * 4u);
+        c_gf[x] = ldf2(g_rsrc, ge + H * 4u, slab * 4u);
+        c_gg[x] = ldf2(g_rsrc, ge + 2 * H * 4u, slab * 4u);
+        c_go[x] = ldf2(g_rsrc, ge + 3 * H * 4u, slab * 4u);
+        c_cv[x] = ldf2(c_rsrc, e * 4u, slab);
+        // (step 0 has no cell state before it: the value is dropped where it is USED - a select
+        // here waits for this load, the youngest of the phase, and with it for the whole ring)
+        c_cp[x] = ldf2(c_rsrc, e * 4u, tp * (unsigned)BS * 2u * H * 4u);
+    };
+
+    unsigned ablock[2];                   // scalar: byte offset of (step, dir) in the exchange buffer
+    float4 iv_next;
+    auto lane_aoff = [&](int x) -> unsigned {
+        const int row = min(x * 16 + (lane & 15), B - 1);
+        return (unsigned)(((size_t)(lane >> 4) * B * 4 + (size_t)row * 4) * sizeof(float));
+    };
+    auto tile_addresses = [&](int s, int x) {
+        ablock[x] = (unsigned)(((s + 1 < T ? x_base + (size_t)(s + 1) * x_step : 0) +
+                                (size_t)dir * B * GH) * sizeof(float));
+        iv_next = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
+                                         (unsigned)(((dir * (H / 16) + pb + ((lane >> 2) & (NPW - 1))) *
+                                                     PRNN_B16_SCALE_ROWS + x * 16 + 4 * (lane & 3)) *
+                                                    sizeof(float)));
+    };
+    u32x4 a[DD][4];                       // ALL of the wave's 8 producers of a tile in flight
+    const unsigned wave_off = (unsigned)(pb * 4) * (unsigned)B * 64u;
+    auto issue = [&](int x, int P) {
+        unsigned bstride = (unsigned)B * 64u;
+        asm volatile("" : "+s"(bstride));
+        const unsigned lo = lane_aoff(x);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)       // g = half * 2 + piece
+            a[P][g] = load16u(x_rsrc, lo, ablock[x] + wave_off + (unsigned)(P * 4 + g) * bstride);
+    };
+    auto poll = [&](int x) -> unsigned {  // lanes 0 .. 7: the arrival counter of group `lane`
+        unsigned v = 0xFFFFFFFFu;
+        if (lane < PRNN_GROUPS)
+            v = __hip_atomic_load(&p.sync->group_cnt[dir][x][lane][0], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto bfrag = [&](int sl) -> u32x4 {   // compile-time slot after unrolling
+        return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
+    };
+
+    // phase timers (CTCASR_RNN_PROF, second instantiation): [0] marker wait, [1] poll wait, [2] the
+    // rest of the main loops, [3] reduce + cell derivative + publish, [5] waiting for the partner
+    unsigned long long pt[4] = {0, 0, 0, 0}, spins_total = 0, hop_total = 0;
+    unsigned long long t_issue = 0, first_wait = 0, first_lat = 0, all_lat = 0;   // (PROF) A operand
+    const bool profw = PROF && p.prof && blockIdx.x == 0 && wave == 0;
+    unsigned marker = 0u;
+
+    auto phase = [&](auto xc, int s, bool prev_arrives, bool has_next, bool next_waits) {
+        constexpr int X = decltype(xc)::value, XN = X ^ 1;
+        const int sn = X == 0 ? s : s - 1;                  // the next phase's step
+        f32x4 total[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        unsigned pv = 0xFFFFFFFFu;
+        unsigned long long c0 = 0, waited = 0;
+        if constexpr (PROF) c0 = profw ? wall_clock64() : 0;
+#pragma unroll
+        for (int j = 0; j < NPW / 2; ++j) {
+            if constexpr (PROF) {
+                if (j == 0 && profw) {      // the first producer's granules: how long after their request
+                    const unsigned long long w0 = wall_clock64();
+                    asm volatile("" ::"v"(a[0][0]), "v"(a[0][3]) : "memory");
+                    const unsigned long long w1 = wall_clock64();
+                    first_wait += w1 - w0;
+                    first_lat += w1 - t_issue;
+                }
+            }
+            if (j == JA && prev_arrives) {
+                // the marker is back -> the publish stores issued in front of it are complete
+                unsigned long long w0 = 0;
+                if constexpr (PROF) w0 = profw ? wall_clock64() : 0;
+                asm volatile("" ::"v"(marker) : "memory");
+                if constexpr (PROF) {
+                    if (profw) {
+                        const unsigned long long w1 = wall_clock64(), d = w1 - w0;
+                        pt[0] += d; waited += d;
+                        all_lat += w1 - t_issue;
+                    }
+                }
+                if (lane == 0) {
+                    const unsigned before = __hip_atomic_fetch_add(
+                        &arrived[XN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((before & 3u) == 3u)
+                        __hip_atomic_fetch_add(&p.sync->group_cnt[dir][XN][grp][0], 1u,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (j == JP && has_next && next_waits) pv = poll(XN);
+            const int P0 = 2 * j, P1 = 2 * j + 1;
+            f32x4 acc[2][2];              // [producer of the pair][n]
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Frag16 w1[2][2], w2[2][2], d1[2], d2[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int pm = (P0 + q) * 2 + m;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        w1[q][n].u = bfrag((pm * 2 + 0) * 2 + n);
+                        w2[q][n].u = bfrag((pm * 2 + 1) * 2 + n);
+                    }
+                    d1[q].u = a[P0 + q][2 * m];
+                    d2[q].u = a[P0 + q][2 * m + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            d1[q].h, w1[q][n].h, m == 0 ? zero : acc[q][n], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            d1[q].h, w2[q][n].h, acc[q][n], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            d2[q].h, w1[q][n].h, acc[q][n], 0, 0, 0);
+            }
+            // the next phase's operands into the slots that came free, as soon as everybody has
+            // published them (unconditional, see prnn_bwd16s_kernel)
+            if (j >= JW) {
+                if (j == JW) {
+                    const unsigned target = (unsigned)group_size * (unsigned)(p.s_hi - 1 - sn);
+                    unsigned long long w1 = 0;
+                    if constexpr (PROF) {
+                        w1 = profw ? wall_clock64() : 0;
+                        asm volatile("" ::"v"(pv) : "memory");
+                        if (profw) { const unsigned long long d = wall_clock64() - w1; pt[1] += d; waited += d; }
+                        w1 = profw ? wall_clock64() : 0;
+                    }
+                    if (__builtin_expect(has_next && next_waits && !__all(pv >= target), 0)) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            __builtin_amdgcn_s_sleep(PRNN_POLL_SLEEP);
+                            const unsigned again = poll(XN);
+                            if constexpr (PROF) spins_total += 1;
+                            if (__all(again >= target)) break;
+                            if (++spins > PRNN_SPIN_LIMIT ||
+                                ((spins & 1023u) == 0 &&
+                                 __hip_atomic_load(&p.sync->error, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT))) {
+                                if (lane == 0)
+                                    __hip_atomic_store(&p.sync->error, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        if constexpr (PROF) {
+                            if (profw) { const unsigned long long d = wall_clock64() - w1; pt[1] += d; waited += d; }
+                        }
+                    }
+                    tile_addresses(sn, XN);
+                    if constexpr (PROF) t_issue = profw ? wall_clock64() : 0;
+#pragma unroll
+                    for (int q = 0; q <= P1; ++q) issue(XN, q);
+                    cell_prefetch(sn, XN);
+                } else {
+                    issue(XN, P0);
+                    issue(XN, P1);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 ivq = invs[(X * NW + wave) * IVL + 4 * (P0 + q) + (lane >> 4)];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    total[n][0] += acc[q][n][0] * ivq.x;
+                    total[n][1] += acc[q][n][1] * ivq.y;
+                    total[n][2] += acc[q][n][2] * ivq.z;
+                    total[n][3] += acc[q][n][3] * ivq.w;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- reduce over the waves' K shares; the partner's tile goes out, ours comes in ---------
+        if constexpr (PROF) {
+            asm volatile("" ::"v"(total[0][0]));
+            if (profw) { const unsigned long long c = wall_clock64(); pt[2] += c - c0 - waited; c0 = c; }
+        }
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lq = tq & 63, iu = tq & 15, unit = u0 + iu, ib = tq >> 4;
+        float *redx = red + X * 2 * RED_FLOATS;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                redx[n * RED_FLOATS + (wave * 16 + 4 * (lq >> 4) + r) * 17 + (lq & 15)] =
+                    total[n][r] * out_scale;
+        __syncthreads();
+        const unsigned tag = (kp_base + (unsigned)(p.s_hi - s)) & 1u;
+        {
+            float theirs = redx[RED_FLOATS + ib * 17 + iu];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) theirs += redx[RED_FLOATS + (w * 16 + ib) * 17 + iu];
+            const unsigned lo = (unsigned)tq * 4u;
+            const unsigned uo = (unsigned)(((dir * PRNN_RS_NWG + partner) * 2 + X) * 256) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32((__float_as_uint(theirs) & ~1u) | tag, kp_rsrc,
+                                                  (int)lo, (int)uo, PRNN_B16K_SC1 ? 16 : 0);
+        }
+        float rec = redx[ib * 17 + iu];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) rec += redx[(w * 16 + ib) * 17 + iu];
+        {
+            // the partner's half of our tile: 64 words per wave, scalar loads past the scalar cache
+            const unsigned *rp = kp_slots + ((dir * PRNN_RS_NWG + slice) * 2 + X) * 256 + wave * 64;
+            unsigned long long h0 = 0;
+            if constexpr (PROF) h0 = profw ? wall_clock64() : 0;
+            unsigned rv = 0u, spins = 0;
+            for (;;) {
+                i32x16 r0, r1, r2, r3;
+                asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\t"
+                             "s_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3) : "s"(rp) : "memory");
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(rv) : "s"(r0[i]), "n"(i));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(rv) : "s"(r1[i]), "n"(i + 16));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(rv) : "s"(r2[i]), "n"(i + 32));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(rv) : "s"(r3[i]), "n"(i + 48));
+                }
+                if (PRNN_B16K_PROBE == 1 || __all((rv & 1u) == tag)) break;
+                if constexpr (PROF) spins_total += 1;
+                if (++spins > PRNN_SPIN_LIMIT ||
+                    ((spins & 1023u) == 0 &&
+                     __hip_atomic_load(&p.sync->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (lane == 0)
+                        __hip_atomic_store(&p.sync->error, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(PRNN_B16K_SLEEP);
+            }
+            if constexpr (PROF) {
+                if (profw) hop_total += wall_clock64() - h0;
+            }
+            rec += __uint_as_float(rv & ~1u);     // (the tag bit dropped: the same value whatever the count)
+        }
+        // ---- cell derivative, publish: prnn_bwd16s_kernel's ---------------------------------------
+        {
+            const bool has = X * 16 + ib < B;
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has)
+                lstm_cell_bwd_pinned(c_dy[X] + rec, dc_state[X], c_gi[X], c_gf[X], c_gg[X], c_go[X],
+                                     c_cv[X], s == 0 ? 0.f : c_cp[X], dg);
+            float mx = fmaxf(fmaxf(fabsf(dg[0]), fabsf(dg[1])), fmaxf(fabsf(dg[2]), fabsf(dg[3])));
+            mx = row16_max(mx);
+            const unsigned mbits = __float_as_uint(mx);
+            const int me = (int)((mbits >> 23) & 0xFF) - 127;
+            const int mse = mbits == 0u ? 0 : min(max(13 - me, -100), 100);
+            const float rscale = __uint_as_float((unsigned)(mse + 127) << 23);
+            const float rinv = __uint_as_float((unsigned)(127 - mse) << 23);
+            unsigned q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) q[g] = f16_pieces(dg[g] * rscale);
+            const bool odd = (tq & 1) != 0;
+            const unsigned f01 = (q[0] & 0xFFFFu) | (q[1] << 16), f23 = (q[2] & 0xFFFFu) | (q[3] << 16);
+            const unsigned s01 = (q[0] >> 16) | (q[1] & 0xFFFF0000u),
+                           s23 = (q[2] >> 16) | (q[3] & 0xFFFF0000u);
+            const unsigned give01 = odd ? f01 : s01, give23 = odd ? f23 : s23;
+            const unsigned got01 = dpp_u32<0xB1>(give01), got23 = dpp_u32<0xB1>(give23);
+            const u32x4 v = odd ? (u32x4){got01, got23, s01, s23} : (u32x4){f01, f23, got01, got23};
+            if (has) {
+                const unsigned lo = (unsigned)(
+                    ((size_t)((slice * 2 + (iu >> 3)) * 2 + (odd ? 1 : 0)) * B * 16 +
+                     (size_t)((iu >> 1) & 3) * B * 4 + (size_t)(X * 16 + ib) * 4) * sizeof(float));
+                const unsigned uo = (unsigned)((x_base + (size_t)s * x_step + (size_t)dir * B * GH) *
+                                               sizeof(float));
+                __builtin_amdgcn_raw_buffer_store_b128(v, x_rsrc, (int)lo, (int)uo, 16);
+            }
+            const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 0));
+            const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 16));
+            const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 32));
+            const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rinv), 48));
+            if (lq == 0)
+                store16_sc1(s_rsrc,
+                            (unsigned)s * S_STEP +
+                                (unsigned)(((dir * (H / 16) + slice) * PRNN_B16_SCALE_ROWS + X * 16 +
+                                            ib) * sizeof(float)),
+                            r0, r1, r2, r3);
+            if (has) {      // dxw in its GEMM layout: read after the launch only
+                const unsigned t = (unsigned)(dir == 0 ? s : T - 1 - s);
+                const unsigned lo = (unsigned)(((X * 16 + ib) * 2 + dir) * GH + unit) * 4u;
+                const unsigned uo = t * (unsigned)BS * 2u * GH * 4u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg[g]), dx_rsrc,
+                                                          (int)(lo + (unsigned)g * H * 4u), (int)uo, 0);
+                    dbs[X][g] += dg[g];
+                    cmx[g] = fmaxf(cmx[g], fabsf(dg[g]));
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        marker = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, 0, 0, 0);
+        if (lane < IVL) invs[(XN * NW + wave) * IVL + lane] = iv_next;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PROF) {
+            if (profw) pt[3] += wall_clock64() - c0;
+        }
+    };
+
+    {
+        const int s = p.s_hi - 1;
+        tile_addresses(s, 0);
+#pragma unroll
+        for (int q = 0; q < DD; ++q) issue(0, q);
+        cell_prefetch(s, 0);
+        if (lane < IVL) invs[(0 * NW + wave) * IVL + lane] = iv_next;
+    }
+    for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
+        phase(std::integral_constant<int, 0>{}, s, s < p.s_hi - 1, true, s < p.s_hi - 1);
+        phase(std::integral_constant<int, 1>{}, s, s > p.s_lo, s > p.s_lo, true);
+    }
+    __syncthreads();        // every wave is through its last poll
+    if (tid == 0) {
+        if (p.s_hi - p.s_lo >= 2) {
+            counters_done(p.sync, dir, 0, p.nwg);
+            counters_done(p.sync, dir, 1, p.nwg);
+        }
+        // the last workgroup to leave advances the slots' write count (every workgroup read it at
+        // its start, and is through its last hand-off)
+        const unsigned before = __hip_atomic_fetch_add(&kpw->done, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1 == (unsigned)(p.ndir * p.nwg)) {
+            __hip_atomic_store(&kpw->total, kp_base + (unsigned)(p.s_hi - p.s_lo), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&kpw->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (PROF) {
+        if (profw && lane == 0) {
+            for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+            p.sync->prof[8] = spins_total;
+            p.sync->prof[9] = hop_total;
+            p.sync->prof[10] = first_wait;
+            p.sync->prof[11] = first_lat;
+            p.sync->prof[12] = all_lat;
+        }
+    }
+    if (p.s_lo > 0) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int brow = x * 16 + (tid >> 4);
+            if (brow < B) p.carry[((size_t)dir * B + brow) * H + unit] = dc_state[x];
+        }
+    }
+    if (p.dbias || p.colmax) {
+        float *sums = red, *tops = reinterpret_cast<float *>(frag);     // (the weights are done with)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                sums[tid + x * NTH] = dbs[x][g];
+                tops[tid + x * NTH] = cmx[g];
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float sum = 0.f, top = 0.f;
+                for (int r = 0; r < 32; ++r) {
+                    sum += sums[r * 16 + tid];
+                    top = fmaxf(top, tops[r * 16 + tid]);
+                }
+                if (p.dbias) atomicAdd(p.dbias + ((size_t)dir * 4 + g) * H + u0 + tid, sum);
+                if (p.colmax)
+                    atomicMax(p.colmax + ((size_t)dir * 4 + g) * H + u0 + tid, __float_as_uint(top));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same backward recurrence on the fp16 matrix pipe for the LSTM at H = 2048 (round 5; the
 // reference's best published models are 4 - 5 x BiLSTM-2048, testruns.md): ONE direction per launch
 // on 256 workgroups of 8 units - 8 x 8192 weights as two fp16 pieces = 256 KB per workgroup, half
@@ -3411,7 +3988,9 @@ static size_t prnn_step_exchange_bytes(int T, int B, int H, int G) {
 // ... and the inverse scales of the fp16 backward kernel
 size_t prnn_exchange_bytes(int T, int B, int H, int G) {
     return prnn_step_exchange_bytes(T, B, H, G) +
-           (G == 4 && H == PRNN_RS_H ? prnn_rs_ring_bytes() + prnn_b16_scale_bytes(T) : 0) +
+           (G == 4 && H == PRNN_RS_H
+                ? prnn_rs_ring_bytes() + ctcasr_align_up(prnn_b16_scale_bytes(T), 256) + prnn_kp_bytes()
+                : 0) +
            (G == 4 && H == PRNN_W16_H ? prnn_w16_scale_bytes(T) : 0) +
            (G == 1 && H == PRNN_R16_H ? prnn_r16_scale_bytes(T) : 0);
 }
@@ -3658,6 +4237,19 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
             return (size_t)128 * 1024 + (size_t)waves * tiles * 16 * 17 * 4 +
                    (size_t)tiles * 256 * 16 + 64;      // (inverse scales: 4 float4 per producer)
         };
+        if (mt == 2 && half_chip && (flags & CTCASR_RNN_KPAIR) && !seq_len) {
+            // K-pair form of the staggered kernel: weights 128 KB, partial tiles [2 tiles][2 n],
+            // inverse scales [2 tiles][4 waves][32] float4
+            p.kp = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(p.rs) +
+                                                ctcasr_align_up(prnn_b16_scale_bytes(T), 256));
+            const size_t kp_lds = (size_t)128 * 1024 + (size_t)4 * 4 * 16 * 17 * 4 +
+                                  (size_t)2 * 4 * 32 * 16 + 64;
+            if (p.prof)
+                return launch_persistent(
+                    prnn_bwd16k_kernel<PRNN_B16K_JW, PRNN_B16K_JP, PRNN_B16K_JA, true>, p, kp_lds, s);
+            return launch_persistent(
+                prnn_bwd16k_kernel<PRNN_B16K_JW, PRNN_B16K_JP, PRNN_B16K_JA>, p, kp_lds, s);
+        }
         if (mt == 2 && half_chip && (flags & CTCASR_RNN_STAGGER) && !seq_len) {
             if (p.prof)
                 return launch_persistent(
@@ -3740,6 +4332,17 @@ int prnn_b16_published(void *sync, int T, int B, int H, const char **xchg, const
 
 size_t prnn_error_offset() { return offsetof(SyncWords, error); }
 
+// The K-pair hand-off words of a block's region (byte offset from its barrier words, size): after
+// a time-out their write counts are undefined - ctcasr_rnn_poll_error zero-fills them with the
+// barrier words.  0 bytes for shapes without them.
+void prnn_kp_region(int T, int B, int H, int G, size_t *offset, size_t *bytes) {
+    *offset = *bytes = 0;
+    if (G != 4 || H != PRNN_RS_H) return;
+    *offset = sizeof(SyncWords) + prnn_step_exchange_bytes(T, B, H, 4) +
+              prnn_rs_ring_bytes() + ctcasr_align_up(prnn_b16_scale_bytes(T), 256);
+    *bytes = prnn_kp_bytes();
+}
+
 int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t s) {
     resident_gate_kernel<<<1, 1, 0, s>>>(reinterpret_cast<SyncWords *>(sync), ticket & 0xFFFFFFu,
                                          (unsigned long long)max_wait_us * 100ull);
@@ -3750,11 +4353,12 @@ int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t
 unsigned dgrad16_build_flags();     // (dgrad16.hip)
 extern "C" unsigned ctcasr_build_flags(void) {
     unsigned flags = dgrad16_build_flags();
-    if (PRNN_PROBE_HALF_LOADS || PRNN_PROBE_RS_Q != 4) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
+    if (PRNN_PROBE_HALF_LOADS || PRNN_PROBE_RS_Q != 4 || PRNN_B16K_PROBE) flags |= CTCASR_BUILD_PROBE_WRONG_RESULTS;
     if (PRNN_GROUPS != 8 || PRNN_XCD_AWARE != 0 || PRNN_CHAIN_LB != 4 || PRNN_CHAIN_REGW != 32 ||
         PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2 ||
         PRNN_XCD_TILE_PAIRS != 1 || PRNN_B16S_D != 8 || PRNN_B16S_JW != 7 || PRNN_B16S_JP != 5 ||
-        PRNN_B16S_JA != 1 || PRNN_B16S_XCD_EXCL != 0)
+        PRNN_B16S_JA != 1 || PRNN_B16S_XCD_EXCL != 0 || PRNN_B16K_JW != 3 || PRNN_B16K_JP != 2 ||
+        PRNN_B16K_JA != 1 || PRNN_B16K_SC1 != 0 || PRNN_B16K_SLEEP != 1)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

@@ -282,6 +282,7 @@ int cell_gates(int cell) {
 extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
 size_t prnn_sync_bytes();
 size_t prnn_error_offset();
+void prnn_kp_region(int T, int B, int H, int G, size_t *offset, size_t *bytes);
 int prnn_resident_gate(void *sync, unsigned ticket, int max_wait_us, hipStream_t s);
 size_t prnn_exchange_bytes(int T, int B, int H, int G);
 int prnn_fwd(int cell, const float *xw, const float *xw_bias, const float *w_hh,
@@ -371,7 +372,7 @@ extern "C" int ctcasr_rnn_fwd_steps(int cell, const float *xw, const float *xw_b
         return CTCASR_ERR_UNSUPPORTED;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
                          CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16 | CTCASR_RNN_XCD_SPLIT |
-                         CTCASR_RNN_STAGGER))
+                         CTCASR_RNN_STAGGER | CTCASR_RNN_KPAIR))
         return CTCASR_ERR_BAD_ARGUMENT;
     if (!xw || !w_hh || !y || !reserve) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
@@ -472,7 +473,7 @@ extern "C" int ctcasr_rnn_bwd_steps(int cell, const float *dy, const float *y,
     if (rc != CTCASR_OK) return rc;
     if (flags & 0xFF & ~(CTCASR_RNN_HALF_CHIP | CTCASR_RNN_WHOLE_CHIP | CTCASR_RNN_ONE_BARRIER |
                          CTCASR_RNN_REDUCE_SCATTER | CTCASR_RNN_F16 | CTCASR_RNN_XCD_SPLIT |
-                         CTCASR_RNN_STAGGER))
+                         CTCASR_RNN_STAGGER | CTCASR_RNN_KPAIR))
         return CTCASR_ERR_BAD_ARGUMENT;
     if (!dy || !y || !w_hh_t || !reserve || !dxw) return CTCASR_ERR_BAD_ARGUMENT;
     if (step_begin < 0 || step_end > T || step_begin >= step_end) return CTCASR_ERR_BAD_ARGUMENT;
@@ -571,6 +572,11 @@ extern "C" int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, in
         // after a time-out the arrival counters are in an undefined state: start over with
         // clean barrier words (this also clears the time-out word)
         if (err && hipMemset(sync, 0, prnn_sync_bytes()) != hipSuccess) return CTCASR_ERR_LAUNCH;
+        // ... and so are the write counts of the K-pair hand-off slots (prnn_bwd16k_kernel)
+        size_t kp_off = 0, kp_bytes = 0;
+        prnn_kp_region(T, prnn_block_rows(B, blk), H, cell_gates(cell), &kp_off, &kp_bytes);
+        if (err && kp_bytes && hipMemset(sync + kp_off, 0, kp_bytes) != hipSuccess)
+            return CTCASR_ERR_LAUNCH;
         timed_out = timed_out || err != 0;
     }
     return timed_out ? CTCASR_ERR_TIMEOUT : CTCASR_OK;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTCASR_ABI_VERSION 6
+#define CTCASR_ABI_VERSION 7
 
 enum {
     CTCASR_OK = 0,
@@ -195,6 +195,14 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
  * Same results bit for bit; every launch of a pass may choose freely.  Calls with per-row lengths
  * and other shapes ignore it.  (ABI v6) */
 #define CTCASR_RNN_STAGGER 64
+/* backward, same calls as CTCASR_RNN_STAGGER (and taking precedence over it): the K-pair form
+ * (prnn_bwd16k_kernel, ABI v7) - pairs of workgroups on one XCD share 32 hidden units, each holds
+ * one K half of their weights, reads only that half of the published dgates (128 KB instead of 256
+ * per tile and step) and hands its partner a [16 x 16] partial tile through L2.  Publishes exactly
+ * what the other fp16 backward kernels publish; results agree with them to rounding (the order of
+ * the K sums differs; the hand-off carries a tag in the lowest significand bit of each partial
+ * sum), step ranges bit-identical to one launch.  Every launch of a pass may choose freely. */
+#define CTCASR_RNN_KPAIR 128
 /* Residency ticket (bits 8..31 of `flags`, 0 = none): a persistent launch that carries one posts
  * it in the workspace once ALL of its workgroups are running; ctcasr_rnn_resident_gate() makes
  * another stream wait for exactly that (bounded).  Use: work for the CUs a half-chip launch

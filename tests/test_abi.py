@@ -45,7 +45,7 @@ def test_host_helper_library_exports_its_header(lib):
 
 
 def test_version_and_error_strings(lib):
-    assert lib.ctcasr_abi_version() == 6
+    assert lib.ctcasr_abi_version() == 7
     assert lib.ctcasr_error_string(0) == b'ok'
     assert b'workspace' in lib.ctcasr_error_string(-3)
     assert lib.ctcasr_error_string(-5) == b'in-kernel wait timed out'

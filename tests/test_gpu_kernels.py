@@ -501,6 +501,89 @@ def test_rnn_bwd_staggered_tiles_equal_one_barrier(hip, xcd, dims):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('xcd', [0, 1])
+@pytest.mark.parametrize('dims', [(12, 32), (7, 17), (61, 27)])
+def test_rnn_bwd_k_pairs(hip, xcd, dims):
+    """CTCASR_RNN_KPAIR (prnn_bwd16k_kernel, round 6): pairs of workgroups share 32 hidden units,
+    each multiplies ONE K half of the published dgates and hands its partner a [16 x 16] partial
+    tile through L2 (words tagged with the parity of the slot's write count).  dxw against autograd
+    through the float64 recurrence within the staggered kernel's error (the sums only differ in
+    their order); column maxima exact; step ranges of any cut - an odd number of steps flips the
+    tag parity the next launch starts from - bit-identical to one launch, repeated passes on one
+    workspace too; what it publishes is what the staggered kernel would publish from the same
+    sums (the data-gradient kernel reads it); the kernels may take turns inside a pass."""
+    num_steps, batch = dims
+    hidden, gh = 1024, 4096
+    g = torch.Generator(device=DEV).manual_seed(47)
+    xw = torch.randn(num_steps, batch, 2, gh, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, gh, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g) * \
+        torch.logspace(-5, 0, batch, device=DEV).view(1, batch, 1)
+    xw64 = xw.double().requires_grad_(True)
+    ref_y = _recurrence_float64('lstm', xw64, w_hh, None, None)
+    (ref_y * dy.double()).sum().backward()
+    ref = xw64.grad
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh)
+    w_hh_t = hip.transpose_batched(w_hh)
+    base = hip.RNN_F16 | (hip.RNN_XCD_SPLIT if xcd else 0)
+    x_off, s_off = hip.dgrad16_published_offsets(num_steps, batch, hidden)
+    x_bytes = (num_steps + 1) * 2 * batch * gh * 4
+    s_bytes = (num_steps + 1) * 2 * 64 * 32 * 4
+
+    def run(flags, cuts=None, alternate=None):
+        db = torch.zeros(2 * gh, device=DEV)
+        colmax = torch.zeros(2 * gh, dtype=torch.int32, device=DEV)
+        dxw = torch.full((num_steps, batch, 2, gh), float('nan'), device=DEV)
+        cuts = cuts or [num_steps, 0]
+        for k, (hi, lo) in enumerate(zip(cuts[:-1], cuts[1:])):
+            hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, None, dxw=dxw, dbias=db, workspace=ws,
+                        steps=(lo, hi), flags=(alternate if alternate and k % 2 else flags),
+                        colmax=colmax)
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+        published = (ws[x_off:x_off + x_bytes].clone(), ws[s_off:s_off + s_bytes].clone())
+        return dxw, db, colmax, published
+
+    def row_err(got):
+        err = (got.double() - ref).abs().amax(dim=(0, 2, 3))
+        return float((err / ref.abs().amax(dim=(0, 2, 3)).clamp_min(1e-30)).max())
+
+    stag = run(base | hip.RNN_STAGGER)
+    want = run(base | hip.RNN_KPAIR)
+    assert torch.isfinite(want[0]).all()
+    e_pair, e_stag = row_err(want[0]), row_err(stag[0])
+    assert e_pair < 1.5 * e_stag + 2e-7, (e_pair, e_stag)
+    assert torch.equal(want[2].view(torch.float32), want[0].abs().amax(dim=(0, 1)).reshape(-1))
+    assert float((want[1] - stag[1]).abs().max()) < 1e-5 * max(1.0, float(stag[1].abs().max()))
+    for attempt in range(3):
+        got = run(base | hip.RNN_KPAIR)
+        assert torch.equal(got[0], want[0]), attempt
+        assert torch.equal(got[2], want[2])
+        assert torch.equal(got[3][0], want[3][0])
+        assert torch.equal(got[3][1], want[3][1])
+    if num_steps >= 7:
+        cuts = [num_steps, num_steps - 1, num_steps - 3, num_steps // 2, 1, 0]
+        for attempt in range(2):
+            got = run(base | hip.RNN_KPAIR, cuts)
+            assert torch.equal(got[0], want[0]), attempt
+            assert torch.equal(got[2], want[2])
+            assert torch.equal(got[3][0], want[3][0])
+            assert torch.equal(got[3][1], want[3][1])
+        # taking turns with the staggered kernel inside one pass: each reads what the other
+        # published
+        mixed = run(base | hip.RNN_KPAIR, cuts, alternate=base | hip.RNN_STAGGER)
+        assert row_err(mixed[0]) < 1.5 * e_stag + 2e-7
+        again = run(base | hip.RNN_KPAIR)
+        assert torch.equal(again[0], want[0])
+    # per-row lengths: the flag is ignored (one-barrier kernel)
+    sl = torch.randint(1, num_steps + 1, (batch,), device=DEV, generator=g).int()
+    y_l, reserve_l, ws_l = hip.rnn_fwd('lstm', xw, w_hh, sl)
+    a = hip.rnn_bwd('lstm', dy, y_l, w_hh_t, reserve_l, sl, workspace=ws_l, flags=base)
+    b = hip.rnn_bwd('lstm', dy, y_l, w_hh_t, reserve_l, sl, workspace=ws_l,
+                    flags=base | hip.RNN_KPAIR)
+    hip.rnn_poll_error('lstm', ws_l, num_steps, batch, hidden)
+    assert torch.equal(a, b)
+
+
 def test_staggered_launch_leaves_at_once_when_the_time_out_word_is_set(hip):
     """The sticky time-out word ends a staggered-tile launch like every other persistent launch
     (nothing written, no spinning), and the pass after the poll is whole again."""

@@ -36,6 +36,8 @@ def main():
         bwd_flags |= hip.RNN_XCD_SPLIT
     if os.environ.get('CTCASR_STAGGER'):       # fp16 LSTM-1024 backward, 17..32 rows: staggered tiles
         bwd_flags |= hip.RNN_STAGGER
+    if os.environ.get('CTCASR_KPAIR'):         # ... with the K axis split over pairs of workgroups
+        bwd_flags |= hip.RNN_KPAIR
     g = torch.Generator(device='cuda').manual_seed(0)
     xw = torch.randn(T, B, 2, G * H, device='cuda', generator=g) * 0.5
     w = torch.randn(2, G * H, H, device='cuda', generator=g) / np.sqrt(H)
@@ -67,7 +69,13 @@ def main():
                 words = ws[base: base + 40].cpu().numpy().view(np.uint64)
                 labels = ['wait', 'partial loads+sum', 'gates+A operand', 'mfma+publish',
                           'drain+arrive+dxw']
-            if name == 'bwd' and os.environ.get('CTCASR_STAGGER'):
+            if name == 'bwd' and os.environ.get('CTCASR_KPAIR'):
+                words = ws[base: base + 72].cpu().numpy().view(np.uint64)
+                labels = ['marker wait', 'poll wait', 'main loops (rest)',
+                          'reduce+hand-off+gates+publish', 'spins x 100', 'of which hand-off wait',
+                          'wait for the first granules', 'request -> first granules',
+                          'request -> arrival point (all landed)']
+            elif name == 'bwd' and os.environ.get('CTCASR_STAGGER'):
                 words = ws[base: base + 40].cpu().numpy().view(np.uint64)
                 labels = ['marker wait', 'poll wait', 'main loops (rest)', 'reduce+gates+publish',
                           'spins x 100']

@@ -530,10 +530,12 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                 # GEMMs of the steps it has finished fill the other 128 CUs
                 cus = 128 if (dom == 'rnn_bwd' and hidden == 1024 and
                               not args.rnn_bwd_whole_chip) else 256
+                # (achieved against the peak of the kernel's OWN pipe on the CUs it holds - the
+                # fp16 pipe's fp32-equivalent peak for the fp16x3 kernels)
                 roofline.update({
                     'cus_occupied': cus,
-                    'frac_of_occupied_cus': round(
-                        achieved / (FP32_MFMA_PEAK_TFLOPS * cus / 256.0), 4)})
+                    'frac_of_pipe_peak_of_occupied_cus': round(
+                        achieved / (peak * cus / 256.0), 4)})
                 roofline.update({
                     'avg_launch_us': round(avg_s * 1e6, 1), 'launches': calls,
                     'algorithmic_flops_per_launch': flops_per_step * launch_steps,
@@ -741,6 +743,9 @@ def measure_c5(args, rank, local_rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     trainer.drain_checks()
+    # (the arithmetic of the TRAINING passes: `arithmetic()` reports the last forward pass, and the
+    # decode passes below run in eval mode - no backward recurrence in theirs)
+    train_arith = model.arithmetic()
 
     # evaluation-style decode: forward in eval mode, logits kept, grouped beam-search launches
     def decode_pass():
@@ -778,7 +783,7 @@ def measure_c5(args, rank, local_rank, world):
         rnn_flops = sum(2.0 * 2 * batch * hidden * gates * hidden * item['t_out'] * layers
                         for item in batches)
         t_outs = [item['t_out'] for item in batches]
-        arith = model.arithmetic()
+        arith = train_arith
         bwd_f16 = arith.get('rnn0/recurrence_bwd') == 'fp16x3'
         bwd_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if bwd_f16 else FP32_MFMA_PEAK_TFLOPS
         result = {

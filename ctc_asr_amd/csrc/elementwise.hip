@@ -160,11 +160,12 @@ adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restric
 }
 
 // skip[0] = any CTC status word != 0 | any per-utterance loss not finite | any time-out word set;
-// skip[1] = the time-out words or-ed together (what the host polls, see engine.Trainer)
+// skip[1] = the time-out words or-ed together, bit 30 = the weight-gradient kernel's give-up word
+// (what the host polls, see engine.Trainer)
 __global__ void step_guard_kernel(const int32_t *__restrict__ status,
                                   const float *__restrict__ loss, int batch,
                                   const unsigned *err0, const unsigned *err1,
-                                  int32_t *__restrict__ skip) {
+                                  const int32_t *wgrad, int32_t *__restrict__ skip) {
     int bad = 0;
     for (int b = threadIdx.x; b < batch; b += blockDim.x) {
         if (status && status[b] != 0) bad = 1;
@@ -175,7 +176,8 @@ __global__ void step_guard_kernel(const int32_t *__restrict__ status,
     if ((threadIdx.x & 63) == 0) any_bad[threadIdx.x >> 6] = bad;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned err = (err0 ? *err0 : 0u) | (err1 ? *err1 : 0u);
+        const unsigned err = (err0 ? *err0 : 0u) | (err1 ? *err1 : 0u) |
+                             (wgrad && *wgrad != 0 ? 1u << 30 : 0u);
         skip[0] = (any_bad[0] | any_bad[1] | any_bad[2] | any_bad[3] | (err != 0u)) ? 1 : 0;
         skip[1] = (int32_t)err;
     }
@@ -340,11 +342,12 @@ extern "C" int ctcasr_adam_step(float *param, const float *grad, float *m, float
 
 extern "C" int ctcasr_step_guard(const int32_t *ctc_status, const float *per_utterance_loss,
                                  int batch, const uint32_t *timeout_word0,
-                                 const uint32_t *timeout_word1, int32_t *skip,
-                                 ctcasr_stream_t stream) {
+                                 const uint32_t *timeout_word1, const int32_t *wgrad_word,
+                                 int32_t *skip, ctcasr_stream_t stream) {
     if (!skip || batch < 0) return CTCASR_ERR_BAD_ARGUMENT;
     step_guard_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ctc_status, per_utterance_loss, batch,
-                                                          timeout_word0, timeout_word1, skip);
+                                                          timeout_word0, timeout_word1, wgrad_word,
+                                                          skip);
     return ctcasr_launch_status();
 }
 

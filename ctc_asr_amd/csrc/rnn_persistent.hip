@@ -3973,11 +3973,15 @@ extern "C" int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H) {
 
 size_t prnn_sync_bytes() { return sizeof(SyncWords); }
 
-// Process-wide profiling switch (the only option): "rnn_kernel_events".  Which variant of a
-// persistent kernel runs is a per-call argument (`flags` of ctcasr_rnn_fwd_steps / _bwd_steps).
+// Process-wide switches that change no result: "rnn_kernel_events" (profiling) and
+// "wgrad16_spin_limit" (polls before a part of ctcasr_wgrad16_gemm gives up waiting for its turn;
+// 0 = the default - for the test of that path).  Which variant of a persistent kernel runs is a
+// per-call argument (`flags` of ctcasr_rnn_fwd_steps / _bwd_steps).
+void wgrad16_set_spin_limit(long polls);      // (wgrad16.hip)
 extern "C" int ctcasr_set_option(const char *name, int value) {
     if (!name) return CTCASR_ERR_BAD_ARGUMENT;
     if (strcmp(name, "rnn_kernel_events") == 0) { g_kernel_events = value ? 1 : 0; return CTCASR_OK; }
+    if (strcmp(name, "wgrad16_spin_limit") == 0) { wgrad16_set_spin_limit(value); return CTCASR_OK; }
     return CTCASR_ERR_BAD_ARGUMENT;
 }
 

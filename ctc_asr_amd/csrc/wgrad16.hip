@@ -46,7 +46,12 @@ struct WgArgs {
     int stages, m_tiles, n_tiles[2], tiles_n[2], tiles_m;
     int parts;              // row ranges one tile's sum is cut into (one workgroup each)
     int *sync;              // [1 + tiles]: time-out word, then the part whose turn it is to add
+    long spin_limit;        // polls of a turn word before a part gives up
 };
+
+// polls before a part gives up waiting for its turn (~5 s); "wgrad16_spin_limit" of
+// ctcasr_set_option shortens it for the test of the give-up path
+long g_wgrad_spin_limit = 1L << 24;
 
 __device__ __forceinline__ void wg_dma16(const char *base, unsigned lane_off, unsigned lds_base) {
     unsigned keep;
@@ -59,9 +64,17 @@ __device__ __forceinline__ void wg_dma16(const char *base, unsigned lane_off, un
 
 __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int gave_up;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    // A time-out word that is already set (sticky until the host has looked: hip.wgrad16_check):
+    // nothing of this launch is added - the step's update is dropped by the guard word anyway, and
+    // turn words a part abandoned would make every later part spin to its limit
+    if (p.parts > 1 &&
+        __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        return;
+    if (tid == 0) gave_up = 0;
     // tile list: operand 0's tiles_m x tiles_n[0], then operand 1's; within an operand the tiles
     // of one row of tiles are neighbours (they share the A panel in L2)
     const int tiles_all = p.tiles_m * (p.tiles_n[0] + p.tiles_n[1]);
@@ -181,23 +194,32 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad16_kernel(WgArgs p) {
         return;
     }
     // The parts of a tile add in order (the same sums on every run): part q waits for the tile's
-    // word to read q.  Part q - 1 has a lower workgroup id, was dispatched before and waits only
-    // on lower ids itself.  dW and the word are read and written at agent scope access by access
-    // (sc1 loads / write-through stores): another XCD's L2 never holds a stale or a dirty line of
-    // them, and no workgroup has to write back or invalidate a whole L2 - which would cost every
-    // other workgroup of its XCD the operand panels they share there.
+    // word to read q - part 0 too: the word is 0 exactly when no launch is adding to this tile, so
+    // launches of two streams that share the words take turns instead of releasing each other's
+    // parts.  Part q - 1 has a lower workgroup id, was dispatched before and waits only on lower ids
+    // itself.  dW and the word are read and written at agent scope access by access (sc1 loads /
+    // write-through stores): another XCD's L2 never holds a stale or a dirty line of them, and no
+    // workgroup has to write back or invalidate a whole L2 - which would cost every other
+    // workgroup of its XCD the operand panels they share there.
+    // A part that gives up (spin limit, or another part's time-out word) raises the sticky word
+    // and leaves WITHOUT adding and without passing the turn on: dW stays a sum of whole parts in
+    // order, CTCModel.step_guard drops the step's update, the host raises and zeroes the words.
     int *turn = p.sync + 1 + tile_id;
-    if (tid == 0 && part > 0) {
+    if (tid == 0) {
         long spins = 0;
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != part) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1L << 24)) {
+            if (++spins > p.spin_limit ||
+                ((spins & 255) == 0 &&
+                 __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 __hip_atomic_store(p.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = 1;
                 break;
             }
         }
     }
     __syncthreads();
+    if (gave_up) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float have[4][4];
@@ -269,6 +291,8 @@ __global__ void __launch_bounds__(256) wgrad16_pack_kernel(const float *x, int64
 
 }  // namespace
 
+void wgrad16_set_spin_limit(long polls) { g_wgrad_spin_limit = polls > 0 ? polls : 1L << 24; }
+
 extern "C" size_t ctcasr_wgrad16_packed_bytes(int stages, int cols) {
     return stages > 0 && cols > 0 ? (size_t)stages * ((cols + 15) / 16) * 2048 : 0;
 }
@@ -322,7 +346,7 @@ extern "C" int ctcasr_wgrad16_gemm(const void *d_packed, int m, int stages, cons
         a.alpha[1] = 1.0f / y_scale; a.out[1] = dw_y; a.ld[1] = ld_y;
         a.n_tiles[1] = (ny + 15) / 16; a.tiles_n[1] = (ny + WG_TILE - 1) / WG_TILE;
     }
-    a.parts = parts; a.sync = sync;
+    a.parts = parts; a.sync = sync; a.spin_limit = g_wgrad_spin_limit;
     const int tiles = a.tiles_m * (a.tiles_n[0] + a.tiles_n[1]) * parts;
     wgrad16_kernel<<<tiles, WG_THREADS, WG_LDS_BYTES, (hipStream_t)stream>>>(a);
     return ctcasr_launch_status();

@@ -126,7 +126,7 @@ SIGNATURES = {
     'ctcasr_features': (_c_int, [_c_p, _c_p] + [_c_int] * 5 + [_c_p, _c_p, _c_int, _c_p, _c_p,
                                  _c_sz, _c_p]),
     'ctcasr_adam_step': (_c_int, [_c_p] * 4 + [_c_i64] + [_c_f] * 4 + [_c_i64, _c_f, _c_p, _c_p]),
-    'ctcasr_step_guard': (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p]),
+    'ctcasr_step_guard': (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p]),
     'ctcasr_rnn_timeout_word_offset': (_c_sz, [_c_int] * 5),
     'ctcasr_absmax': (_c_int, [_c_p, _c_i64, _c_p, _c_p]),
     'ctcasr_occupy_cus': (_c_int, [_c_int, _c_int, _c_p]),
@@ -732,7 +732,9 @@ def wgrad16_gemm(d_packed, m, stages, inv_scale, x_packed, x_stage0, x_scale, dw
                  y_packed=None, y_stage0=0, y_scale=1.0, dw_y=None, parts=1):
     """dw_x [m, nx] += D^T X and (optional) dw_y [m, ny] += D^T Y over `stages` stages of 32 rows,
     from operands packed by `wgrad16_pack` (include/ctcasr.h: ctcasr_wgrad16_gemm).  `parts`
-    workgroups per tile add in order through the device's zeroed sync words."""
+    workgroups per tile add in order through the device's zeroed sync words (one buffer per device:
+    launches of different streams / models that meet at a tile's word take turns - part 0 waits
+    for the word to read 0)."""
     parts = max(1, min(int(parts), int(stages)))
     sync = None
     if parts > 1:
@@ -758,12 +760,32 @@ def wgrad16_gemm(d_packed, m, stages, inv_scale, x_packed, x_stage0, x_scale, dw
 _WGRAD16_SYNC = {}
 
 
+def _wgrad16_sync_of(device):
+    device = torch.device(device)
+    return _WGRAD16_SYNC.get(torch.cuda.current_device() if device.index is None else device.index)
+
+
 def wgrad16_gave_up_waiting(device):
     """True if a part of a `wgrad16_gemm` launch on `device` ever stopped waiting for its turn
     (the sticky word 0 of the sync words; synchronises)."""
-    device = torch.device(device)
-    sync = _WGRAD16_SYNC.get(torch.cuda.current_device() if device.index is None else device.index)
+    sync = _wgrad16_sync_of(device)
     return bool(sync is not None and int(sync[0].item()) != 0)
+
+
+def wgrad16_check(device):
+    """Raise `CtcAsrError` if a part of a `wgrad16_gemm` launch on `device` gave up waiting for
+    its turn since the last check (it, and every part after it, left without adding: the weight
+    gradients of that step are incomplete - `step_guard` has dropped its update), and hand the
+    words back zeroed.  Synchronises; `CTCModel.check_rnn_error` calls it with the recurrence
+    kernels' time-out poll."""
+    sync = _wgrad16_sync_of(device)
+    if sync is not None and int(sync[0].item()) != 0:
+        sync.zero_()
+        torch.cuda.synchronize(sync.device)
+        raise CtcAsrError('wgrad16_gemm: a part of a weight-gradient tile timed out waiting for '
+                          'its turn to add; the step\'s update was not applied ({}).'.format(
+                              load().ctcasr_error_string(-5).decode()))
+
 
 
 def dgrad16_packed_bytes(n):
@@ -1153,17 +1175,21 @@ def rnn_timeout_words(cell, workspace, num_steps, batch, hidden):
 
 
 @_on_tensor_device
-def step_guard(status, per_utterance_loss, timeout_words=(0, 0), out=None):
+def step_guard(status, per_utterance_loss, timeout_words=(0, 0), out=None, wgrad_word=True):
     """out int32[2]: [0] = 1 when this step's gradients must not be applied (a CTC status word
-    != 0, a non-finite per-utterance loss, a persistent recurrence that timed out), [1] = the
-    time-out words or-ed.  Everything stays on the device (`adam_step(skip=out)`)."""
+    != 0, a non-finite per-utterance loss, a persistent recurrence that timed out, a part of a
+    `wgrad16_gemm` tile on this device that gave up waiting for its turn), [1] = the time-out words
+    or-ed (bit 30: the weight-gradient word).  Everything stays on the device
+    (`adam_step(skip=out)`)."""
     if out is None:
         out = torch.empty(2, dtype=torch.int32, device=status.device)
+    sync = _WGRAD16_SYNC.get(status.device.index) if wgrad_word else None
     _check(load().ctcasr_step_guard(_dev(status, torch.int32, 'status'),
                                     _dev(per_utterance_loss, name='per_utterance_loss'),
                                     status.numel(), timeout_words[0] or None,
-                                    timeout_words[1] or None, _dev(out, torch.int32, 'out'),
-                                    _stream()), 'step_guard')
+                                    timeout_words[1] or None,
+                                    None if sync is None else sync.data_ptr(),
+                                    _dev(out, torch.int32, 'out'), _stream()), 'step_guard')
     return out
 
 

@@ -484,6 +484,10 @@ class CTCModel:
         # (prnn_bwd16s_kernel; bit-identical results) instead of both behind one barrier
         self.rnn_stagger_flag = hip.RNN_STAGGER \
             if os.environ.get('CTCASR_RNN_STAGGER', '1') == '1' else 0
+        # ... with the K axis split over pairs of workgroups (prnn_bwd16k_kernel, round 6: built,
+        # parity-green and 3.4 us per time step slower - profiles/r06_rnn_bwd_k_pair.md; off)
+        if os.environ.get('CTCASR_RNN_KPAIR', '0') == '1':
+            self.rnn_stagger_flag |= hip.RNN_KPAIR
         # the fp16-pipe forward kernel writes the fp16 pieces of its output itself (no split pass)
         self.rnn_fwd_pieces = os.environ.get('CTCASR_RNN_FWD_PIECES', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
@@ -1016,6 +1020,9 @@ class CTCModel:
         and every gradient computed from it - is invalid.  Synchronises the stream."""
         for (cell, batch, hidden), (workspace, t_out) in self._rnn_ws.items():
             hip.rnn_poll_error(cell, workspace, t_out, batch, hidden)
+        # ... or a part of a weight-gradient tile stopped waiting for its turn (its sum was not
+        # added; the guard word has dropped the update)
+        hip.wgrad16_check(self.device)
 
     def _pipeline_forward(self, layer, cell, t_out, batch, hidden, rnn_len, rnn_rate):
         """Whether layer ``layer``'s forward recurrence runs on half of the chip in step ranges

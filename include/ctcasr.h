@@ -542,12 +542,15 @@ int ctcasr_adam_step(float *param, const float *grad, float *m, float *v, int64_
  *   skip[0] = any ctc_status[b] != 0 (tf.nn.ctc_loss would have raised, asr/model.py:259)
  *             | any per_utterance_loss[b] not finite | any persistent-recurrence time-out word
  *             (device pointers to the sticky words of up to two row blocks of the workspace,
- *             ctcasr_rnn_timeout_word_offset; either may be NULL);
- *   skip[1] = the time-out words or-ed together (the host can poll this copy asynchronously -
- *             ctcasr_rnn_poll_error synchronises). */
+ *             ctcasr_rnn_timeout_word_offset; either may be NULL)
+ *             | *wgrad_word (ABI v7; may be NULL: word 0 of ctcasr_wgrad16_gemm's `sync`, raised
+ *             by a part of a weight-gradient tile that gave up waiting for its turn - it and
+ *             every later part then leave without adding);
+ *   skip[1] = the time-out words or-ed together, bit 30 for the weight-gradient word (the host
+ *             can poll this copy asynchronously - ctcasr_rnn_poll_error synchronises). */
 int ctcasr_step_guard(const int32_t *ctc_status, const float *per_utterance_loss, int batch,
-                      const uint32_t *timeout_word0, const uint32_t *timeout_word1, int32_t *skip,
-                      ctcasr_stream_t stream);
+                      const uint32_t *timeout_word0, const uint32_t *timeout_word1,
+                      const int32_t *wgrad_word, int32_t *skip, ctcasr_stream_t stream);
 /* byte offset inside the recurrence workspace of the sticky time-out word of row block `block`
  * (0 .. (B - 1) / 32), or (size_t)-1 when (cell, T, B, H) runs the streaming kernels / there is
  * no such block */

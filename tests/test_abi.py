@@ -74,7 +74,7 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.ctcasr_rnn_fwd_steps(2, None, None, None, None, None, 8, 2, 64, None, None, None,
                                     None, 0, 0, 8, 16, None) == -1       # (null pointers)
     assert lib.ctcasr_rnn_fwd_f16_supported(2, 8, 2, 64, 16) == 0
-    assert lib.ctcasr_step_guard(None, None, 4, None, None, None, None) == -1
+    assert lib.ctcasr_step_guard(None, None, 4, None, None, None, None, None) == -1
     assert lib.ctcasr_absmax(None, 4, None, None) == -1
     assert lib.ctcasr_colscale_from_max(None, 4, None, None, None) == -1
     assert lib.ctcasr_rnn_bwd_f16_supported(2, 8, 2, 64, 16) == 0

@@ -145,3 +145,68 @@ def test_the_model_with_the_own_kernel_agrees_with_the_library_form(hip, batch, 
         ref = grad_lib[a:b].double()
         rel = float((ref - grad_own[a:b].double()).norm() / ref.norm().clamp_min(1e-30))
         assert rel < 2e-5, (name, rel)
+
+
+def test_a_part_that_gives_up_adds_nothing_and_the_step_is_dropped(hip):
+    """VERDICT r05 item 4 / ADVICE r05: a part of a tile that stops waiting for its turn raises the
+    sticky word and leaves WITHOUT adding (dW stays a sum of whole parts, in order); every later
+    launch leaves at once while the word is set; `step_guard` folds the word into the Adam skip
+    flag; `hip.wgrad16_check` (from `CTCModel.check_rnn_error`) raises and hands the words back
+    zeroed - through the Trainer: the update is not applied, the deferred check raises, the next
+    step trains again."""
+    from ctc_asr_amd.hip import _WGRAD16_SYNC
+    g = torch.Generator(device=DEV).manual_seed(11)
+    rows, m, nx = 1024, 512, 512
+    d = torch.randn(rows, m, device=DEV, generator=g) * 1e-3
+    x = torch.rand(rows, nx, device=DEV, generator=g) * 2 - 1
+    good = own_wgrad(hip, d, x, 32768.0, parts=2)[0]
+    sync = _WGRAD16_SYNC[torch.cuda.current_device()]
+    hip.set_option('wgrad16_spin_limit', 1 << 16)     # (~20 ms instead of ~5 s)
+    try:
+        sync[1] = 99                    # tile 0's word: nobody's turn
+        torch.cuda.synchronize()
+        bad = own_wgrad(hip, d, x, 32768.0, parts=2)[0]
+        torch.cuda.synchronize()
+        assert hip.wgrad16_gave_up_waiting(DEV)
+        assert float(bad[:256, :256].abs().max()) == 0.0        # tile 0: no part added
+        status = torch.zeros(3, dtype=torch.int32, device=DEV)
+        assert hip.step_guard(status, torch.ones(3, device=DEV)).tolist() == [1, 1 << 30]
+        assert hip.step_guard(status, torch.ones(3, device=DEV), wgrad_word=False).tolist() == [0, 0]
+        # the word is sticky: a later launch adds nothing at all
+        later = own_wgrad(hip, d, x, 32768.0, parts=2)[0]
+        assert float(later.abs().max()) == 0.0
+        with pytest.raises(hip.CtcAsrError, match='turn'):
+            hip.wgrad16_check(DEV)
+        hip.wgrad16_check(DEV)
+        assert int(sync.abs().sum()) == 0
+        assert torch.equal(own_wgrad(hip, d, x, 32768.0, parts=2)[0], good)
+
+        # through the Trainer (a model whose weight gradients take the own kernel in 2 parts)
+        from ctc_asr_amd.engine import Trainer
+        from ctc_asr_amd.model import ModelConfig
+        cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32), num_units_dense=2048,
+                          num_layers_rnn=1, num_units_rnn=1024, rnn_cell='lstm', cudnn=True,
+                          dense_dropout_rate=0.0, conv_dropout_rate=0.0)
+        trainer = Trainer(cfg, device=DEV, seed=3)
+        rng = np.random.default_rng(5)
+        feats = torch.tensor(rng.normal(size=(20, 261, 80)).astype(np.float32))
+        flen = torch.full((20,), 261, dtype=torch.int32)
+        labels = [list(rng.integers(1, 28, size=12)) for _ in range(20)]
+        trainer.train_step(feats, flen, labels)
+        trainer.drain_checks()
+        sync = _WGRAD16_SYNC[torch.cuda.current_device()]
+        before = trainer.model.arena.param.clone()
+        sync[1] = 99
+        trainer.train_step(feats, flen, labels)
+        torch.cuda.synchronize()
+        assert torch.equal(trainer.model.arena.param, before)
+        with pytest.raises(hip.CtcAsrError, match='turn'):
+            trainer.drain_checks()
+        trainer.drain_checks()
+        trainer.train_step(feats, flen, labels)
+        trainer.drain_checks()
+        assert not torch.equal(trainer.model.arena.param, before)
+        assert torch.isfinite(trainer.model.arena.param).all()
+    finally:
+        hip.set_option('wgrad16_spin_limit', 0)
+        _WGRAD16_SYNC[torch.cuda.current_device()].zero_()

@@ -68,7 +68,7 @@ RELEASE_TEXT = {
     'held': 'after the last persistent recurrence launch of the step (hold_until=rnn0), in '
             'buckets of at most max_bucket_bytes',
     'early': 'per layer, behind its weight-gradient GEMMs on the side stream, beside the '
-             'recurrences of the layers below (CTCASR_ALLREDUCE_EARLY=1)'}
+             'recurrences of the layers below (CTCASR_ALLREDUCE_EARLY=1, the Trainer\'s default)'}
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0

@@ -401,7 +401,10 @@ extern "C" int ctcasr_dgrad16_published_offsets(int T, int B, int hidden, size_t
 }
 
 extern "C" int ctcasr_dgrad16_supported(int cell, int T, int B, int hidden) {
-    return cell == CTCASR_CELL_LSTM && hidden == DG_H && T >= 1 && B >= 1 && B <= 32;
+    // (the per-step block offsets inside the exchange buffer are 32-bit, like the buffer descriptor
+    // of the recurrence kernel that fills it: ctcasr_rnn_persistent_supported has the same bound)
+    return cell == CTCASR_CELL_LSTM && hidden == DG_H && T >= 1 && B >= 1 && B <= 32 &&
+           (size_t)(T + 1) * 2 * B * 4 * DG_H * sizeof(float) < (1ull << 31);
 }
 
 extern "C" int ctcasr_dgrad16_blockscaled(void *workspace, int T, int B, int hidden,

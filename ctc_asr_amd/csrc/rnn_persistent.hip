@@ -3307,23 +3307,42 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16k_kernel(PArgs p) {
 #ifndef PRNN_W16_D
 #define PRNN_W16_D 12                  // ring depth: producers whose A granules are in flight
 #endif
+#ifndef PRNN_W16_KD
+#define PRNN_W16_KD 16                 // ... of the K-pair form (32 producers per wave)
+#endif
 __host__ __device__ inline size_t prnn_w16_scale_bytes(int T) {
     return (size_t)(T + 1) * 2 * (PRNN_W16_H / 8) * PRNN_B16_SCALE_ROWS * sizeof(float);
 }
-template <int D>
+// K pairs: one KPairWords per direction, then [dir][workgroup][128 words]
+__host__ __device__ inline size_t prnn_w16_kp_bytes() {
+    return 2 * sizeof(KPairWords) + (size_t)2 * (PRNN_W16_H / 8) * 128 * sizeof(unsigned);
+}
+// KP (round 6, CTCASR_RNN_KPAIR): the K-pair form.  The workgroups {slice, slice ^ 8} - one XCD -
+// share 16 hidden units = ONE FULL N tile (the plain form multiplies half-empty tiles): each holds
+// one K half (128 producers) of the weights of all 16 units (the same 256 KB: 64 KB per wave,
+// half in LDS, half in 128 registers), reads only that half's blocks - 256 KB instead of 512 KB per
+// direction-step, through L2s that were at half of their aggregate peak - issues half of the
+// MFMAs, and hands its partner the partial sums of the partner's 8 units: 16 x 8 fp32 words, each
+// tagged in its lowest significand bit with the parity of the slot's write count (KPairWords of
+// the direction; the receiver clears the bit again).  This kernel has ONE barrier per step and
+// nothing in flight at the hand-off, so the receiver polls with L2-bypassing vector loads.
+// Publishes what the plain form publishes; the K sums differ in their order (to rounding).
+template <int D, bool KP = false>
 __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     constexpr int H = PRNN_W16_H, GH = 4 * H, NW = 4, NTH = PRNN_THREADS;
     constexpr int NP = H / 8;               // producers per direction = workgroups
-    constexpr int NPW = NP / NW;            // producers per wave: 64
+    constexpr int NPW = NP / NW / (KP ? 2 : 1);     // producers per wave: 64 (K pairs: 32)
     constexpr int QS = NPW * 2;             // B-fragment slots per wave: (producer, piece)
-    constexpr int QL = QS / 2, REGW = QS - QL;      // 64 slots in LDS (512 B each), 64 in registers
+    // 64 slots in LDS (512 B each: 8 real columns), 64 in registers; K pairs: 32 full slots of
+    // 1 KB in LDS, 32 in registers
+    constexpr int QL = QS / 2, REGW = QS - QL, SLOT = KP ? 64 : 32;
     constexpr int RED_FLOATS = NW * 16 * 17;
     constexpr int IVL = NPW * 4;            // float4 slots of a wave's inverse scales
     extern __shared__ __attribute__((aligned(16))) char smem[];
     resident_signal(p.sync, p.ticket);
     if (launch_poisoned(p.sync)) return;
     u32x4 *frag = reinterpret_cast<u32x4 *>(smem);          // [wave][QL][32 granules]
-    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * 32 * sizeof(u32x4));
+    float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * SLOT * sizeof(u32x4));
     float4 *invs = reinterpret_cast<float4 *>(red + RED_FLOATS);        // [wave][IVL]
     float *wave_top = reinterpret_cast<float *>(invs + NW * IVL);
 
@@ -3336,15 +3355,37 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * 8;
+    // K pairs: column c of the N tile = unit u0 + c (c < 8, ours) or the partner's unit c - 8;
+    // this workgroup's K half: producers 128 kh .. 128 kh + 127
+    const int partner = slice ^ 8, kh = KP ? (slice >> 3) & 1 : 0;
+    const int pb = (KP ? 128 * kh : 0) + wave * NPW;        // this wave's first producer
+    auto tile_unit = [&](int c) -> int { return KP && c >= 8 ? partner * 8 + c - 8 : u0 + (c & 7); };
+    KPairWords *kpw = nullptr;
+    unsigned kp_base = 0;
+    if constexpr (KP) {
+        kpw = reinterpret_cast<KPairWords *>(p.kp) + dir;
+        kp_base = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+            &kpw->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
 
     // ---- this workgroup's 8 columns of R^T as scaled fp16 pieces -------------------------------
     float w_scale;
     {
         float m = 0.f;
-        const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 7)) * GH;
-        for (int n = (tid >> 3) * 4; n < GH; n += NTH / 8 * 4) {
-            const float4 v = ldg4(wrow + n);
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if constexpr (KP) {
+            // 16 rows of R^T, the K half's 1024 columns of every gate
+            const float *wrow = p.w + ((size_t)dir * H + tile_unit(tid & 15)) * GH + 1024 * kh;
+            for (int g = 0; g < 4; ++g)
+                for (int x = (tid >> 4) * 4; x < 1024; x += NTH / 16 * 4) {
+                    const float4 v = ldg4(wrow + (size_t)g * H + x);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+        } else {
+            const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 7)) * GH;
+            for (int n = (tid >> 3) * 4; n < GH; n += NTH / 8 * 4) {
+                const float4 v = ldg4(wrow + n);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
         }
         m = wave_max(m);
         if (lane == 0) wave_top[wave] = m;
@@ -3360,8 +3401,8 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     {
         // fragment of producer P (of this wave): lane (k group q = lane >> 4, column lane & 7)
         auto pieces = [&](int pw, u32x4 &first, u32x4 &second) {
-            const float *wcol = p.w + ((size_t)dir * H + u0 + (lane & 7)) * GH +
-                                8 * (wave * NPW + pw) + 2 * (lane >> 4);
+            const float *wcol = p.w + ((size_t)dir * H + tile_unit(lane & 15)) * GH +
+                                8 * (pb + pw) + 2 * (lane >> 4);
             unsigned q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -3374,7 +3415,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
         for (int pw = 0; pw < QL / 2; ++pw) {
             u32x4 first, second;
             pieces(pw, first, second);
-            if ((lane & 15) < 8) {
+            if constexpr (KP) {
+                frag[(wave * QL + 2 * pw) * 64 + lane] = first;
+                frag[(wave * QL + 2 * pw + 1) * 64 + lane] = second;
+            } else if ((lane & 15) < 8) {
                 const int cell16 = (lane >> 4) * 8 + (lane & 7);
                 frag[(wave * QL + 2 * pw) * 32 + cell16] = first;
                 frag[(wave * QL + 2 * pw + 1) * 32 + cell16] = second;
@@ -3398,6 +3442,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, rnum, 0x00020000);
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cells, 0, rnum, 0x00020000);
     const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dxw, 0, rnum, 0x00020000);
+    // K pairs: the hand-off slots behind the two directions' KPairWords: [dir][slice][128 words]
+    const __amdgpu_buffer_rsrc_t kp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        KP ? p.kp + 2 * sizeof(KPairWords) / sizeof(unsigned) : nullptr, 0,
+        KP ? (int)(2 * NP * 128 * sizeof(unsigned)) : 0, 0x00020000);
     auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
     };
@@ -3440,12 +3488,12 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
                 if (s == p.s_lo && tid == 0) counters_done(p.sync, dir, chain, p.nwg);
             }
             if (prof) { unsigned long long c = wall_clock64(); pt[0] += c - c0; c0 = c; }
-            // inverse scales of the wave's 64 producers x 16 rows: four 1 KB loads
-            float4 iv[4];
+            // inverse scales of the wave's 64 (32) producers x 16 rows: four (two) 1 KB loads
+            float4 iv[NPW / 16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NPW / 16; ++j)
                 iv[j] = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
-                                               (unsigned)(((dir * NP + wave * NPW + 16 * j + (lane >> 2)) *
+                                               (unsigned)(((dir * NP + pb + 16 * j + (lane >> 2)) *
                                                            PRNN_B16_SCALE_ROWS + row0 + 4 * (lane & 3)) *
                                                           sizeof(float)));
             const bool ok = s + 1 < a_steps;        // otherwise: the all-zero block
@@ -3458,7 +3506,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
             // a hundred scalar registers)
             unsigned gstride = (unsigned)(B * 16 * sizeof(float));
             asm volatile("" : "+s"(gstride));
-            const unsigned wbase = (unsigned)(wave * NPW * 2) * gstride;
+            const unsigned wbase = (unsigned)(pb * 2) * gstride;
             auto issue = [&](int P, u32x4 (&dst)[2]) {
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc)
@@ -3468,8 +3516,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
             for (int P = 0; P < D; ++P) issue(P, a[P]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) invs[wave * IVL + 64 * j + lane] = iv[j];
+            for (int j = 0; j < NPW / 16; ++j) invs[wave * IVL + 64 * j + lane] = iv[j];
             auto bfrag = [&](int sl) -> u32x4 {      // compile-time slot after unrolling
+                if constexpr (KP)
+                    return sl < QL ? frag[(wave * QL + sl) * 64 + lane] : wreg[sl - QL];
                 return sl < QL ? frag[(wave * QL + sl) * 32 + (lane >> 4) * 8 + (lane & 7)]
                                : wreg[sl - QL];
             };
@@ -3503,12 +3553,51 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
             red[(wave * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = total[r] * out_scale;
         __syncthreads();
 
+        float theirs_half = 0.f;            // K pairs: the partner's K half of this item's sum
+        if constexpr (KP) {
+            const unsigned tag = (kp_base + (unsigned)(p.s_hi - s)) & 1u;
+            if (!has_item) {
+                // threads 128 .. 255: row (tid >> 3) & 15, the partner's unit tid & 7 -> word
+                // tid - 128 of the partner's slot
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += red[(w * 16 + ib) * 17 + 8 + iu];
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    (__float_as_uint(v) & ~1u) | tag, kp_rsrc, (int)((tid - 128) * 4),
+                    (int)(((dir * NP + partner) * 128) * 4), 16);
+            } else {
+                unsigned rv = 0u, spins = 0;
+                for (;;) {
+                    rv = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
+                        kp_rsrc, (int)(tid * 4), (int)(((dir * NP + slice) * 128) * 4), 16);
+                    if (__all((rv & 1u) == tag)) break;
+                    if (++spins > PRNN_SPIN_LIMIT ||
+                        ((spins & 1023u) == 0 &&
+                         __hip_atomic_load(&p.sync->error, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT))) {
+                        if (lane == 0)
+                            __hip_atomic_store(&p.sync->error, 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                theirs_half = __uint_as_float(rv & ~1u);
+            }
+        }
         if (has_item) {
             float dg[4] = {0.f, 0.f, 0.f, 0.f};
             if (it_t >= 0) {
                 float dh = dyv;
+                if constexpr (KP) {
+                    float rec = red[ib * 17 + iu];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) dh += red[(w * 16 + ib) * 17 + iu];
+                    for (int w = 1; w < NW; ++w) rec += red[(w * 16 + ib) * 17 + iu];
+                    dh += rec + theirs_half;
+                } else {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) dh += red[(w * 16 + ib) * 17 + iu];
+                }
                 const float tc = tanhf_(cv);
                 const float dc = dc_state + dh * go * (1.f - tc * tc);
                 dg[0] = dc * gg * gi * (1.f - gi);
@@ -3576,6 +3665,19 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     }
     if (prof)
         for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+    if constexpr (KP) {
+        // the last workgroup to leave advances the direction's write count (prnn_bwd16k_kernel)
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned before = __hip_atomic_fetch_add(&kpw->done, 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1 == (unsigned)p.nwg) {
+                __hip_atomic_store(&kpw->total, kp_base + (unsigned)(p.s_hi - p.s_lo),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&kpw->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (p.s_lo > 0 && steps > 0) p.carry[((size_t)dir * B + brow) * H + unit] = dc_state;
     if (p.dbias || p.colmax) {
         float *sums = red, *tops = reinterpret_cast<float *>(frag);
@@ -3995,7 +4097,8 @@ size_t prnn_exchange_bytes(int T, int B, int H, int G) {
            (G == 4 && H == PRNN_RS_H
                 ? prnn_rs_ring_bytes() + ctcasr_align_up(prnn_b16_scale_bytes(T), 256) + prnn_kp_bytes()
                 : 0) +
-           (G == 4 && H == PRNN_W16_H ? prnn_w16_scale_bytes(T) : 0) +
+           (G == 4 && H == PRNN_W16_H
+                ? ctcasr_align_up(prnn_w16_scale_bytes(T), 256) + prnn_w16_kp_bytes() : 0) +
            (G == 1 && H == PRNN_R16_H ? prnn_r16_scale_bytes(T) : 0);
 }
 
@@ -4205,10 +4308,15 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
                                          prnn_step_exchange_bytes(T, B, H, 4));
         const size_t lds = (size_t)4 * 64 * 32 * 16 + (size_t)4 * 16 * 17 * 4 +
                            (size_t)4 * 256 * 16 + 64;
+        const bool pairs = (flags & CTCASR_RNN_KPAIR) != 0;
+        p.kp = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(p.rs) +
+                                            ctcasr_align_up(prnn_w16_scale_bytes(T), 256));
         for (int tile = 0; tile < mt; ++tile)
             for (int dir = 0; dir < 2; ++dir) {
                 p.chain0 = tile; p.dir0 = dir;
-                const int rc = launch_persistent(prnn_bwd16w_kernel<PRNN_W16_D>, p, lds, s);
+                const int rc = pairs
+                    ? launch_persistent(prnn_bwd16w_kernel<PRNN_W16_KD, true>, p, lds, s)
+                    : launch_persistent(prnn_bwd16w_kernel<PRNN_W16_D>, p, lds, s);
                 if (rc != CTCASR_OK) return rc;
             }
         return CTCASR_OK;
@@ -4341,6 +4449,12 @@ size_t prnn_error_offset() { return offsetof(SyncWords, error); }
 // barrier words.  0 bytes for shapes without them.
 void prnn_kp_region(int T, int B, int H, int G, size_t *offset, size_t *bytes) {
     *offset = *bytes = 0;
+    if (G == 4 && H == PRNN_W16_H) {
+        *offset = sizeof(SyncWords) + prnn_step_exchange_bytes(T, B, H, 4) +
+                  ctcasr_align_up(prnn_w16_scale_bytes(T), 256);
+        *bytes = prnn_w16_kp_bytes();
+        return;
+    }
     if (G != 4 || H != PRNN_RS_H) return;
     *offset = sizeof(SyncWords) + prnn_step_exchange_bytes(T, B, H, 4) +
               prnn_rs_ring_bytes() + ctcasr_align_up(prnn_b16_scale_bytes(T), 256);
@@ -4362,7 +4476,8 @@ extern "C" unsigned ctcasr_build_flags(void) {
         PRNN_CHAIN0_PRIO != 1 || PRNN_POLL_SLEEP != 1 || PRNN_RS_LOCK != 1 || PRNN_TURN_PRIO != 2 ||
         PRNN_XCD_TILE_PAIRS != 1 || PRNN_B16S_D != 8 || PRNN_B16S_JW != 7 || PRNN_B16S_JP != 5 ||
         PRNN_B16S_JA != 1 || PRNN_B16S_XCD_EXCL != 0 || PRNN_B16K_JW != 3 || PRNN_B16K_JP != 2 ||
-        PRNN_B16K_JA != 1 || PRNN_B16K_SC1 != 0 || PRNN_B16K_SLEEP != 1)
+        PRNN_B16K_JA != 1 || PRNN_B16K_SC1 != 0 || PRNN_B16K_SLEEP != 1 || PRNN_W16_D != 12 ||
+        PRNN_W16_KD != 16)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

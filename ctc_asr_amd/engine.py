@@ -9,6 +9,7 @@ as the backward pass has finished that layer so the collective overlaps the rest
 """
 
 import collections
+import warnings
 import os
 import time
 
@@ -205,19 +206,26 @@ class Trainer:
         self.beta2 = getattr(flags, 'adam_beta2', 0.999) if flags is not None else 0.999
         self.eps = getattr(flags, 'adam_epsilon', 1e-8) if flags is not None else 1e-8
         # Release of the gradient buckets (``allreduce_early``; None = CTCASR_ALLREDUCE_EARLY):
-        #   held (default)  nothing is reduced before the last persistent recurrence launch of
-        #                   the backward pass has been issued (`hold_until='rnn0'`);
-        #   early           every layer's bucket is reduced as soon as its weight-gradient GEMMs
+        #   early (default since round 6)
+        #                   every layer's bucket is reduced as soon as its weight-gradient GEMMs
         #                   are done on the side stream, beside the recurrences of the layers
         #                   below.  RCCL's workgroups occupy CUs for as long as a collective runs;
         #                   the H = 1024 backward recurrence needs 128 of the 256 CUs, so both
         #                   fit - a persistent workgroup that finds its CU taken waits (spin
-        #                   limit: seconds).  bench.py measures both modes at N > 1.
+        #                   limit: seconds).
+        #   held            nothing is reduced before the last persistent recurrence launch of
+        #                   the backward pass has been issued (`hold_until='rnn0'`).
+        # Why early: with a stand-in that has a ring all-reduce's CU footprint AND its memory
+        # traffic beside the real step (one GPU) the C3 step pays +2.3 ms
+        # (4.6 %) for early against +5.3 ms (10.4 %) for held, and neither mode timed out; held
+        # leaves the whole 0.49 GB of gradients to be reduced behind the backward pass.  bench.py
+        # measures both modes at N > 1 and reports the better one, so a node on which RCCL beside
+        # the recurrences behaves worse than the stand-in still shows in the line.
         # Models whose recurrence takes ALL 256 CUs (LSTM / GRU at H = 2048) always hold: there
         # the hooks run on the main stream right in front of whole-chip persistent launches,
         # whose resident workgroups would spin until the collective has drained.
         if allreduce_early is None:
-            allreduce_early = os.environ.get('CTCASR_ALLREDUCE_EARLY', '0') == '1'
+            allreduce_early = os.environ.get('CTCASR_ALLREDUCE_EARLY', '1') == '1'
         whole_chip = cfg.cell in ('lstm', 'gru') and cfg.num_units_rnn == 2048
         early = bool(allreduce_early) and not whole_chip
         active = (world_size > 1 or force_reducer or collective_stand_in is not None) and reduce
@@ -249,6 +257,7 @@ class Trainer:
         self.rnn_poll_every = 50
         self._pending_status = collections.deque()
         self._skipped = None
+        self._skipped_reconciled = 0
         self._steps_since_poll = 0
 
     def _check_finished_steps(self, wait=False):
@@ -282,6 +291,19 @@ class Trainer:
         self._check_finished_steps(wait=True)
         self.model.check_rnn_error()
         self._steps_since_poll = 0
+        # Steps the device dropped without a check having raised for them (`train_step(check=
+        # False)`, --no-step-checks): TensorFlow's global step would not have advanced - take them
+        # back out of the step counter here, where the host is synchronised anyway, so that Adam's
+        # bias correction and the step a checkpoint is written under count applied updates only
+        # (ADVICE r05), and say so.
+        dropped = self.skipped_step_count()
+        if dropped > self._skipped_reconciled:
+            new = dropped - self._skipped_reconciled
+            self._skipped_reconciled = dropped
+            self.model.step_count -= new
+            warnings.warn('{} training step(s) were dropped on the device (CTC status, non-finite '
+                          'loss or a kernel time-out); the step counter is back at {}.'.format(
+                              new, self.model.step_count), RuntimeWarning)
 
     def train_step(self, features, feature_len, labels, check=True):
         """forward + CTC + backward (+ all-reduce) + Adam on this rank's shard of the global
@@ -339,10 +361,10 @@ class Trainer:
 
     def skipped_step_count(self):
         """Training steps whose update the device dropped (guard word set: CTC status, non-finite
-        loss, recurrence time-out) since this trainer was built; synchronises.  The step counter
-        of Adam's bias correction advances for such a step as well (TensorFlow's global step
-        would not): one extra power of beta per dropped step, and a dropped step always raises
-        at the next check of `train_step(check=True)` / `drain_checks()`."""
+        loss, recurrence / weight-gradient time-out) since this trainer was built; synchronises.
+        The step counter advances for such a step at first (TensorFlow's global step would not);
+        `drain_checks()` takes it back out.  A dropped step always raises at the next check of
+        `train_step(check=True)` / `drain_checks()`."""
         return 0 if self._skipped is None else int(self._skipped.item())
 
     def global_mean(self, value):

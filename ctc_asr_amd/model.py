@@ -488,6 +488,9 @@ class CTCModel:
         # parity-green and 3.4 us per time step slower - profiles/r06_rnn_bwd_k_pair.md; off)
         if os.environ.get('CTCASR_RNN_KPAIR', '0') == '1':
             self.rnn_stagger_flag |= hip.RNN_KPAIR
+        # LSTM-2048 backward recurrence (prnn_bwd16w_kernel): the K-pair form - there the loads are
+        # bound by L2 throughput, not by a latency chain, and a pair fills a whole MFMA tile
+        self.rnn_kpair_wide = os.environ.get('CTCASR_RNN_KPAIR_2048', '1') == '1'
         # the fp16-pipe forward kernel writes the fp16 pieces of its output itself (no split pass)
         self.rnn_fwd_pieces = os.environ.get('CTCASR_RNN_FWD_PIECES', '1') == '1'
         self._w_split, self._w_split_ready, self._w_split_bufs = {}, None, {}
@@ -1506,7 +1509,9 @@ class CTCModel:
             # dgates W_hh on the fp16 matrix pipe where the kernel exists (LSTM-1024); it then also
             # leaves the column maxima of each launch's rows of dxw for the fp16 weight gradients
             bwd_flags = self.rnn_bwd_flags | ((hip.RNN_F16 | self.rnn_xcd_flag |
-                                               self.rnn_stagger_flag)
+                                               self.rnn_stagger_flag |
+                                               (hip.RNN_KPAIR if hidden == 2048 and
+                                                self.rnn_kpair_wide else 0))
                                               if self.rnn_bwd_f16 else 0)
             f16_rec = hip.rnn_f16_recurrence(cell, t_out, batch, hidden, bwd_flags, backward=True,
                                              ragged=acts['rnn_len'] is not None)

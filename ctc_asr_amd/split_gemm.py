@@ -215,14 +215,22 @@ class ColScaled:
     `col_inv` the inverse column scales."""
 
     def __init__(self, x2d):
-        self.x2d, self._pieces, self.col_inv = x2d, None, None
+        self.x2d, self._pieces, self.col_inv, self._made_on = x2d, None, None, None
 
     def __getitem__(self, index):
         if index == 1:
             return 1.0
+        current = torch.cuda.current_stream(self.x2d.device)
         if self._pieces is None:
             scale, self.col_inv = hip.colmax_scale(self.x2d)
             self._pieces = Split(hip.split_f16_cols(self.x2d, scale, 1.0, H_A), H_A)
+            self._made_on = current
+        elif current != self._made_on:
+            # read on another stream than the one whose allocator made them (the whole-chip path
+            # runs the upper layers' weight gradients on the main stream, the bottom layer's on the
+            # side stream): the block must not be handed out again before that stream is through
+            self._pieces.buf.record_stream(current)
+            self.col_inv.record_stream(current)
         return self._pieces
 
 

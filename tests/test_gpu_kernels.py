@@ -584,6 +584,74 @@ def test_rnn_bwd_k_pairs(hip, xcd, dims):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('use_len', [False, True])
+@pytest.mark.parametrize('dims', [(12, 16), (9, 5), (7, 27), (5, 40)])
+def test_rnn_bwd_k_pairs_at_2048(hip, use_len, dims):
+    """CTCASR_RNN_KPAIR on the LSTM-2048 backward kernel (prnn_bwd16w_kernel<.., true>, round 6):
+    the workgroups {s, s ^ 8} share one FULL N tile of 16 units, each multiplies one K half and
+    hands the partner a [16 x 8] partial (tagged words through L2).  dxw against autograd through
+    the float64 recurrence within the plain fp16 kernel's error, column maxima exact, step ranges
+    (odd counts flip the tag parity) and repeated passes bit-identical, per-row lengths, batches
+    of two and three 16-row tiles (sequential launches share the slots), kernels taking turns."""
+    num_steps, batch = dims
+    hidden, gh = 2048, 8192
+    g = torch.Generator(device=DEV).manual_seed(53)
+    xw = torch.randn(num_steps, batch, 2, gh, device=DEV, generator=g) * 0.5
+    w_hh = torch.randn(2, gh, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+    dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g) * \
+        torch.logspace(-6, 0, batch, device=DEV).view(1, batch, 1)
+    sl = None
+    if use_len:
+        sl = torch.randint(1, num_steps + 1, (batch,), device=DEV, generator=g).int()
+        sl[0] = num_steps
+    xw64 = xw.double().requires_grad_(True)
+    ref_y = _recurrence_float64('lstm', xw64, w_hh, None, sl)
+    (ref_y * dy.double()).sum().backward()
+    ref = xw64.grad
+    y, reserve, ws = hip.rnn_fwd('lstm', xw, w_hh, sl)
+    w_hh_t = hip.transpose_batched(w_hh)
+
+    def run(flags, cuts=None, alternate=None):
+        db = torch.zeros(2 * gh, device=DEV)
+        colmax = torch.zeros(2 * gh, dtype=torch.int32, device=DEV)
+        dxw = torch.full((num_steps, batch, 2, gh), float('nan'), device=DEV)
+        cuts = cuts or [num_steps, 0]
+        for k, (hi, lo) in enumerate(zip(cuts[:-1], cuts[1:])):
+            hip.rnn_bwd('lstm', dy, y, w_hh_t, reserve, sl, dxw=dxw, dbias=db, workspace=ws,
+                        steps=(lo, hi), flags=(alternate if alternate and k % 2 else flags),
+                        colmax=colmax)
+        hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+        return dxw, db, colmax
+
+    def row_err(got):
+        got = torch.nan_to_num(got.double())       # (steps past a row's length: zero-filled / nan)
+        err = (got - ref).abs().amax(dim=(0, 2, 3))
+        return float((err / ref.abs().amax(dim=(0, 2, 3)).clamp_min(1e-30)).max())
+
+    plain = run(hip.RNN_F16)
+    want = run(hip.RNN_F16 | hip.RNN_KPAIR)
+    e_pair, e_plain = row_err(want[0]), row_err(plain[0])
+    assert e_pair < 1.5 * e_plain + 2e-7, (e_pair, e_plain)
+    assert not torch.equal(want[0], plain[0])
+    assert torch.equal(want[2].view(torch.float32),
+                       torch.nan_to_num(want[0]).abs().amax(dim=(0, 1)).reshape(-1))
+    assert float((want[1] - plain[1]).abs().max()) < 1e-5 * max(1.0, float(plain[1].abs().max()))
+    for attempt in range(2):
+        got = run(hip.RNN_F16 | hip.RNN_KPAIR)
+        assert torch.equal(got[0], want[0]), attempt
+        assert torch.equal(got[2], want[2])
+    if num_steps >= 7:
+        cuts = [num_steps, num_steps - 1, num_steps - 3, num_steps // 2, 1, 0]
+        for attempt in range(2):
+            got = run(hip.RNN_F16 | hip.RNN_KPAIR, cuts)
+            assert torch.equal(got[0], want[0]), attempt
+            assert torch.equal(got[2], want[2])
+        mixed = run(hip.RNN_F16 | hip.RNN_KPAIR, cuts, alternate=hip.RNN_F16)
+        assert row_err(mixed[0]) < 1.5 * e_plain + 2e-7
+        again = run(hip.RNN_F16 | hip.RNN_KPAIR)
+        assert torch.equal(again[0], want[0])
+
+
 def test_staggered_launch_leaves_at_once_when_the_time_out_word_is_set(hip):
     """The sticky time-out word ends a staggered-tile launch like every other persistent launch
     (nothing written, no spinning), and the pass after the poll is whole again."""

@@ -248,9 +248,14 @@ def test_a_nan_loss_raises_what_the_reference_raises():
     assert torch.equal(trainer.model.arena.param, before)
     with pytest.raises(NanLossDuringTrainingError, match='NaN loss during training'):
         trainer.drain_checks()
-    trainer.drain_checks()
+    # the dropped step leaves the step counter again (TensorFlow's global step would not have
+    # advanced): Adam's bias correction and checkpoint names count applied updates
+    with pytest.warns(RuntimeWarning, match='dropped on the device'):
+        trainer.drain_checks()
+    assert trainer.model.step_count == 1 and trainer.skipped_step_count() == 1
     trainer.train_step(feats, flen, labels)
     trainer.drain_checks()
+    assert trainer.model.step_count == 2
     assert torch.isfinite(trainer.model.arena.param).all()
 
 

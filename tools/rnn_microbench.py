@@ -69,7 +69,7 @@ def main():
                 words = ws[base: base + 40].cpu().numpy().view(np.uint64)
                 labels = ['wait', 'partial loads+sum', 'gates+A operand', 'mfma+publish',
                           'drain+arrive+dxw']
-            if name == 'bwd' and os.environ.get('CTCASR_KPAIR'):
+            if name == 'bwd' and os.environ.get('CTCASR_KPAIR') and H == 1024:
                 words = ws[base: base + 72].cpu().numpy().view(np.uint64)
                 labels = ['marker wait', 'poll wait', 'main loops (rest)',
                           'reduce+hand-off+gates+publish', 'spins x 100', 'of which hand-off wait',

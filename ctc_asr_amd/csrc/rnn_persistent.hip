@@ -3307,35 +3307,42 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16k_kernel(PArgs p) {
 #ifndef PRNN_W16_D
 #define PRNN_W16_D 12                  // ring depth: producers whose A granules are in flight
 #endif
+#ifndef PRNN_W16_KS
+#define PRNN_W16_KS 2                  // CTCASR_RNN_KPAIR: workgroups that share a K axis (2 or 4)
+#endif
 #ifndef PRNN_W16_KD
-#define PRNN_W16_KD 16                 // ... of the K-pair form (32 producers per wave)
+#define PRNN_W16_KD 12                 // ... and their ring depth (64 / KS producers per wave)
 #endif
 __host__ __device__ inline size_t prnn_w16_scale_bytes(int T) {
     return (size_t)(T + 1) * 2 * (PRNN_W16_H / 8) * PRNN_B16_SCALE_ROWS * sizeof(float);
 }
-// K pairs: one KPairWords per direction, then [dir][workgroup][128 words]
+// K split: one KPairWords per direction, then [dir][workgroup][sending member 0 .. 3][128 words]
 __host__ __device__ inline size_t prnn_w16_kp_bytes() {
-    return 2 * sizeof(KPairWords) + (size_t)2 * (PRNN_W16_H / 8) * 128 * sizeof(unsigned);
+    return 2 * sizeof(KPairWords) + (size_t)2 * (PRNN_W16_H / 8) * 4 * 128 * sizeof(unsigned);
 }
-// KP (round 6, CTCASR_RNN_KPAIR): the K-pair form.  The workgroups {slice, slice ^ 8} - one XCD -
-// share 16 hidden units = ONE FULL N tile (the plain form multiplies half-empty tiles): each holds
-// one K half (128 producers) of the weights of all 16 units (the same 256 KB: 64 KB per wave,
-// half in LDS, half in 128 registers), reads only that half's blocks - 256 KB instead of 512 KB per
-// direction-step, through L2s that were at half of their aggregate peak - issues half of the
-// MFMAs, and hands its partner the partial sums of the partner's 8 units: 16 x 8 fp32 words, each
-// tagged in its lowest significand bit with the parity of the slot's write count (KPairWords of
-// the direction; the receiver clears the bit again).  This kernel has ONE barrier per step and
-// nothing in flight at the hand-off, so the receiver polls with L2-bypassing vector loads.
-// Publishes what the plain form publishes; the K sums differ in their order (to rounding).
-template <int D, bool KP = false>
+// KS > 1 (round 6, CTCASR_RNN_KPAIR): the K axis split over KS workgroups of one XCD (2: pairs,
+// 4: quads).  The workgroups that differ only in bits 3.. of their slice share 8 KS hidden units =
+// KS / 2 FULL N tiles (the plain form multiplies half-empty tiles): each holds one K part
+// (256 / KS producers) of the weights of all those units (the same 256 KB: 64 KB per wave, half in
+// LDS, half in 128 registers), reads only that part's blocks - 512 / KS KB instead of 512 KB per
+// direction-step, through L2s that were at half of their aggregate peak -, issues half of the
+// MFMAs, and hands every partner the partial sums of that partner's 8 units: 16 x 8 fp32 words,
+// each tagged in its lowest significand bit with the parity of the slot's write count
+// (KPairWords of the direction; the receiver clears the bit again).  This kernel has ONE barrier
+// per step and nothing in flight at the hand-off, so the receiver polls with L2-bypassing vector
+// loads.  Publishes what the plain form publishes; the K sums differ in their order (to rounding).
+template <int D, int KS = 1>
 __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     constexpr int H = PRNN_W16_H, GH = 4 * H, NW = 4, NTH = PRNN_THREADS;
     constexpr int NP = H / 8;               // producers per direction = workgroups
-    constexpr int NPW = NP / NW / (KP ? 2 : 1);     // producers per wave: 64 (K pairs: 32)
-    constexpr int QS = NPW * 2;             // B-fragment slots per wave: (producer, piece)
-    // 64 slots in LDS (512 B each: 8 real columns), 64 in registers; K pairs: 32 full slots of
-    // 1 KB in LDS, 32 in registers
+    constexpr bool KP = KS > 1;
+    constexpr int NT = KP ? KS / 2 : 1;     // N tiles of 16 units (plain form: one, half empty)
+    constexpr int NPW = NP / NW / KS;       // producers per wave: 64 / KS
+    constexpr int QS = NPW * 2 * NT;        // B-fragment slots per wave: (producer, piece, N tile)
+    // plain form: 64 slots in LDS (512 B each: 8 real columns), 64 in registers; K split: 32 full
+    // slots of 1 KB in LDS, 32 in registers
     constexpr int QL = QS / 2, REGW = QS - QL, SLOT = KP ? 64 : 32;
+    static_assert(KS == 1 || KS == 2 || KS == 4, "K split");
     constexpr int RED_FLOATS = NW * 16 * 17;
     constexpr int IVL = NPW * 4;            // float4 slots of a wave's inverse scales
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3343,7 +3350,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     if (launch_poisoned(p.sync)) return;
     u32x4 *frag = reinterpret_cast<u32x4 *>(smem);          // [wave][QL][32 granules]
     float *red = reinterpret_cast<float *>(smem + (size_t)NW * QL * SLOT * sizeof(u32x4));
-    float4 *invs = reinterpret_cast<float4 *>(red + RED_FLOATS);        // [wave][IVL]
+    float4 *invs = reinterpret_cast<float4 *>(red + NT * RED_FLOATS);   // [wave][IVL]
     float *wave_top = reinterpret_cast<float *>(invs + NW * IVL);
 
     const int chain = p.chain0 + (int)blockIdx.x / (p.ndir * p.nwg);
@@ -3355,11 +3362,13 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     const int group_size = p.nwg / PRNN_GROUPS, grp = slice / group_size;
     const int B = p.B, T = p.T, BS = p.BS;
     const int u0 = slice * 8;
-    // K pairs: column c of the N tile = unit u0 + c (c < 8, ours) or the partner's unit c - 8;
-    // this workgroup's K half: producers 128 kh .. 128 kh + 127
-    const int partner = slice ^ 8, kh = KP ? (slice >> 3) & 1 : 0;
-    const int pb = (KP ? 128 * kh : 0) + wave * NPW;        // this wave's first producer
-    auto tile_unit = [&](int c) -> int { return KP && c >= 8 ? partner * 8 + c - 8 : u0 + (c & 7); };
+    // K split: the KS workgroups that differ in bits 3.. of their slice (one XCD: workgroup b runs
+    // on XCD b % 8); member j's 8 units are columns 8 j .. 8 j + 7 of the N tiles; this workgroup
+    // is member kh and multiplies K part kh: producers (256 / KS) kh ...
+    const int kh = KP ? (slice >> 3) & (KS - 1) : 0;
+    auto member = [&](int j) -> int { return (slice & ~(8 * (KS - 1))) | (8 * j); };
+    const int pb = (NP / KS) * kh + wave * NPW;             // this wave's first producer
+    auto tile_unit = [&](int c) -> int { return KP ? member(c >> 3) * 8 + (c & 7) : u0 + (c & 7); };
     KPairWords *kpw = nullptr;
     unsigned kp_base = 0;
     if constexpr (KP) {
@@ -3373,13 +3382,17 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     {
         float m = 0.f;
         if constexpr (KP) {
-            // 16 rows of R^T, the K half's 1024 columns of every gate
-            const float *wrow = p.w + ((size_t)dir * H + tile_unit(tid & 15)) * GH + 1024 * kh;
-            for (int g = 0; g < 4; ++g)
-                for (int x = (tid >> 4) * 4; x < 1024; x += NTH / 16 * 4) {
-                    const float4 v = ldg4(wrow + (size_t)g * H + x);
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-                }
+            // 16 NT rows of R^T, the K part's H / KS columns of every gate
+            for (int n = 0; n < NT; ++n) {
+                const float *wrow = p.w + ((size_t)dir * H + tile_unit(n * 16 + (tid & 15))) * GH +
+                                    (H / KS) * kh;
+                for (int g = 0; g < 4; ++g)
+                    for (int x = (tid >> 4) * 4; x < H / KS; x += NTH / 16 * 4) {
+                        const float4 v = ldg4(wrow + (size_t)g * H + x);
+                        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))),
+                                  fmaxf(fabsf(v.z), fabsf(v.w)));
+                    }
+            }
         } else {
             const float *wrow = p.w + ((size_t)dir * H + u0 + (tid & 7)) * GH;
             for (int n = (tid >> 3) * 4; n < GH; n += NTH / 8 * 4) {
@@ -3399,9 +3412,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     const float out_scale = 1.0f / w_scale;
     u32x4 wreg[REGW];
     {
-        // fragment of producer P (of this wave): lane (k group q = lane >> 4, column lane & 7)
-        auto pieces = [&](int pw, u32x4 &first, u32x4 &second) {
-            const float *wcol = p.w + ((size_t)dir * H + tile_unit(lane & 15)) * GH +
+        // fragment of producer P (of this wave), N tile n: lane (k group q = lane >> 4, column
+        // lane & 15 [& 7])
+        auto pieces = [&](int pw, int n, u32x4 &first, u32x4 &second) {
+            const float *wcol = p.w + ((size_t)dir * H + tile_unit(n * 16 + (lane & 15))) * GH +
                                 8 * (pb + pw) + 2 * (lane >> 4);
             unsigned q[8];
 #pragma unroll
@@ -3412,20 +3426,25 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
             second = (u32x4){(q[0] >> 16) | (q[1] & 0xFFFF0000u), (q[2] >> 16) | (q[3] & 0xFFFF0000u),
                              (q[4] >> 16) | (q[5] & 0xFFFF0000u), (q[6] >> 16) | (q[7] & 0xFFFF0000u)};
         };
-        for (int pw = 0; pw < QL / 2; ++pw) {
-            u32x4 first, second;
-            pieces(pw, first, second);
-            if constexpr (KP) {
-                frag[(wave * QL + 2 * pw) * 64 + lane] = first;
-                frag[(wave * QL + 2 * pw + 1) * 64 + lane] = second;
-            } else if ((lane & 15) < 8) {
-                const int cell16 = (lane >> 4) * 8 + (lane & 7);
-                frag[(wave * QL + 2 * pw) * 32 + cell16] = first;
-                frag[(wave * QL + 2 * pw + 1) * 32 + cell16] = second;
+        // slot = (producer 2 + piece) NT + n
+        for (int pw = 0; pw < QL / 2 / NT; ++pw)
+            for (int n = 0; n < NT; ++n) {
+                u32x4 first, second;
+                pieces(pw, n, first, second);
+                if constexpr (KP) {
+                    frag[(wave * QL + (2 * pw) * NT + n) * 64 + lane] = first;
+                    frag[(wave * QL + (2 * pw + 1) * NT + n) * 64 + lane] = second;
+                } else if ((lane & 15) < 8) {
+                    const int cell16 = (lane >> 4) * 8 + (lane & 7);
+                    frag[(wave * QL + 2 * pw) * 32 + cell16] = first;
+                    frag[(wave * QL + 2 * pw + 1) * 32 + cell16] = second;
+                }
             }
-        }
 #pragma unroll
-        for (int pw = 0; pw < REGW / 2; ++pw) pieces(QL / 2 + pw, wreg[2 * pw], wreg[2 * pw + 1]);
+        for (int pw = 0; pw < REGW / 2 / NT; ++pw)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                pieces(QL / 2 / NT + pw, n, wreg[(2 * pw) * NT + n], wreg[(2 * pw + 1) * NT + n]);
     }
     __syncthreads();
 
@@ -3442,10 +3461,11 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, rnum, 0x00020000);
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cells, 0, rnum, 0x00020000);
     const __amdgpu_buffer_rsrc_t dx_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dxw, 0, rnum, 0x00020000);
-    // K pairs: the hand-off slots behind the two directions' KPairWords: [dir][slice][128 words]
+    // K split: the hand-off slots behind the two directions' KPairWords:
+    // [dir][slice][sending member 0 .. 3][128 words]
     const __amdgpu_buffer_rsrc_t kp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         KP ? p.kp + 2 * sizeof(KPairWords) / sizeof(unsigned) : nullptr, 0,
-        KP ? (int)(2 * NP * 128 * sizeof(unsigned)) : 0, 0x00020000);
+        KP ? (int)(2 * NP * 4 * 128 * sizeof(unsigned)) : 0, 0x00020000);
     auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> float {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
     };
@@ -3461,26 +3481,34 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
     const int a_steps = arow < B ? row_steps(p.seq_len, arow, T) : 0;
 
     unsigned long long pt[4] = {0, 0, 0, 0};
-    const bool prof = p.prof && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool prof = p.prof && threadIdx.x == 0;       // (every workgroup: prof_all)
     for (int s = p.s_hi - 1; s >= p.s_lo; --s) {
         unsigned long long c0 = prof ? wall_clock64() : 0;
         float dyv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cv = 0.f, cpv = 0.f;
         int it_t = -1;
-        if (s < steps) {
-            const int t = row_time(dir, s, steps);
-            it_t = t;
-            const unsigned e0 = (unsigned)(((t * BS + brow) * 2 + dir) * H + unit);
-            dyv = ldf(dy_rsrc, e0 * 4u);
-            gi = ldf(g_rsrc, (e0 * 4u - 3u * unit) * 4u);
-            gf = ldf(g_rsrc, (e0 * 4u - 3u * unit + H) * 4u);
-            gg = ldf(g_rsrc, (e0 * 4u - 3u * unit + 2 * H) * 4u);
-            go = ldf(g_rsrc, (e0 * 4u - 3u * unit + 3 * H) * 4u);
-            cv = ldf(c_rsrc, e0 * 4u);
-            if (s > 0)
-                cpv = ldf(c_rsrc, (unsigned)(((row_time(dir, s - 1, steps) * BS + brow) * 2 + dir) *
-                                             H + unit) * 4u);
-        }
-        f32x4 total = {0.f, 0.f, 0.f, 0.f};
+        // what the cell derivative needs besides dh_rec: requested before the barrier (behind the
+        // first ring loads instead - the barrier's polls wait for everything in front of them in
+        // the in-order queue - measured slower: profiles/r06_rnn_bwd_k_split_2048.md)
+        auto cell_prefetch = [&]() {
+            if (s < steps) {
+                const int t = row_time(dir, s, steps);
+                it_t = t;
+                const unsigned e0 = (unsigned)(((t * BS + brow) * 2 + dir) * H + unit);
+                dyv = ldf(dy_rsrc, e0 * 4u);
+                gi = ldf(g_rsrc, (e0 * 4u - 3u * unit) * 4u);
+                gf = ldf(g_rsrc, (e0 * 4u - 3u * unit + H) * 4u);
+                gg = ldf(g_rsrc, (e0 * 4u - 3u * unit + 2 * H) * 4u);
+                go = ldf(g_rsrc, (e0 * 4u - 3u * unit + 3 * H) * 4u);
+                cv = ldf(c_rsrc, e0 * 4u);
+                if (s > 0)
+                    cpv = ldf(c_rsrc, (unsigned)(((row_time(dir, s - 1, steps) * BS + brow) * 2 +
+                                                  dir) * H + unit) * 4u);
+            }
+        };
+        cell_prefetch();
+        f32x4 total[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) total[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s < T - 1) {
             if (s < p.s_hi - 1) {
                 dir_wait<1>(p.sync, nullptr, dir, chain, group_size, (unsigned)(p.s_hi - 2 - s),
@@ -3526,51 +3554,86 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int P = 0; P < NPW; ++P) {
-                Frag16 w1, w2, d1, d2;
-                w1.u = bfrag(2 * P);
-                w2.u = bfrag(2 * P + 1);
+                Frag16 w1[NT], w2[NT], d1, d2;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    w1[n].u = bfrag((2 * P) * NT + n);
+                    w2[n].u = bfrag((2 * P + 1) * NT + n);
+                }
                 d1.u = a[P % D][0];
                 d2.u = a[P % D][1];
-                f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w1.h, zero, 0, 0, 0);
-                f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w2.h, zero, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2.h, w1.h, acc1, 0, 0, 0);
+                f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc0[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w1[n].h, zero, 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1.h, w2[n].h, zero, 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2.h, w1[n].h, acc1[n], 0, 0, 0);
                 if (P + D < NPW) issue(P + D, a[P % D]);
                 const float4 ivp = invs[wave * IVL + 4 * P + (lane >> 4)];
-                const f32x4 sum = acc0 + acc1;
-                total[0] += sum[0] * ivp.x;
-                total[1] += sum[1] * ivp.y;
-                total[2] += sum[2] * ivp.z;
-                total[3] += sum[3] * ivp.w;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 sum = acc0[n] + acc1[n];
+                    total[n][0] += sum[0] * ivp.x;
+                    total[n][1] += sum[1] * ivp.y;
+                    total[n][2] += sum[2] * ivp.z;
+                    total[n][3] += sum[3] * ivp.w;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (prof) {
-            asm volatile("" ::"v"(total[0]));
+            asm volatile("" ::"v"(total[0][0]));
             unsigned long long c = wall_clock64(); pt[1] += c - c0; c0 = c;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            red[(wave * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] = total[r] * out_scale;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[n * RED_FLOATS + (wave * 16 + 4 * (lane >> 4) + r) * 17 + (lane & 15)] =
+                    total[n][r] * out_scale;
         __syncthreads();
 
-        float theirs_half = 0.f;            // K pairs: the partner's K half of this item's sum
+        // K split: sum of the waves' shares of member j's 8 columns, for row ib and unit iu
+        auto member_sum = [&](int j) -> float {
+            const float *r = red + (j >> 1) * RED_FLOATS + ib * 17 + (j & 1) * 8 + iu;
+            float v = r[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += r[w * 16 * 17];
+            return v;
+        };
+        float others = 0.f;                 // K split: the partners' K parts of this item's sum
         if constexpr (KP) {
             const unsigned tag = (kp_base + (unsigned)(p.s_hi - s)) & 1u;
             if (!has_item) {
-                // threads 128 .. 255: row (tid >> 3) & 15, the partner's unit tid & 7 -> word
-                // tid - 128 of the partner's slot
-                float v = 0.f;
+                // threads 128 .. 255: row (tid >> 3) & 15, unit tid & 7 of every partner -> word
+                // tid - 128 of the partner's slot for this sender
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v += red[(w * 16 + ib) * 17 + 8 + iu];
-                __builtin_amdgcn_raw_buffer_store_b32(
-                    (__float_as_uint(v) & ~1u) | tag, kp_rsrc, (int)((tid - 128) * 4),
-                    (int)(((dir * NP + partner) * 128) * 4), 16);
+                for (int j = 0; j < KS; ++j) {
+                    if (j == kh) continue;
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        (__float_as_uint(member_sum(j)) & ~1u) | tag, kp_rsrc, (int)((tid - 128) * 4),
+                        (int)((((dir * NP + member(j)) * 4 + kh) * 128) * 4),
+                        16);
+                }
             } else {
-                unsigned rv = 0u, spins = 0;
+                unsigned rv[KS], spins = 0;
                 for (;;) {
-                    rv = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
-                        kp_rsrc, (int)(tid * 4), (int)(((dir * NP + slice) * 128) * 4), 16);
-                    if (__all((rv & 1u) == tag)) break;
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        rv[j] = tag;
+                        if (j != kh)
+                            rv[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
+                                kp_rsrc, (int)(tid * 4), (int)((((dir * NP + slice) * 4 + j) * 128) * 4),
+                                16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) ok = ok && (rv[j] & 1u) == tag;
+                    if (__all(ok)) break;
                     if (++spins > PRNN_SPIN_LIMIT ||
                         ((spins & 1023u) == 0 &&
                          __hip_atomic_load(&p.sync->error, __ATOMIC_RELAXED,
@@ -3582,7 +3645,9 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                theirs_half = __uint_as_float(rv & ~1u);
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+                    if (j != kh) others += __uint_as_float(rv[j] & ~1u);
             }
         }
         if (has_item) {
@@ -3590,10 +3655,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
             if (it_t >= 0) {
                 float dh = dyv;
                 if constexpr (KP) {
-                    float rec = red[ib * 17 + iu];
-#pragma unroll
-                    for (int w = 1; w < NW; ++w) rec += red[(w * 16 + ib) * 17 + iu];
-                    dh += rec + theirs_half;
+                    dh += member_sum(kh) + others;
                 } else {
 #pragma unroll
                     for (int w = 0; w < NW; ++w) dh += red[(w * 16 + ib) * 17 + iu];
@@ -3664,7 +3726,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16w_kernel(PArgs p) {
         if (prof) { unsigned long long c = wall_clock64(); pt[3] += c - c0; c0 = c; }
     }
     if (prof)
-        for (int i = 0; i < 4; ++i) p.sync->prof[4 + i] = pt[i];
+        for (int i = 0; i < 4; ++i) {
+            if (blockIdx.x == 0) p.sync->prof[4 + i] = pt[i];
+            p.sync->prof_all[blockIdx.x & 255][i] = pt[i];
+        }
     if constexpr (KP) {
         // the last workgroup to leave advances the direction's write count (prnn_bwd16k_kernel)
         __syncthreads();
@@ -4315,7 +4380,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
             for (int dir = 0; dir < 2; ++dir) {
                 p.chain0 = tile; p.dir0 = dir;
                 const int rc = pairs
-                    ? launch_persistent(prnn_bwd16w_kernel<PRNN_W16_KD, true>, p, lds, s)
+                    ? launch_persistent(prnn_bwd16w_kernel<PRNN_W16_KD, PRNN_W16_KS>, p, lds, s)
                     : launch_persistent(prnn_bwd16w_kernel<PRNN_W16_D>, p, lds, s);
                 if (rc != CTCASR_OK) return rc;
             }
@@ -4477,7 +4542,7 @@ extern "C" unsigned ctcasr_build_flags(void) {
         PRNN_XCD_TILE_PAIRS != 1 || PRNN_B16S_D != 8 || PRNN_B16S_JW != 7 || PRNN_B16S_JP != 5 ||
         PRNN_B16S_JA != 1 || PRNN_B16S_XCD_EXCL != 0 || PRNN_B16K_JW != 3 || PRNN_B16K_JP != 2 ||
         PRNN_B16K_JA != 1 || PRNN_B16K_SC1 != 0 || PRNN_B16K_SLEEP != 1 || PRNN_W16_D != 12 ||
-        PRNN_W16_KD != 16)
+        PRNN_W16_KD != 12 || PRNN_W16_KS != 2)
         flags |= CTCASR_BUILD_NONDEFAULT_TUNING;
     return flags;
 }

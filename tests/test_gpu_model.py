@@ -1,6 +1,8 @@
 """End-to-end parity of the MI355X model (forward, CTC loss, backward, Adam) against the CPU
 oracle: logits and loss within 1e-3 (north_star bar, fp32), gradients to 1e-3 relative."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -427,6 +429,48 @@ def test_assembled_reference_default_model(frames, label_len):
         cfg, batch=16, frames=frames, label_len=label_len, seed=22,
         grad_names=('conv2/kernel', 'rnn0/w_ih', 'rnn1/w_hh', 'rnn3/w_hh', 'dense4/kernel'),
         kinked=True)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('cell', ['rnn_relu', 'lstm'])
+def test_the_reference_models_at_full_length(cell):
+    """the reference's OWN models at the length the benchmark times them -
+    `ref_default` (asr/params.py: 3 conv + 4 x BiRNN(relu)-2048) and `ref_best` (testruns.md:
+    3 conv + 4 x BiLSTM-2048), batch 16, 999 frames -> T' = 500, 150 labels per utterance - through
+    the default path (fp16-split projections, the fp16-pipe recurrences where they exist) against
+    the float64 torch restatement: logits and loss to 1e-3, greedy strings identical.  (Forward
+    and loss only: the float64 backward pass of 4 x 2048 units over 500 steps is the better part
+    of an hour on the host; the gradients of these models are tested at T' <= 160 above and, for
+    the kernels they run, step by step in test_gpu_kernels.py.)"""
+    cfg = ModelConfig(used_model='ds2', conv_filters=(32, 32, 96), num_units_dense=2048,
+                      num_layers_rnn=4, num_units_rnn=2048, rnn_cell=cell, cudnn=True,
+                      dense_dropout_rate=0.0)
+    batch, frames, label_len = 16, 999, 150
+    rng = np.random.default_rng(31)
+    flat = init_params(cfg, 31)
+    feats = rng.normal(size=(batch, frames, 80)).astype(np.float32)
+    flen = np.full(batch, frames, dtype=np.int32)
+    labels = [list(rng.integers(1, 28, size=label_len)) for _ in range(batch)]
+    model = CTCModel(cfg, 'cuda', params=flat)
+    logits, seq_len = model.inference_fn(torch.tensor(feats), torch.tensor(flen), training=True)
+    loss = model.loss_fn(logits, seq_len, labels)
+    model.check_rnn_error()
+    t_out = cfg.output_time(frames)
+    assert t_out == 500 and logits.shape == (t_out, batch, 29)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(threads, min(32, os.cpu_count() or 8)))
+    try:
+        ref = torch_ref.TorchRefModel(to_oracle_layout(flat, cfg), cfg.used_model, cfg.rnn_cell,
+                                      cfg.cudnn, dtype=torch.float64)
+        with torch.no_grad():
+            t_logits, t_len = ref(torch.tensor(feats, dtype=torch.float64), flen)
+            t_loss, _ = ref.loss(t_logits, t_len, labels)
+    finally:
+        torch.set_num_threads(threads)
+    assert np.abs(logits.cpu().numpy() - t_logits.numpy()).max() < 1e-3
+    assert abs(float(loss) - float(t_loss)) < 1e-3 * max(1.0, abs(float(t_loss)))
+    decoded, _, _ = model.decode_fn(logits, seq_len, None, greedy=True)
+    assert decoded == octc.greedy_decode(t_logits.numpy(), [t_out] * batch)
 
 
 def test_decode_many_equals_batch_by_batch_decoding():

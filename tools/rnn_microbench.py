@@ -106,6 +106,28 @@ def main():
                           'per blockIdx % 8: {}'.format(
                               busy.min(), np.median(busy), busy.max(),
                               np.round([busy[i::8].mean() for i in range(8)], 2).tolist()))
+            if name == 'bwd' and H == 2048 and cell == 'lstm' and os.environ.get('CTCASR_F16'):
+                # (the last launch of the pass: tile 0 / the last tile, direction 1)
+                fbase = state + 9216 + 256
+                every = ws[fbase + 128: fbase + 128 + 256 * 32].cpu().numpy().view(np.uint64) \
+                    .reshape(256, 4).astype(np.float64) / 100.0 / T
+                for k, label in enumerate(labels[:4]):
+                    col = every[:, k]
+                    print('    all 256 workgroups, {:<22s} min {:.2f}  median {:.2f}  max {:.2f}'
+                          .format(label, col.min(), np.median(col), col.max()))
+                busy = every[:, 1] + every[:, 2] + every[:, 3]
+                print('    busy (all but wait): min {:.2f} median {:.2f} max {:.2f}; per slice % 8: {}; '
+                      'per (slice >> 3) & 3: {}'.format(
+                          busy.min(), np.median(busy), busy.max(),
+                          np.round([busy[i::8].mean() for i in range(8)], 2).tolist(),
+                          np.round([busy[[b for b in range(256) if (b >> 3) & 3 == j]].mean()
+                                    for j in range(4)], 2).tolist()))
+                order = np.argsort(busy)
+                print('    busiest workgroups: {}  us {}'.format(
+                    order[-8:].tolist(), np.round(busy[order[-8:]], 2).tolist()))
+                for k, label in enumerate(labels[:4]):
+                    print('      {:<22s} of the busiest 8: {}'.format(
+                        label, np.round(every[order[-8:], k], 2).tolist()))
             if name == 'fwd':
                 every = ws[base + 128: base + 128 + 256 * 32].cpu().numpy().view(np.uint64) \
                     .reshape(256, 4).astype(np.float64) / 100.0 / T

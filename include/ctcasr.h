@@ -515,7 +515,12 @@ int ctcasr_dgrad16_blockscaled(void *workspace, int T, int B, int hidden, const 
  * outputs; `parts` >= 1 cuts every tile's row sum into that many workgroups (for launches whose
  * tiles alone do not fill the chip), which add to dW in part order through the words of `sync`
  * (ctcasr_wgrad16_sync_ints(m, nx, ny) int32, ZERO before the first launch that uses them; every
- * launch leaves them zero; word 0 turns 1 should a part give up waiting - sticky, never seen).
+ * launch leaves them zero).  Part q adds when the tile's word reads q - part 0 too, so launches
+ * of different streams that share the words take turns at a tile.  ABI v7: a part that gives up
+ * waiting (bounded; ctcasr_set_option("wgrad16_spin_limit", polls) shortens the bound for tests)
+ * sets word 0 and leaves WITHOUT adding and without passing the turn on; while word 0 is set
+ * every launch on these words returns at once.  The caller folds word 0 into the optimizer's skip
+ * flag (ctcasr_step_guard's wgrad_word), raises, and zeroes the words before the next launch.
  * sync may be NULL for parts == 1. */
 size_t ctcasr_wgrad16_packed_bytes(int stages, int cols);
 size_t ctcasr_wgrad16_sync_ints(int m, int nx, int ny);

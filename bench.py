@@ -497,11 +497,21 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                              hidden == 1024 and 16 < batch <= 32 and cfg.cudnn and
                              not args.rnn_bwd_whole_chip and
                              bool(getattr(model, 'rnn_stagger_flag', 0)))
+                # the kernel's name as a trace shows it: H = 2048 LSTM backward = prnn_bwd16w_kernel
+                # (one direction per launch; K split over pairs of workgroups unless
+                # CTCASR_RNN_KPAIR_2048=0), the ReLU cell's fp16 backward = prnn_relu16_kernel<true>
+                kname = 'prnn_{}{}_kernel<{}>'.format(
+                    dom[4:], ('16s' if staggered else '16') if f16_kernel else '', rnn_cell.upper())
+                if f16_kernel and dom == 'rnn_bwd' and rnn_cell == 'lstm' and hidden == 2048:
+                    kname = 'prnn_bwd16w_kernel<LSTM-2048{}>'.format(
+                        ', K split over pairs of workgroups'
+                        if getattr(model, 'rnn_kpair_wide', False) else '')
+                elif f16_kernel and rnn_cell == 'rnn_relu':
+                    kname = 'prnn_relu16_kernel<{}>'.format('true' if dom == 'rnn_bwd' else 'false')
                 roofline = {
-                    'kernel': 'prnn_{}{}_kernel<{}> (persistent, LDS-resident recurrent weights; '
+                    'kernel': '{} (persistent, LDS-resident recurrent weights; '
                               'one launch = {:.0f} time steps x 2 directions, batch {}{})'.format(
-                                  dom[4:], ('16s' if staggered else '16') if f16_kernel else '',
-                                  rnn_cell.upper(), launch_steps, batch,
+                                  kname, launch_steps, batch,
                                   '; the two 16-row tiles staggered by half a step'
                                   if staggered else ''),
                     'bound': 'mfma', 'achieved': round(achieved, 2),

@@ -72,6 +72,10 @@ def main(src, workload, out_md):
     entries, traffic_text = [], []
     for which, pattern in (('rnn_bwd', 'prnn_bwd'), ('rnn_fwd', 'prnn_fwd')):
         kernel = step_kernel(fetch, pattern)
+        if kernel is None and cell in ('rnn_relu', 'rnn_tanh'):
+            # the ReLU cell's fp16-pipe kernel: one template, <true> = backward
+            kernel = step_kernel(fetch, 'prnn_relu16_kernel<{}>'.format(
+                'true' if which == 'rnn_bwd' else 'false'))
         if kernel is None:
             continue
         f_kb, w_kb = value(fetch, kernel, 'FETCH_SIZE'), value(write, kernel, 'WRITE_SIZE')
@@ -102,8 +106,9 @@ def main(src, workload, out_md):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = cycles the kernel ran (at the clock
             # it really had); busy cycles are summed over the SIMDs of the CUs it occupies
             cus = 256 if which == 'rnn_fwd' else 128
-            if 'rnn_bwd_whole_chip' in line.get('config', {}).get('workload', ''):
-                cus = 256
+            if 'rnn_bwd_whole_chip' in line.get('config', {}).get('workload', '') or \
+                    (hidden == 2048 and cell in ('lstm', 'gru')):
+                cus = 256       # (H = 2048 LSTM / GRU: one direction per launch on the whole chip)
             text += ('  MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES {:.0f} M / (GRBM_GUI_ACTIVE {:.1f} M '
                      '/ 8 XCDs x {} CUs x 4 SIMDs) = {:.0f} % of the CUs the kernel occupies.'
                      .format(busy / 1e6, gui / 1e6, cus, 100.0 * busy / (gui / 8 * cus * 4)))

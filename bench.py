@@ -494,7 +494,7 @@ def measure(name, args, rank, local_rank, world, allreduce_early=None, reduce=Tr
                 # 17..32 rows, LSTM-1024, cuDNN semantics, half of the chip: the staggered-tile
                 # kernel (prnn_bwd16s_kernel) unless CTCASR_RNN_STAGGER=0
                 staggered = (dom == 'rnn_bwd' and f16_kernel and rnn_cell == 'lstm' and
-                             hidden == 1024 and 16 < batch <= 32 and cfg.cudnn and
+                             hidden == 1024 and 16 < batch <= 32 and batch % 8 == 0 and cfg.cudnn and
                              not args.rnn_bwd_whole_chip and
                              bool(getattr(model, 'rnn_stagger_flag', 0)))
                 # the kernel's name as a trace shows it: H = 2048 LSTM backward = prnn_bwd16w_kernel

@@ -2420,7 +2420,10 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16s_kernel(PArgs p) {
     auto tile_addresses = [&](int s, int x) {
         ablock[x] = (unsigned)(((s + 1 < T ? x_base + (size_t)(s + 1) * x_step : 0) +
                                 (size_t)dir * B * GH) * sizeof(float));
-        iv_next = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
+        // (L1 / L2 bypassed: a producer's 32 inverse scales - BOTH tiles' - share one 128-byte line,
+        // and the other tile's half is written after this tile's half has been read: see the
+        // dispatch in prnn_bwd)
+        iv_next = load16_sc1<16>(s_rsrc, (unsigned)(s + 1) * S_STEP +
                                          (unsigned)(((dir * (H / 16) + wave * NPW + (lane >> 2)) *
                                                      PRNN_B16_SCALE_ROWS + x * 16 + 4 * (lane & 3)) *
                                                     sizeof(float)));
@@ -2928,7 +2931,7 @@ __global__ void __launch_bounds__(PRNN_THREADS) prnn_bwd16k_kernel(PArgs p) {
     auto tile_addresses = [&](int s, int x) {
         ablock[x] = (unsigned)(((s + 1 < T ? x_base + (size_t)(s + 1) * x_step : 0) +
                                 (size_t)dir * B * GH) * sizeof(float));
-        iv_next = load16_sc1(s_rsrc, (unsigned)(s + 1) * S_STEP +
+        iv_next = load16_sc1<16>(s_rsrc, (unsigned)(s + 1) * S_STEP +
                                          (unsigned)(((dir * (H / 16) + pb + ((lane >> 2) & (NPW - 1))) *
                                                      PRNN_B16_SCALE_ROWS + x * 16 + 4 * (lane & 3)) *
                                                     sizeof(float)));
@@ -4414,7 +4417,17 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
             return (size_t)128 * 1024 + (size_t)waves * tiles * 16 * 17 * 4 +
                    (size_t)tiles * 256 * 16 + 64;      // (inverse scales: 4 float4 per producer)
         };
-        if (mt == 2 && half_chip && (flags & CTCASR_RNN_KPAIR) && !seq_len) {
+        // The kernels that stagger the two tiles publish tile 1's rows of a step AFTER tile 0's
+        // rows of that step have been read: the two must not share a cache line, or the reader's
+        // L1 / L2 keeps tile 1's bytes as they were when the line came in for tile 0 (round 6,
+        // tools/r06_stale_probe.py: the K-pair kernel at B = 17 .. 20 read the pass before; the
+        // staggered kernel was never caught, but nothing but the volume of its other loads
+        // protects it).  A k group's rows are B x 16 bytes in the exchange buffer: tile 1 starts on
+        // a 128-byte line when B is a multiple of 8 - other batches keep the one-barrier kernel.
+        // (The inverse scales of a producer share ONE line for both tiles at every B: the
+        // staggered kernels read them past the caches.)
+        const bool tiles_apart = B % 8 == 0;
+        if (mt == 2 && half_chip && (flags & CTCASR_RNN_KPAIR) && !seq_len && tiles_apart) {
             // K-pair form of the staggered kernel: weights 128 KB, partial tiles [2 tiles][2 n],
             // inverse scales [2 tiles][4 waves][32] float4
             p.kp = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(p.rs) +
@@ -4427,7 +4440,7 @@ int prnn_bwd(int cell, const float *dy, const float *y, const float *w_hh_t,
             return launch_persistent(
                 prnn_bwd16k_kernel<PRNN_B16K_JW, PRNN_B16K_JP, PRNN_B16K_JA>, p, kp_lds, s);
         }
-        if (mt == 2 && half_chip && (flags & CTCASR_RNN_STAGGER) && !seq_len) {
+        if (mt == 2 && half_chip && (flags & CTCASR_RNN_STAGGER) && !seq_len && tiles_apart) {
             if (p.prof)
                 return launch_persistent(
                     prnn_bwd16s_kernel<PRNN_B16S_D, PRNN_B16S_JW, PRNN_B16S_JP, PRNN_B16S_JA, true>,

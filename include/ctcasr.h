@@ -189,8 +189,9 @@ int ctcasr_rnn_fwd(int cell, const float *xw, const float *xw_bias, const float 
  * direction 1's on XCDs 4 - 7 (workgroup b runs on XCD b % 8) - every exchange block crosses the
  * fabric into four L2s instead of eight.  Same results bit for bit (ABI v5). */
 #define CTCASR_RNN_XCD_SPLIT 32
-/* backward, LSTM with H = 1024 on the fp16 pipe, 17..32 rows on half of the chip: the two 16-row
- * tiles staggered by half a step (prnn_bwd16s_kernel: each tile with its own arrival counters, one
+/* backward, LSTM with H = 1024 on the fp16 pipe, 24 or 32 rows (17..32 and a multiple of 8: tile 1's
+ * rows then start on a cache line of their own in the exchange buffer; ABI v7 - other batches keep
+ * the one-barrier kernel) on half of the chip: the two 16-row tiles staggered by half a step (prnn_bwd16s_kernel: each tile with its own arrival counters, one
  * tile's exchange round trip under the other tile's loads) instead of both behind one barrier.
  * Same results bit for bit; every launch of a pass may choose freely.  Calls with per-row lengths
  * and other shapes ignore it.  (ABI v6) */

@@ -431,7 +431,7 @@ def test_rnn_bwd_on_the_fp16_matrix_pipe(hip, use_len, dims):
 
 
 @pytest.mark.parametrize('xcd', [0, 1])
-@pytest.mark.parametrize('dims', [(12, 32), (9, 19), (7, 17), (61, 27), (200, 32)])
+@pytest.mark.parametrize('dims', [(12, 32), (9, 19), (7, 17), (61, 27), (11, 24), (200, 32)])
 def test_rnn_bwd_staggered_tiles_equal_one_barrier(hip, xcd, dims):
     """CTCASR_RNN_STAGGER (prnn_bwd16s_kernel): the two 16-row tiles of a 17..32-row batch half
     a step apart, each with its own arrival counters, next phase's operands requested under this
@@ -502,7 +502,7 @@ def test_rnn_bwd_staggered_tiles_equal_one_barrier(hip, xcd, dims):
 
 
 @pytest.mark.parametrize('xcd', [0, 1])
-@pytest.mark.parametrize('dims', [(12, 32), (7, 17), (61, 27)])
+@pytest.mark.parametrize('dims', [(12, 32), (7, 17), (61, 24)])
 def test_rnn_bwd_k_pairs(hip, xcd, dims):
     """CTCASR_RNN_KPAIR (prnn_bwd16k_kernel, round 6): pairs of workgroups share 32 hidden units,
     each multiplies ONE K half of the published dgates and hands its partner a [16 x 16] partial
@@ -650,6 +650,46 @@ def test_rnn_bwd_k_pairs_at_2048(hip, use_len, dims):
         assert row_err(mixed[0]) < 1.5 * e_plain + 2e-7
         again = run(hip.RNN_F16 | hip.RNN_KPAIR)
         assert torch.equal(again[0], want[0])
+
+
+@pytest.mark.parametrize('xcd', [0, 1])
+@pytest.mark.parametrize('batch', [17, 20, 24, 27, 32])
+def test_staggered_tiles_read_nothing_of_the_pass_before(hip, xcd, batch):
+    """Round 6: the kernels that stagger the two 16-row tiles publish tile 1's rows of a step after
+    tile 0's rows of that step have been read; where the two share a cache line the reader's L1 /
+    L2 keeps tile 1's bytes of the PASS BEFORE (same addresses) - invisible when every pass
+    computes the same thing, which is what every other test of these kernels does.  Here: a pass
+    over data A, then a pass over data B on the same workspace, against data B on a fresh
+    workspace through the one-barrier kernel.  Staggered: bit for bit (batches that are not a
+    multiple of 8 keep the one-barrier kernel: `prnn_bwd`); K pairs: to rounding.  (The K-pair
+    kernel at 17 .. 20 rows failed this before the dispatch kept it to multiples of 8:
+    tools/r06_stale_probe.py.)"""
+    num_steps, hidden, gh = 40, 1024, 4096
+    base = hip.RNN_F16 | (hip.RNN_XCD_SPLIT if xcd else 0)
+
+    def data(seed):
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        xw = torch.randn(num_steps, batch, 2, gh, device=DEV, generator=g) * 0.5
+        w = torch.randn(2, gh, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+        dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g)
+        return xw, w, hip.transpose_batched(w), dy
+
+    for extra, exact in ((hip.RNN_STAGGER, True), (hip.RNN_KPAIR, False)):
+        for rep in range(3):
+            xa, wa, wta, dya = data(100 + rep)
+            xb, wb, wtb, dyb = data(200 + rep)
+            ya, ra, ws = hip.rnn_fwd('lstm', xa, wa)
+            hip.rnn_bwd('lstm', dya, ya, wta, ra, workspace=ws, flags=base | extra)
+            yb, rb, _ = hip.rnn_fwd('lstm', xb, wb, workspace=ws)
+            got = hip.rnn_bwd('lstm', dyb, yb, wtb, rb, workspace=ws, flags=base | extra)
+            hip.rnn_poll_error('lstm', ws, num_steps, batch, hidden)
+            yf, rf, wsf = hip.rnn_fwd('lstm', xb, wb)
+            want = hip.rnn_bwd('lstm', dyb, yf, wtb, rf, workspace=wsf, flags=base)
+            hip.rnn_poll_error('lstm', wsf, num_steps, batch, hidden)
+            if exact:
+                assert torch.equal(got, want), (rep, int((got != want).sum()))
+            else:
+                assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max()), rep
 
 
 def test_staggered_launch_leaves_at_once_when_the_time_out_word_is_set(hip):

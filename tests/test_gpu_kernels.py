@@ -692,6 +692,48 @@ def test_staggered_tiles_read_nothing_of_the_pass_before(hip, xcd, batch):
                 assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max()), rep
 
 
+@pytest.mark.parametrize('cell,hidden', [('lstm', 1024), ('gru', 1024), ('rnn_relu', 2048),
+                                         ('lstm', 2048)])
+def test_no_persistent_kernel_reads_the_pass_before(hip, cell, hidden):
+    """Every persistent recurrence variant, forward and backward: a pass over data A, then a pass
+    over data B on the SAME workspace, equals data B on a fresh workspace bit for bit (same
+    kernel).  Exchange blocks, scales, counters and hand-off slots live at the same addresses in
+    every pass; a kernel that meets a cached copy of the pass before - see
+    test_staggered_tiles_read_nothing_of_the_pass_before - only shows when the data changes."""
+    num_steps = 24
+    gates = hip.CELL_GATES[cell]
+
+    def data(batch, seed):
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        xw = torch.randn(num_steps, batch, 2, gates * hidden, device=DEV, generator=g) * 0.5
+        w = torch.randn(2, gates * hidden, hidden, device=DEV, generator=g) / np.sqrt(hidden)
+        dy = torch.randn(num_steps, batch, 2 * hidden, device=DEV, generator=g)
+        bh = torch.randn(2, gates * hidden, device=DEV, generator=g) * 0.3 if cell == 'gru' else None
+        return xw, w, hip.transpose_batched(w), dy, bh
+
+    def both(d, ws, fwd_flags, bwd_flags):
+        xw, w, wt, dy, bh = d
+        y, res, ws = hip.rnn_fwd(cell, xw, w, workspace=ws, flags=fwd_flags, b_hh_n=bh)
+        dxw = hip.rnn_bwd(cell, dy, y, wt, res, workspace=ws, flags=bwd_flags)
+        hip.rnn_poll_error(cell, ws, num_steps, d[0].shape[1], hidden)
+        return y, dxw, ws
+
+    f16 = hip.RNN_F16 | hip.RNN_XCD_SPLIT
+    variants = ((0, 0), (0, hip.RNN_WHOLE_CHIP), (hip.RNN_ONE_BARRIER, hip.RNN_ONE_BARRIER),
+                (f16, f16 | hip.RNN_STAGGER), (f16, f16 | hip.RNN_KPAIR),
+                (hip.RNN_F16 | hip.RNN_HALF_CHIP, hip.RNN_F16))
+    for batch in (9, 17, 27, 32):
+        if not hip.rnn_persistent_supported(cell, num_steps, batch, hidden):
+            continue
+        for fwd_flags, bwd_flags in variants:
+            a, b = data(batch, 10 + batch), data(batch, 20 + batch)
+            _, _, ws = both(a, None, fwd_flags, bwd_flags)
+            y2, d2, _ = both(b, ws, fwd_flags, bwd_flags)
+            y1, d1, _ = both(b, None, fwd_flags, bwd_flags)
+            assert torch.equal(y1, y2), (batch, fwd_flags)
+            assert torch.equal(d1, d2), (batch, bwd_flags)
+
+
 def test_staggered_launch_leaves_at_once_when_the_time_out_word_is_set(hip):
     """The sticky time-out word ends a staggered-tile launch like every other persistent launch
     (nothing written, no spinning), and the pass after the poll is whole again."""

@@ -20,7 +20,7 @@ RNN_DEFAULT, RNN_HALF_CHIP, RNN_WHOLE_CHIP, RNN_ONE_BARRIER = 0, 1, 2, 4   # rnn
 RNN_REDUCE_SCATTER = 8
 RNN_F16 = 16          # persistent LSTM / GRU kernels: the recurrent products as fp16x3 (ABI v5)
 RNN_XCD_SPLIT = 32    # fp16-pipe kernels: one direction per half of the XCDs
-RNN_STAGGER = 64      # fp16-pipe LSTM-1024 backward, 17..32 rows: tiles staggered by half a step
+RNN_STAGGER = 64      # fp16-pipe LSTM-1024 backward, 24 / 32 rows: tiles staggered by half a step
 RNN_KPAIR = 128       # ... and the K axis split over pairs of workgroups (ABI v7)
 CELL_IDS = {'rnn_relu': 0, 'rnn_tanh': 1, 'lstm': 2, 'gru': 3}
 CELL_GATES = {'rnn_relu': 1, 'rnn_tanh': 1, 'lstm': 4, 'gru': 3}

@@ -480,7 +480,7 @@ class CTCModel:
         # shorter in two alternating A/Bs: profiles/r04_ab.md)
         self.rnn_xcd_flag = hip.RNN_XCD_SPLIT \
             if os.environ.get('CTCASR_RNN_XCD_SPLIT', '1') == '1' else 0
-        # backward LSTM-1024 recurrence, 17..32 rows: the two 16-row tiles staggered by half a step
+        # backward LSTM-1024 recurrence, 24 or 32 rows: the two 16-row tiles staggered by half a step
         # (prnn_bwd16s_kernel; bit-identical results) instead of both behind one barrier
         self.rnn_stagger_flag = hip.RNN_STAGGER \
             if os.environ.get('CTCASR_RNN_STAGGER', '1') == '1' else 0

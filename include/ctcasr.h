@@ -229,7 +229,8 @@ int ctcasr_rnn_persistent_supported(int cell, int T, int B, int H);
 /* Synchronises the stream and returns CTCASR_ERR_TIMEOUT if ANY persistent launch that used
  * `workspace` since the previous poll abandoned a grid barrier (the results of that pass are then
  * invalid), else CTCASR_OK.  The time-out word is sticky across launches, layers and passes and
- * is cleared by this call. */
+ * is cleared by this call (after a time-out the barrier words and - ABI v7 - the write counts of
+ * the K-split kernels' hand-off slots are zero-filled with it). */
 int ctcasr_rnn_poll_error(void *workspace, size_t workspace_bytes, int cell, int T, int B,
                           int H, ctcasr_stream_t stream);
 /* Enqueues a one-lane gate kernel on `stream` that returns as soon as the persistent launch that

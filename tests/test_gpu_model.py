@@ -473,7 +473,7 @@ def test_the_reference_models_at_full_length(cell):
     assert decoded == octc.greedy_decode(t_logits.numpy(), [t_out] * batch)
 
 
-@pytest.mark.parametrize('cell,hidden,batch', [('lstm', 1024, 32), ('lstm', 1024, 20),
+@pytest.mark.parametrize('cell,hidden,batch', [('lstm', 1024, 32), ('lstm', 1024, 20), ('lstm', 1024, 24),
                                                ('lstm', 2048, 16), ('rnn_relu', 2048, 16)])
 def test_a_pass_reads_nothing_of_the_pass_before(cell, hidden, batch):
     """Workspaces, exchange buffers, packed operands and piece buffers are reused from pass to pass
